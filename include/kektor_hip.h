@@ -1,0 +1,196 @@
+/*
+ * kektor_hip.h -- C ABI of libkektor_hip.so: the MI355X (gfx950) HNSW / flat-scan search path
+ * that drops in behind KektorDB's hnsw.Index.SearchWithScores.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the upstream repo):
+ *
+ *   kdb_search_batch        hnsw.Index.SearchWithScores -> searchInternal -> searchLayerUnlocked
+ *                           pkg/core/hnsw/hnsw_index.go:343-366, 369-468, 2351-2611
+ *                           (interface: core.VectorIndex.SearchWithScores, pkg/core/vector_index.go:35;
+ *                            engine call sites pkg/engine/ops.go:1006 and :1296)
+ *   kdb_flat_scan_batch     BruteForceIndex.SearchWithScores, pkg/core/vector_index.go:104-140
+ *                           (the exact scan north_star routes filtered queries to)
+ *   kdb_distance_batch      the per-pair distance FFI of native/compute/include/kektordb_compute.h:8-11
+ *                           (squared_euclidean_f32 / dot_product_f32 / squared_euclidean_f16 /
+ *                            dot_product_i8, bound by pkg/core/distance/distance_rust.go:12-17,57-125),
+ *                           batched: B queries x C gathered candidate rows per call
+ *   kdb_index_upload_rows   Node.vec slices into mmap.VectorArena (pkg/core/hnsw/hnsw_index.go:602-633,
+ *                           pkg/storage/mmap/arena.go:378-447): same dense row-major row layout
+ *   kdb_index_upload_graph  Node.Connections (pkg/core/hnsw/hnsw_node.go:13-68) as exported by
+ *                           SnapshotData (hnsw_index.go:3064): per-level adjacency, entry point, maxLevel
+ *   kdb_index_mark_deleted  Node.Deleted soft delete (hnsw_index.go:2303)
+ *   kdb_index_build         addBatchInternal (hnsw_index.go:1479-2088), phases 1-4, on the GPU
+ *   kdb_merge_topk          the merge step of the id-range shard (no reference
+ *                           counterpart -- the reference is single process)
+ *
+ * Conventions (mirroring native/compute's embedder half, native/compute/src/embedder.rs:33-63):
+ *   - every function returns 0 on success and a negative kdb_status on failure; the message for the
+ *     calling thread is available from kdb_last_error(); nothing throws or unwinds across the ABI;
+ *   - the caller owns every buffer it passes; host inputs are consumed before the call returns
+ *     (cgo rule: Go memory need not stay pinned after the call);
+ *   - handles are opaque, usable from any thread, calls on one handle are serialised internally;
+ *   - ids are the reference's internal ids: uint32, 1-based, id 0 never names a vector
+ *     (hnsw_index.go:590); at most 2^30-1 ids per index;
+ *   - distances are returned as the RAW f32 accumulate: sum (q-x)^2 for KDB_METRIC_L2, the dot
+ *     product for KDB_METRIC_COSINE (f32), the f64-scaled cosine distance for int8.  The shim applies
+ *     the reference's f64 epilogue -- float64(sum) (distance_go.go:67) or 1.0-float64(dot)
+ *     (distance_go.go:127) -- when it fills types.SearchResult.Score (pkg/core/types/types.go:12-15).
+ *   - there is NO CPU fallback: every compute entry point fails with KDB_ERR_NO_DEVICE when no gfx950
+ *     device is visible.
+ */
+#ifndef KEKTOR_HIP_H
+#define KEKTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KDB_ABI_VERSION 1
+#if defined(__GNUC__)
+#define KDB_API __attribute__((visibility("default")))
+#else
+#define KDB_API
+#endif
+
+typedef enum {
+    KDB_OK = 0,
+    KDB_ERR_INVALID = -1,   /* bad argument */
+    KDB_ERR_NO_DEVICE = -2, /* no HIP device / not gfx950 */
+    KDB_ERR_HIP = -3,       /* a HIP runtime call failed */
+    KDB_ERR_OOM = -4,
+    KDB_ERR_STATE = -5,     /* e.g. search before a graph was uploaded */
+    KDB_ERR_UNSUPPORTED = -6
+} kdb_status;
+
+enum { KDB_METRIC_L2 = 0, KDB_METRIC_COSINE = 1 };       /* distance.Euclidean / distance.Cosine */
+enum { KDB_PREC_F32 = 0, KDB_PREC_F16 = 1, KDB_PREC_I8 = 2 }; /* arena.go:73-77 PrecFloat32/16/Int8 */
+
+/* kdb_search_batch flags */
+enum {
+    KDB_SEARCH_STRICT = 0,            /* one candidate expanded per step: the reference's best-first order */
+    KDB_SEARCH_NEEDS_REFINE = 1u << 0, /* apply the needsRefine ef boost (hnsw_index.go:387-399)            */
+    KDB_SEARCH_PREPARED = 1u << 1      /* queries are already in stored form (normalised); skip query prep  */
+};
+
+typedef struct kdb_index kdb_index;
+
+typedef struct {
+    uint32_t dim;
+    uint32_t metric;     /* KDB_METRIC_*  */
+    uint32_t precision;  /* KDB_PREC_*    */
+    uint32_t m;          /* 0 -> 16; mMax0 = 2m (hnsw_index.go:140-151) */
+    uint32_t ef_construction; /* 0 -> 200 */
+    uint32_t capacity;   /* largest internal id the index may hold */
+    int32_t device_id;   /* HIP device ordinal */
+    uint32_t reserved;
+} kdb_index_desc;
+
+/* Per-level CSR adjacency.  offsets[l] has count+2 entries: node i's neighbours at level l are
+ * neighbors[l][offsets[l][i] .. offsets[l][i+1]) (empty when levels[i] < l).  Lists keep the
+ * reference's stored order.                                                                     */
+typedef struct {
+    uint32_t count;        /* nodeCounter: ids 1..count exist                          */
+    uint32_t entry;        /* entrypointID                                             */
+    int32_t max_level;     /* maxLevel, -1 for an empty graph                          */
+    uint32_t reserved;
+    const uint8_t *levels;            /* [count+1], levels[0] ignored                  */
+    const uint64_t *const *offsets;   /* [max_level+1] pointers                        */
+    const uint32_t *const *neighbors; /* [max_level+1] pointers                        */
+    const uint64_t *deleted_bits;     /* NULL or ((count>>6)+1) words, bit id set = deleted */
+} kdb_graph_view;
+
+typedef struct {
+    uint64_t n_dist;       /* distance evaluations of the last search call             */
+    uint64_t n_hops;       /* expanded candidates of the last search call              */
+    uint64_t bytes;        /* algorithmic bytes of the last call   */
+    double last_kernel_ms; /* HIP-event duration of the dominant kernel of the last call */
+} kdb_counters;
+
+typedef struct {
+    uint32_t batch;         /* nodes inserted per GPU round (0 = auto)                 */
+    uint32_t ef_construction; /* 0 = index default                                     */
+    uint64_t seed;          /* level draw (hnsw_index.go:2616-2625 uses the global RNG) */
+    uint32_t flags;
+    uint32_t reserved;
+} kdb_build_params;
+
+KDB_API int kdb_abi_version(void);
+KDB_API int kdb_hip_device_count(void);
+KDB_API const char *kdb_last_error(void);
+
+KDB_API int kdb_index_create(const kdb_index_desc *desc, kdb_index **out);
+KDB_API void kdb_index_destroy(kdb_index *idx);
+
+/* Rows in stored form, row-major, `n` rows for ids first_id..first_id+n-1 (cosine/f32 rows already
+ * normalised, f16 as IEEE binary16 bits, int8 quantised).  *_dev takes a device pointer.          */
+KDB_API int kdb_index_upload_rows(kdb_index *idx, uint32_t first_id, uint32_t n, const void *rows);
+KDB_API int kdb_index_upload_rows_dev(kdb_index *idx, uint32_t first_id, uint32_t n, const void *d_rows);
+/* int8 only: quantizedNorms[id] (hnsw_index.go:3371-3377) and the quantizer's AbsMax.            */
+KDB_API int kdb_index_upload_norms(kdb_index *idx, uint32_t first_id, uint32_t n, const float *norms);
+KDB_API int kdb_index_set_quantizer(kdb_index *idx, float abs_max);
+KDB_API int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g);
+KDB_API int kdb_index_mark_deleted(kdb_index *idx, const uint32_t *ids, uint32_t n);
+/* Rows without a graph (flat scan only): declare ids 1..count present.                            */
+KDB_API int kdb_index_set_count(kdb_index *idx, uint32_t count);
+
+/* Copies the device graph back in the kdb_graph_view layout.  Call once with neighbors == NULL to
+ * get sizes: level_sizes[l] = number of neighbour ids at level l (array of max_level+1).         */
+KDB_API int kdb_index_graph_info(kdb_index *idx, uint32_t *count, uint32_t *entry, int32_t *max_level);
+KDB_API int kdb_index_download_graph(kdb_index *idx, uint8_t *levels, uint64_t *const *offsets,
+                             uint32_t *const *neighbors, uint64_t *level_sizes);
+KDB_API int kdb_index_download_rows(kdb_index *idx, uint32_t first_id, uint32_t n, void *rows);
+
+/* SearchWithScores for B queries.  queries: [B][dim] f32, un-normalised (the library performs the
+ * reference's query prep, hnsw_index.go:404-434).  allow_bits: NULL (nil allow-list) or
+ * ((count>>6)+1) uint64 words (a zero bitmap is the non-nil EMPTY list -> zero results).
+ * Outputs: out_ids/out_dist [B][k], out_count [B].                                               */
+KDB_API int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                     const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                     uint32_t *out_count);
+/* Same with every pointer in device memory, asynchronous on `stream` (a hipStream_t, may be NULL). */
+KDB_API int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
+                         const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
+                         float *d_out_dist, uint32_t *d_out_count, void *stream);
+/* Optional per-query instrumentation of the NEXT search call: device or host arrays [B] are filled
+ * with n_dist / n_hops per query (pass NULL to disable).                                          */
+KDB_API int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device);
+
+/* Exact scan over every non-deleted (and allowed) row.  An EMPTY allow list means "no filter"
+ * (vector_index.go:130).  k <= 128.                                                               */
+KDB_API int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k,
+                        const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                        uint32_t *out_count);
+KDB_API int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k,
+                            const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
+                            float *d_out_dist, uint32_t *d_out_count, void *stream);
+
+/* B queries x C candidate ids each (ids[B][C], id 0 = skip -> +inf): raw accumulates out[B][C].   */
+KDB_API int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t B, const uint32_t *ids, uint32_t C,
+                       uint32_t flags, float *out);
+KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids,
+                           uint32_t C, uint32_t flags, float *d_out, void *stream);
+
+/* GPU batched graph construction over rows 1..count already uploaded.                             */
+KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
+
+/* Shard merge: G per-shard results for B queries -> global top-k.  ids are already global ids.
+ * in_ids/in_dist: [G][B][k], in_count: [G][B]; keys ascend by (raw L2 sum) or descend by (dot)
+ * according to `metric`.  Host pointers.                                                          */
+KDB_API int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids,
+                   const float *in_dist, const uint32_t *in_count, uint32_t *out_ids, float *out_dist,
+                   uint32_t *out_count);
+KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
+                       const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
+                       float *d_out_dist, uint32_t *d_out_count, void *stream);
+
+KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
+/* Block until all work queued on the index's internal stream has finished. */
+KDB_API int kdb_index_sync(kdb_index *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEKTOR_HIP_H */

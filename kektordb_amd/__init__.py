@@ -1,0 +1,9 @@
+"""kektordb_amd -- MI355X (gfx950) native HNSW / flat-scan search path for KektorDB.
+
+Only what the hot path needs lives here: `csrc/` (hand-written HIP kernels + the C ABI of
+include/kektor_hip.h), `index.py` (host-side mirror of hnsw.Index for the search path) and
+`shard.py` (id-range shards + RCCL all-gather merge).  PyTorch is plumbing (device buffers,
+streams, torch.distributed), never the compute path.
+"""
+from ._lib import KdbError, build_library, load, LIB_PATH, ABI_SYMBOLS  # noqa: F401
+from .index import HipIndex, SearchResult, L2, COSINE, F32, F16, I8  # noqa: F401

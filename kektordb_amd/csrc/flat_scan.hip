@@ -1,0 +1,522 @@
+// flat_scan.hip -- exact brute-force scan for gfx950 (the filtered path of north_star; reference
+// semantics: BruteForceIndex.SearchWithScores, pkg/core/vector_index.go:104-140).
+//
+// Shape: scores[query][row] = Q . X^T is a true GEMM (every row is shared by all B queries), so it
+// runs on the f32-input matrix cores: v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fmaf chain).
+// A 256-thread workgroup owns a (128 rows x 128 queries) tile, 4 waves in a 2x2 grid, each wave a
+// 64x64 sub-tile (4x4 MFMA tiles, 64 accumulator VGPRs).  Operands are staged through LDS in
+// 128-byte full-line pieces (row stride 160 B => conflict-free ds_read_b128 fragment reads), the next
+// K-slab is prefetched into registers while the current one is multiplied.
+// The score tile never leaves the chip: a threshold filter (current k-th best per query) feeds an LDS
+// queue that the query's owner thread drains into its running top-k list.  One workgroup walks a
+// stripe of rows; per-stripe lists are merged by a second kernel (bitonic sort in LDS) which also
+// re-scores L2 finalists exactly.
+//
+// Accumulation order per (query,row): for s (16-element K block), for j<4, for g<4: k = 16s+4g+j
+// (oracle: orc_dot_f32_hipmfma).  blockIdx -> (stripe, query tile) is XCD-aware: the query tiles of
+// one stripe run on the same XCD so the stripe's rows are fetched from HBM once and shared in L2.
+#include "kdb_device.cuh"
+#include <math.h>
+
+namespace {
+
+constexpr int FS_TR = 128;          // rows per tile
+constexpr int FS_TQ = 128;          // queries per tile
+constexpr int FS_BK = 32;           // K slab (floats) per stage = 128 B per row
+constexpr int FS_LDS_STRIDE = 40;   // floats per LDS row (160 B)
+constexpr int FS_QCAP = 2048;       // survivor queue entries
+constexpr uint32_t FS_MAX_MERGE = 8192;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FsParams {
+    const uint32_t *scan_ids; // compacted ids (filter / deletes) or null = identity (id = r+1)
+    uint32_t n_scan;          // rows to scan
+    uint32_t rows_per_stripe; // multiple of FS_TR
+    uint32_t n_stripes, n_qtiles;
+    uint32_t B, kl;           // kl = per-stripe list length
+    float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
+    uint32_t *part_id;
+    uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
+};
+
+__device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint32_t id2) {
+    return (k1 < k2) || (k1 == k2 && id1 < id2);
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128][ld] prepared*/, FsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds_a = reinterpret_cast<float *>(smem);                       // [128][40]
+    float *lds_b = lds_a + FS_TR * FS_LDS_STRIDE;                         // [128][40]
+    float *tau = lds_b + FS_TQ * FS_LDS_STRIDE;                           // [128]
+    uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FS_TQ);         // [128] id of the current worst
+    float *q_key = reinterpret_cast<float *>(tau_id + FS_TQ);             // [QCAP]
+    uint32_t *q_row = reinterpret_cast<uint32_t *>(q_key + FS_QCAP);      // [QCAP]
+    uint32_t *q_q = q_row + FS_QCAP;                                      // [QCAP]
+    uint32_t *q_cnt = q_q + FS_QCAP;                                      // [4]
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wq = wave & 1; // wave position: rows half, queries half
+    const int fi = lane & 15, fg = lane >> 4;
+
+    // XCD-aware decode: blocks b, b+8, b+16, ... (same XCD) walk the query tiles of one stripe
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, local = bid >> 3;
+    const uint32_t stripe = (local / p.n_qtiles) * 8u + xcd;
+    const uint32_t qtile = local % p.n_qtiles;
+    if (stripe >= p.n_stripes) return;
+
+    const uint32_t row_begin = stripe * p.rows_per_stripe;
+    uint32_t row_end = row_begin + p.rows_per_stripe;
+    if (row_end > p.n_scan) row_end = p.n_scan;
+    const uint32_t q0 = qtile * FS_TQ;
+
+    // owner state: thread t < 128 owns query q0+t
+    const size_t list_base = ((size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid) * p.kl;
+    float *my_key = p.part_key + list_base;
+    uint32_t *my_id = p.part_id + list_base;
+    uint32_t my_cnt = 0, my_maxpos = 0;
+    float my_max = INFINITY;
+    uint32_t my_maxid = 0xffffffffu;
+    if (tid < FS_TQ) {
+        tau[tid] = INFINITY;
+        tau_id[tid] = 0xffffffffu;
+    }
+    if (tid == 0) q_cnt[0] = 0;
+
+    const float *rows = reinterpret_cast<const float *>(v.rows);
+    const uint32_t nslab = v.ld / FS_BK + ((v.ld % FS_BK) ? 1u : 0u); // ld is a multiple of 16; last slab may be half
+    // staging map: thread t loads float4 #(t%8) of rows t/8 + 32*i (i<4) of both operands
+    const int s_r = tid >> 3, s_c = tid & 7;
+
+    for (uint32_t tile = row_begin; tile < row_end; tile += FS_TR) {
+        // row ids of this thread's 4 staging rows
+        uint32_t a_id[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = tile + (uint32_t)(s_r + 32 * i);
+            a_id[i] = r < row_end ? (p.scan_ids ? p.scan_ids[r] : r + 1u) : 0u;
+        }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float4 ra[4], rb[4];
+        auto gload = [&](uint32_t slab) {
+            const uint32_t col = slab * FS_BK + (uint32_t)s_c * 4u;
+            const bool in = col < v.ld;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ra[i] = in ? *reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = in ? *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        gload(0);
+        for (uint32_t slab = 0; slab < nslab; slab++) {
+            __syncthreads(); // previous slab's fragment reads are done
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                *reinterpret_cast<float4 *>(lds_a + (s_r + 32 * i) * FS_LDS_STRIDE + s_c * 4) = ra[i];
+                *reinterpret_cast<float4 *>(lds_b + (s_r + 32 * i) * FS_LDS_STRIDE + s_c * 4) = rb[i];
+            }
+            __syncthreads();
+            if (slab + 1 < nslab) gload(slab + 1); // in flight during the MFMAs
+#pragma unroll
+            for (int s = 0; s < FS_BK / 16; s++) {
+                float4 fa[4], fb[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    fa[t] = *reinterpret_cast<const float4 *>(lds_a + (wr * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
+                    fb[t] = *reinterpret_cast<const float4 *>(lds_b + (wq * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        const float av = j == 0 ? fa[a].x : j == 1 ? fa[a].y : j == 2 ? fa[a].z : fa[a].w;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const float bv = j == 0 ? fb[b].x : j == 1 ? fb[b].y : j == 2 ? fb[b].z : fb[b].w;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- fused selection: lane holds, per MFMA tile (a,b): query qq = wq*64+b*16+fi,
+        //      rows rr = wr*64 + a*16 + fg*4 + r (r<4)
+        unsigned long long pend[4] = {0ull, 0ull, 0ull, 0ull}; // bit (b*4+r) of pend[a]
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t rr = tile + (uint32_t)(wr * 64 + a * 16 + fg * 4 + r);
+                const bool live = rr < row_end;
+                float nrm = 0.f;
+                if (METRIC == KDB_METRIC_L2) {
+                    const uint32_t rid = live ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
+                    nrm = v.norms[rid];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const float dotv = acc[a][b][r];
+                    // keys overwrite the accumulators: cosine -dot; L2 ||x||^2 - 2 q.x (ranking only)
+                    acc[a][b][r] = METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nrm);
+                    if (live) pend[a] |= 1ull << (b * 4 + r);
+                }
+            }
+        for (;;) {
+            __syncthreads(); // tau / queue stable
+            bool left = false;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int qq = wq * 64 + b * 16 + fi;
+                    const float t_k = tau[qq];
+                    const uint32_t t_id = tau_id[qq];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned long long bit = 1ull << (b * 4 + r);
+                        if (!(pend[a] & bit)) continue;
+                        const uint32_t rr = tile + (uint32_t)(wr * 64 + a * 16 + fg * 4 + r);
+                        const uint32_t rid = p.scan_ids ? p.scan_ids[rr] : rr + 1u;
+                        const float key = acc[a][b][r];
+                        if (!fs_better(key, rid, t_k, t_id)) {
+                            pend[a] &= ~bit; // cannot enter the list any more (tau only tightens)
+                            continue;
+                        }
+                        const uint32_t slot = atomicAdd(&q_cnt[0], 1u);
+                        if (slot < (uint32_t)FS_QCAP) {
+                            q_key[slot] = key;
+                            q_row[slot] = rid;
+                            q_q[slot] = (uint32_t)qq;
+                            pend[a] &= ~bit;
+                        } else {
+                            left = true; // queue full: retry next round
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            uint32_t nq = q_cnt[0];
+            if (nq > (uint32_t)FS_QCAP) nq = FS_QCAP;
+            if (tid < FS_TQ && nq) { // drain: the owner thread of each query takes its entries
+                for (uint32_t e = 0; e < nq; e++) {
+                    if (q_q[e] != (uint32_t)tid) continue;
+                    const float key = q_key[e];
+                    const uint32_t rid = q_row[e];
+                    if (my_cnt < p.kl) {
+                        my_key[my_cnt] = key;
+                        my_id[my_cnt] = rid;
+                        my_cnt++;
+                        if (my_cnt == p.kl) { // list full: find the worst
+                            my_max = my_key[0]; my_maxid = my_id[0]; my_maxpos = 0;
+                            for (uint32_t i = 1; i < p.kl; i++) {
+                                const float kk = my_key[i];
+                                const uint32_t ii = my_id[i];
+                                if (fs_better(my_max, my_maxid, kk, ii)) { my_max = kk; my_maxid = ii; my_maxpos = i; }
+                            }
+                        }
+                    } else if (fs_better(key, rid, my_max, my_maxid)) {
+                        my_key[my_maxpos] = key;
+                        my_id[my_maxpos] = rid;
+                        my_max = my_key[0]; my_maxid = my_id[0]; my_maxpos = 0;
+                        for (uint32_t i = 1; i < p.kl; i++) {
+                            const float kk = my_key[i];
+                            const uint32_t ii = my_id[i];
+                            if (fs_better(my_max, my_maxid, kk, ii)) { my_max = kk; my_maxid = ii; my_maxpos = i; }
+                        }
+                    }
+                }
+                if (my_cnt == p.kl) {
+                    tau[tid] = my_max;
+                    tau_id[tid] = my_maxid;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) q_cnt[0] = 0;
+            if (!__syncthreads_or(left ? 1 : 0)) break;
+        }
+    }
+    if (tid < FS_TQ) p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid] = my_cnt;
+}
+
+__device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id) {
+    uint32_t u = __float_as_uint(key);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving map
+    return ((unsigned long long)u << 32) | id;
+}
+__device__ __forceinline__ float fs_unpack_key(unsigned long long x) {
+    uint32_t u = (uint32_t)(x >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+// Merge the per-stripe lists of one query (block = 256 threads), re-score L2 finalists exactly in
+// the wave order, write the first k ascending by (distance, id).
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t k, uint32_t npow2,
+                  uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [npow2]
+    float *fin_d = reinterpret_cast<float *>(ent + npow2);                  // [256]
+    uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + 256);           // [256]
+    float *qlds = reinterpret_cast<float *>(fin_id + 256);                  // [ld]
+    uint32_t &total = *reinterpret_cast<uint32_t *>(qlds + v.ld);           // all LDS in the dynamic region
+    const uint32_t q = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) total = 0;
+    for (uint32_t i = (uint32_t)tid; i < npow2; i += 256) ent[i] = ~0ull;
+    __syncthreads();
+    const uint32_t qstride = p.n_qtiles * FS_TQ;
+    for (uint32_t s = 0; s < p.n_stripes; s++) {
+        const uint32_t c = p.part_cnt[(size_t)s * qstride + q];
+        uint32_t base = 0;
+        if (tid == 0) { base = total; total += c; }
+        __syncthreads();
+        base = total - c;
+        const size_t lb = ((size_t)s * qstride + q) * p.kl;
+        for (uint32_t i = (uint32_t)tid; i < c; i += 256) ent[base + i] = fs_pack(p.part_key[lb + i], p.part_id[lb + i]);
+        __syncthreads();
+    }
+    const uint32_t n = total;
+    // bitonic sort ascending
+    for (uint32_t sz = 2; sz <= npow2; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            for (uint32_t i = (uint32_t)tid; i < npow2 / 2; i += 256) {
+                const uint32_t lo = 2 * i - (i & (st - 1));
+                const uint32_t hi = lo + st;
+                const bool up = (lo & sz) == 0;
+                unsigned long long a = ent[lo], b = ent[hi];
+                if ((a > b) == up) { ent[lo] = b; ent[hi] = a; }
+            }
+        }
+    __syncthreads();
+    uint32_t nout = n < k ? n : k;
+    if (METRIC == KDB_METRIC_COSINE) {
+        for (uint32_t i = (uint32_t)tid; i < k; i += 256) {
+            if (i < nout) {
+                out_ids[(size_t)q * k + i] = (uint32_t)(ent[i] & 0xffffffffu);
+                out_dist[(size_t)q * k + i] = -fs_unpack_key(ent[i]); // raw dot
+            } else {
+                out_ids[(size_t)q * k + i] = 0u;
+                out_dist[(size_t)q * k + i] = INFINITY;
+            }
+        }
+    } else {
+        // exact re-score of the best nf = min(n, kl) by approximate key
+        uint32_t nf = n < p.kl ? n : p.kl;
+        if (nf > 256) nf = 256;
+        for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256)
+            reinterpret_cast<float4 *>(qlds)[i] = reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld)[i];
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, t = lane & 15;
+        for (uint32_t base = (uint32_t)wave * 4u; base < nf; base += 16u) {
+            const uint32_t r = base + (uint32_t)g;
+            const bool act = r < nf;
+            const uint32_t id = act ? (uint32_t)(ent[r] & 0xffffffffu) : 0u;
+            const float *row = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
+            float part = kdb_row_partial_f32<KDB_METRIC_L2>(row, qlds, v.ld, t);
+            part = kdb_reduce16(part);
+            if (act && t == 0) { fin_d[r] = part; fin_id[r] = id; }
+        }
+        __syncthreads();
+        if ((uint32_t)tid < nf) { // rank by counting
+            const float d = fin_d[tid];
+            const uint32_t id = fin_id[tid];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
+            if (rank < k) {
+                out_ids[(size_t)q * k + rank] = id;
+                out_dist[(size_t)q * k + rank] = d;
+            }
+        }
+        for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
+            out_ids[(size_t)q * k + i] = 0u;
+            out_dist[(size_t)q * k + i] = INFINITY;
+        }
+    }
+    if (tid == 0) out_count[q] = nout;
+}
+
+// ids of rows that are live (and allowed): wave-aggregated atomic compaction.  Order is arbitrary;
+// results do not depend on it because selection uses the total order (key, id).
+__global__ void compact_ids_kernel(const uint32_t *deleted, const uint32_t *allow, uint32_t count, uint32_t *out,
+                                   uint32_t *out_n) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x + 1u;
+    bool keep = id <= count;
+    if (keep && ((deleted[id >> 5] >> (id & 31)) & 1u)) keep = false;
+    if (keep && allow && !((allow[id >> 5] >> (id & 31)) & 1u)) keep = false;
+    const unsigned long long m = __ballot(keep);
+    if (!m) return;
+    uint32_t base = 0;
+    if (kdb_lane() == __builtin_ctzll(m)) base = atomicAdd(out_n, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, __builtin_ctzll(m), 64);
+    if (keep) out[base + kdb_mbcnt(m)] = id;
+}
+
+__global__ void any_bit_kernel(const uint32_t *bits, uint32_t words, uint32_t *out) {
+    bool f = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) f |= bits[i] != 0u;
+    if (__ballot(f) && kdb_lane() == 0) atomicOr(out, 1u);
+}
+
+// Shard merge: G lists of <=k per query -> top-k. One 64-thread block per query.
+__global__ void __launch_bounds__(64)
+merge_topk_kernel(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const float *in_dist,
+                  const uint32_t *in_count, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
+    const uint32_t q = blockIdx.x;
+    const int lane = kdb_lane();
+    uint32_t total = 0;
+    for (uint32_t g = 0; g < G; g++) total += in_count[(size_t)g * B + q];
+    const uint32_t nout = total < k ? total : k;
+    const uint32_t n = G * k;
+    for (uint32_t e = (uint32_t)lane; e < n; e += 64) {
+        const uint32_t g = e / k, i = e % k;
+        if (i >= in_count[(size_t)g * B + q]) continue;
+        const size_t off = ((size_t)g * B + q) * k + i;
+        const float d = in_dist[off];
+        const uint32_t id = in_ids[off];
+        const float key = metric == KDB_METRIC_COSINE ? -d : d;
+        uint32_t rank = 0;
+        for (uint32_t g2 = 0; g2 < G; g2++) {
+            const uint32_t c2 = in_count[(size_t)g2 * B + q];
+            const size_t o2 = ((size_t)g2 * B + q) * k;
+            for (uint32_t j = 0; j < c2; j++) {
+                const float d2 = in_dist[o2 + j];
+                const float key2 = metric == KDB_METRIC_COSINE ? -d2 : d2;
+                rank += fs_better(key2, in_ids[o2 + j], key, id) ? 1u : 0u;
+            }
+        }
+        if (rank < k) {
+            out_ids[(size_t)q * k + rank] = id;
+            out_dist[(size_t)q * k + rank] = d;
+        }
+    }
+    for (uint32_t i = nout + (uint32_t)lane; i < k; i += 64) {
+        out_ids[(size_t)q * k + i] = 0u;
+        out_dist[(size_t)q * k + i] = INFINITY;
+    }
+    if (lane == 0) out_count[q] = nout;
+}
+
+} // namespace
+
+int kdb_launch_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
+                          const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
+                          float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
+    if (B == 0) return KDB_OK;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, s, metric, G, B, k, d_in_ids, d_in_dist, d_in_count,
+                       d_out_ids, d_out_dist, d_out_count);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                         uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
+                         uint32_t *d_out_count, hipStream_t s) {
+    (void)d_qnorm;
+    if (v.precision != KDB_PREC_F32) {
+        kdb_set_error("flat scan: only float32 rows are supported in this version");
+        return KDB_ERR_UNSUPPORTED;
+    }
+    if (k == 0 || k > 128) {
+        kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
+        return KDB_ERR_INVALID;
+    }
+    if (B == 0) return KDB_OK;
+    const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
+    const uint32_t kl = v.metric == KDB_METRIC_COSINE ? k : (k + 16 > 144 ? 144 : k + 16);
+
+    // ---- scan list
+    uint32_t n_scan = v.count;
+    const uint32_t *scan_ids = nullptr;
+    // scratch layout: [scan_ids: count u32][n_scan word + flag (64 B)][partials]
+    const size_t ids_bytes = ((size_t)v.count * 4 + 255) / 256 * 256;
+    const bool need_ids = filter || idx->n_deleted > 0;
+    uint32_t stripes_max = FS_MAX_MERGE / kl;
+    if (stripes_max < 1) stripes_max = 1;
+    // stripes: enough workgroups to fill the chip twice, at least 8 tiles each, XCD multiple
+    uint32_t want = (2048 + n_qtiles - 1) / n_qtiles;
+    if (want > stripes_max) want = stripes_max;
+    const size_t max_part = (size_t)want * n_qtiles * FS_TQ;
+    const size_t part_bytes = max_part * kl * 8 + max_part * 4 + 1024;
+    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + part_bytes + (size_t)n_qtiles * FS_TQ * v.ld * 4 + 4096);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
+    // region 0 (queries, written by the caller) sits at the END of scratch: see kdb_api
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
+    uint32_t *d_nscan = reinterpret_cast<uint32_t *>(base + ids_bytes);
+    unsigned char *part = base + ids_bytes + 256;
+    if (need_ids) {
+        KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
+        const uint32_t *use_allow = filter ? d_allow : nullptr;
+        hipLaunchKernelGGL(compact_ids_kernel, dim3((v.count + 255) / 256), dim3(256), 0, s, v.deleted, use_allow, v.count,
+                           d_ids, d_nscan);
+        KDB_HIP(hipGetLastError());
+        KDB_HIP(hipMemcpyAsync(&n_scan, d_nscan, 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        scan_ids = d_ids;
+    }
+    if (n_scan == 0) {
+        KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
+        KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+        return KDB_OK;
+    }
+    uint32_t n_tiles = (n_scan + FS_TR - 1) / FS_TR;
+    uint32_t n_stripes = want;
+    if (n_stripes > (n_tiles + 7) / 8) n_stripes = (n_tiles + 7) / 8; // >= 8 tiles per stripe
+    if (n_stripes < 1) n_stripes = 1;
+    uint32_t tiles_per = (n_tiles + n_stripes - 1) / n_stripes;
+    n_stripes = (n_tiles + tiles_per - 1) / tiles_per;
+
+    FsParams p;
+    p.scan_ids = scan_ids;
+    p.n_scan = n_scan;
+    p.rows_per_stripe = tiles_per * FS_TR;
+    p.n_stripes = n_stripes;
+    p.n_qtiles = n_qtiles;
+    p.B = B;
+    p.kl = kl;
+    const size_t n_part = (size_t)n_stripes * n_qtiles * FS_TQ;
+    p.part_key = reinterpret_cast<float *>(part);
+    p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
+    p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
+
+    const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 8 + (size_t)FS_QCAP * 12 + 16;
+    const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
+    const uint32_t grid = stripes8 * n_qtiles;
+    KDB_HIP(hipEventRecord(idx->ev0, s));
+    if (v.metric == KDB_METRIC_COSINE) {
+        KDB_HIP(hipFuncSetAttribute((const void *)flat_scan_kernel<KDB_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(flat_scan_kernel<KDB_METRIC_COSINE>, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
+    } else {
+        KDB_HIP(hipFuncSetAttribute((const void *)flat_scan_kernel<KDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(flat_scan_kernel<KDB_METRIC_L2>, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
+    }
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipEventRecord(idx->ev1, s));
+    uint32_t npow2 = 64;
+    while (npow2 < n_stripes * kl) npow2 <<= 1;
+    const size_t mlds = (size_t)npow2 * 8 + 256 * 8 + (size_t)v.ld * 4 + 16;
+    if (v.metric == KDB_METRIC_COSINE) {
+        KDB_HIP(hipFuncSetAttribute((const void *)flat_merge_kernel<KDB_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(flat_merge_kernel<KDB_METRIC_COSINE>, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids, d_out_dist, d_out_count);
+    } else {
+        KDB_HIP(hipFuncSetAttribute((const void *)flat_merge_kernel<KDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(flat_merge_kernel<KDB_METRIC_L2>, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids, d_out_dist, d_out_count);
+    }
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}

@@ -1,0 +1,828 @@
+// kdb_api.hip -- host side of the C ABI declared in include/kektor_hip.h.
+// Memory layout in HBM (one index):
+//   rows     (cap+1) x ld elements, row-major, row 0 and the pad columns zero  (arena row layout,
+//            pkg/storage/mmap/arena.go:403-404, with the 64-byte chunk headers stripped)
+//   adj0     (cap+1) x mMax0 uint32, level-0 neighbour ids in stored order, 0 = empty slot
+//   adj_up   upper-level pool, m uint32 per (node, level>=1) slot; up_idx[id] = first slot of a node
+//   levels   (cap+1) uint8;  deleted: bitset;  norms: (cap+1) f32 (int8 norms / L2 row norms)
+//   visited  one bitset of (cap>>5)+1 words per resident search wave
+#include "kdb_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void kdb_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *kdb_last_error(void) { return g_err; }
+extern "C" int kdb_abi_version(void) { return KDB_ABI_VERSION; }
+
+extern "C" int kdb_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int check_device(int dev) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        kdb_set_error("no HIP device visible: libkektor_hip has no CPU fallback");
+        return KDB_ERR_NO_DEVICE;
+    }
+    if (dev < 0 || dev >= n) {
+        kdb_set_error("device_id %d out of range (0..%d)", dev, n - 1);
+        return KDB_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    KDB_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        kdb_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        return KDB_ERR_NO_DEVICE;
+    }
+    return KDB_OK;
+}
+
+#define KDB_CHECK_IDX(idx)                       \
+    do {                                         \
+        if (!(idx)) {                            \
+            kdb_set_error("null index handle");  \
+            return KDB_ERR_INVALID;              \
+        }                                        \
+    } while (0)
+
+KdbView kdb_make_view(const kdb_index *idx) {
+    KdbView v;
+    v.rows = idx->d_rows;
+    v.norms = idx->d_norms;
+    v.adj0 = idx->d_adj0;
+    v.adj_up = idx->d_adj_up;
+    v.up_idx = idx->d_up_idx;
+    v.levels = idx->d_levels;
+    v.deleted = idx->d_deleted;
+    v.dim = idx->desc.dim;
+    v.ld = idx->ld;
+    v.deg0 = idx->deg0;
+    v.deg_up = idx->deg_up;
+    v.count = idx->count;
+    v.entry = idx->entry;
+    v.max_level = idx->max_level;
+    v.metric = idx->desc.metric;
+    v.precision = idx->desc.precision;
+    v.vis_words = (idx->cap >> 5) + 1;
+    v.vis_words = (v.vis_words + 3u) & ~3u;
+    v.q_absmax = idx->absmax;
+    return v;
+}
+
+int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
+    if (idx->scratch_bytes >= bytes) return KDB_OK;
+    if (idx->d_scratch) {
+        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipFree(idx->d_scratch));
+        idx->d_scratch = nullptr;
+        idx->scratch_bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    KDB_HIP(hipMalloc(&idx->d_scratch, want));
+    idx->scratch_bytes = want;
+    return KDB_OK;
+}
+
+int kdb_ensure_visited(kdb_index *idx, uint32_t slots) {
+    if (idx->vis_slots >= slots) return KDB_OK;
+    if (idx->d_visited) {
+        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipFree(idx->d_visited));
+        idx->d_visited = nullptr;
+        idx->vis_slots = 0;
+    }
+    uint32_t words = (((idx->cap >> 5) + 1) + 3u) & ~3u;
+    KDB_HIP(hipMalloc(&idx->d_visited, (size_t)slots * words * 4));
+    KDB_HIP(hipMemsetAsync(idx->d_visited, 0, (size_t)slots * words * 4, idx->stream));
+    idx->vis_slots = slots;
+    return KDB_OK;
+}
+
+static int ensure_qbuf(kdb_index *idx, size_t bytes) {
+    if (idx->qbuf_bytes >= bytes) return KDB_OK;
+    if (idx->d_qbuf) {
+        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipFree(idx->d_qbuf));
+        idx->d_qbuf = nullptr;
+        idx->qbuf_bytes = 0;
+    }
+    KDB_HIP(hipMalloc(&idx->d_qbuf, bytes + bytes / 4));
+    idx->qbuf_bytes = bytes + bytes / 4;
+    return KDB_OK;
+}
+
+static int ensure_iobuf(kdb_index *idx, size_t bytes) {
+    if (idx->iobuf_bytes >= bytes) return KDB_OK;
+    if (idx->d_iobuf) {
+        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipFree(idx->d_iobuf));
+        idx->d_iobuf = nullptr;
+        idx->iobuf_bytes = 0;
+    }
+    KDB_HIP(hipMalloc(&idx->d_iobuf, bytes + bytes / 4));
+    idx->iobuf_bytes = bytes + bytes / 4;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
+    if (!desc || !out) {
+        kdb_set_error("kdb_index_create: null argument");
+        return KDB_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (desc->dim == 0 || desc->capacity == 0 || desc->capacity > KDB_ID_MASK - 1) {
+        kdb_set_error("kdb_index_create: dim and capacity must be > 0 (capacity < 2^30)");
+        return KDB_ERR_INVALID;
+    }
+    // hnsw.New validation (hnsw_index.go:203-229): f16 only euclidean, int8 only cosine
+    if (desc->precision > KDB_PREC_I8 || desc->metric > KDB_METRIC_COSINE) {
+        kdb_set_error("unsupported precision/metric enum");
+        return KDB_ERR_INVALID;
+    }
+    if (desc->precision == KDB_PREC_F16 && desc->metric != KDB_METRIC_L2) {
+        kdb_set_error("precision 'float16' only supports the 'euclidean' metric");
+        return KDB_ERR_INVALID;
+    }
+    if (desc->precision == KDB_PREC_I8 && desc->metric != KDB_METRIC_COSINE) {
+        kdb_set_error("precision 'int8' only supports the 'cosine' metric");
+        return KDB_ERR_INVALID;
+    }
+    uint32_t m = desc->m ? desc->m : 16;
+    if (2 * m > KDB_MAX_DEG0) {
+        kdb_set_error("m=%u too large (mMax0 = 2m must be <= %u)", m, KDB_MAX_DEG0);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    int rc = check_device(desc->device_id);
+    if (rc) return rc;
+    KDB_HIP(hipSetDevice(desc->device_id));
+    kdb_index *idx = new (std::nothrow) kdb_index();
+    if (!idx) return KDB_ERR_OOM;
+    idx->desc = *desc;
+    idx->desc.m = m;
+    if (!idx->desc.ef_construction) idx->desc.ef_construction = 200;
+    idx->device = desc->device_id;
+    idx->cap = desc->capacity;
+    idx->deg0 = 2 * m;
+    idx->deg_up = m;
+    idx->elem = desc->precision == KDB_PREC_F32 ? 4 : desc->precision == KDB_PREC_F16 ? 2 : 1;
+    idx->ld = (desc->dim + 15u) & ~15u;
+    auto fail = [&](int code) {
+        kdb_index_destroy(idx);
+        return code;
+    };
+#define KDB_TRY(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            kdb_set_error("%s failed: %s", #call, hipGetErrorString(_e));                              \
+            return fail(_e == hipErrorOutOfMemory ? KDB_ERR_OOM : KDB_ERR_HIP);                        \
+        }                                                                                              \
+    } while (0)
+    const size_t n1 = (size_t)idx->cap + 1;
+    KDB_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    KDB_TRY(hipEventCreate(&idx->ev0));
+    KDB_TRY(hipEventCreate(&idx->ev1));
+    KDB_TRY(hipMalloc(&idx->d_rows, n1 * idx->ld * idx->elem));
+    KDB_TRY(hipMemsetAsync(idx->d_rows, 0, (size_t)idx->ld * idx->elem, idx->stream)); // row 0
+    KDB_TRY(hipMalloc(&idx->d_norms, n1 * 4));
+    KDB_TRY(hipMemsetAsync(idx->d_norms, 0, n1 * 4, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_adj0, n1 * idx->deg0 * 4));
+    KDB_TRY(hipMemsetAsync(idx->d_adj0, 0, n1 * idx->deg0 * 4, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_up_idx, n1 * 4));
+    KDB_TRY(hipMemsetAsync(idx->d_up_idx, 0, n1 * 4, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_levels, n1));
+    KDB_TRY(hipMemsetAsync(idx->d_levels, 0, n1, idx->stream));
+    const size_t dw = ((n1 + 31) / 32 + 3) & ~(size_t)3;
+    KDB_TRY(hipMalloc(&idx->d_deleted, dw * 4));
+    KDB_TRY(hipMemsetAsync(idx->d_deleted, 0, dw * 4, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_work, 64 * 4));
+    KDB_TRY(hipMemsetAsync(idx->d_work, 0, 64 * 4, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_ctr, 64));
+    KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, 64, idx->stream));
+    KDB_TRY(hipStreamSynchronize(idx->stream));
+#undef KDB_TRY
+    *out = idx;
+    return KDB_OK;
+}
+
+extern "C" void kdb_index_destroy(kdb_index *idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
+                    idx->d_deleted, idx->d_visited, idx->d_scratch, idx->d_work,  idx->d_ctr,    idx->d_qbuf,
+                    idx->d_iobuf, idx->d_build};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const void *rows, hipMemcpyKind kind) {
+    KDB_CHECK_IDX(idx);
+    if (n == 0) return KDB_OK;
+    if (!rows || first_id == 0 || (uint64_t)first_id + n - 1 > idx->cap) {
+        kdb_set_error("upload_rows: ids %u..%llu outside 1..%u", first_id, (unsigned long long)first_id + n - 1, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    const size_t rb = (size_t)idx->desc.dim * idx->elem, lb = (size_t)idx->ld * idx->elem;
+    unsigned char *dst = reinterpret_cast<unsigned char *>(idx->d_rows) + (size_t)first_id * lb;
+    if (lb != rb) KDB_HIP(hipMemsetAsync(dst, 0, (size_t)n * lb, idx->stream)); // zero the pad columns
+    KDB_HIP(hipMemcpy2DAsync(dst, lb, rows, rb, rb, n, kind, idx->stream));
+    if (idx->desc.precision == KDB_PREC_F32 && idx->desc.metric == KDB_METRIC_L2) {
+        KdbView v = kdb_make_view(idx);
+        int rc = kdb_launch_row_norms(v, idx->d_norms, first_id, n, idx->stream);
+        if (rc) return rc;
+    }
+    KDB_HIP(hipStreamSynchronize(idx->stream)); // host rows are consumed before returning (cgo rule)
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_upload_rows(kdb_index *idx, uint32_t first_id, uint32_t n, const void *rows) {
+    return upload_rows_impl(idx, first_id, n, rows, hipMemcpyHostToDevice);
+}
+extern "C" int kdb_index_upload_rows_dev(kdb_index *idx, uint32_t first_id, uint32_t n, const void *d_rows) {
+    return upload_rows_impl(idx, first_id, n, d_rows, hipMemcpyDeviceToDevice);
+}
+
+extern "C" int kdb_index_download_rows(kdb_index *idx, uint32_t first_id, uint32_t n, void *rows) {
+    KDB_CHECK_IDX(idx);
+    if (n == 0) return KDB_OK;
+    if (!rows || first_id == 0 || (uint64_t)first_id + n - 1 > idx->cap) {
+        kdb_set_error("download_rows: bad id range");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    const size_t rb = (size_t)idx->desc.dim * idx->elem, lb = (size_t)idx->ld * idx->elem;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(idx->d_rows) + (size_t)first_id * lb;
+    KDB_HIP(hipMemcpy2DAsync(rows, rb, src, lb, rb, n, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_upload_norms(kdb_index *idx, uint32_t first_id, uint32_t n, const float *norms) {
+    KDB_CHECK_IDX(idx);
+    if (idx->desc.precision != KDB_PREC_I8) {
+        kdb_set_error("upload_norms: only int8 indexes carry stored norms");
+        return KDB_ERR_INVALID;
+    }
+    if (!norms || first_id == 0 || (uint64_t)first_id + n - 1 > idx->cap) {
+        kdb_set_error("upload_norms: bad id range");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    KDB_HIP(hipMemcpyAsync(idx->d_norms + first_id, norms, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_set_quantizer(kdb_index *idx, float abs_max) {
+    KDB_CHECK_IDX(idx);
+    idx->absmax = abs_max;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
+    KDB_CHECK_IDX(idx);
+    if (count > idx->cap) {
+        kdb_set_error("set_count: %u exceeds capacity %u", count, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->count = count;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
+    KDB_CHECK_IDX(idx);
+    if (!g || g->count > idx->cap || (g->count && (!g->levels || !g->offsets || !g->neighbors))) {
+        kdb_set_error("upload_graph: bad graph view (count %u, capacity %u)", g ? g->count : 0, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    if (g->max_level >= 0 && (g->entry == 0 || g->entry > g->count)) {
+        kdb_set_error("upload_graph: entry point %u outside 1..%u", g->entry, g->count);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    const uint32_t n = g->count;
+    const size_t n1 = (size_t)n + 1;
+    std::vector<uint32_t> adj0(n1 * idx->deg0, 0u);
+    std::vector<uint32_t> up_idx(n1, 0u);
+    std::vector<uint8_t> levels(n1, 0);
+    size_t slots = 0;
+    for (uint32_t i = 1; i <= n; i++) {
+        int lv = g->levels[i];
+        if (lv > g->max_level) lv = g->max_level < 0 ? 0 : g->max_level;
+        levels[i] = (uint8_t)lv;
+        up_idx[i] = (uint32_t)slots;
+        slots += (size_t)lv;
+    }
+    std::vector<uint32_t> adj_up(slots * idx->deg_up + 1, 0u);
+    for (int l = 0; l <= g->max_level; l++) {
+        const uint64_t *off = g->offsets[l];
+        const uint32_t *nb = g->neighbors[l];
+        const uint32_t cap = l == 0 ? idx->deg0 : idx->deg_up;
+        for (uint32_t i = 1; i <= n; i++) {
+            if ((int)levels[i] < l) continue;
+            const uint64_t a = off[i], b = off[i + 1];
+            if (b - a > cap) {
+                kdb_set_error("upload_graph: node %u has %llu links at level %d (cap %u)", i, (unsigned long long)(b - a), l, cap);
+                return KDB_ERR_INVALID;
+            }
+            uint32_t *dst = l == 0 ? &adj0[(size_t)i * idx->deg0] : &adj_up[((size_t)up_idx[i] + (size_t)(l - 1)) * idx->deg_up];
+            for (uint64_t e = a; e < b; e++) {
+                if (nb[e] == 0 || nb[e] > n) {
+                    kdb_set_error("upload_graph: neighbour id %u of node %u out of range", nb[e], i);
+                    return KDB_ERR_INVALID;
+                }
+                dst[e - a] = nb[e];
+            }
+        }
+    }
+    if (slots > idx->up_slots_cap) {
+        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
+        idx->d_adj_up = nullptr;
+        KDB_HIP(hipMalloc(&idx->d_adj_up, (slots * idx->deg_up + 1) * 4));
+        idx->up_slots_cap = slots;
+    } else if (!idx->d_adj_up) {
+        KDB_HIP(hipMalloc(&idx->d_adj_up, 4 * (size_t)idx->deg_up + 4));
+    }
+    idx->up_slots = slots;
+    KDB_HIP(hipMemcpyAsync(idx->d_adj0, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, idx->stream));
+    if (slots) KDB_HIP(hipMemcpyAsync(idx->d_adj_up, adj_up.data(), slots * idx->deg_up * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipMemcpyAsync(idx->d_up_idx, up_idx.data(), n1 * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipMemcpyAsync(idx->d_levels, levels.data(), n1, hipMemcpyHostToDevice, idx->stream));
+    // deleted bits: uint64 words, bit id -> uint32 words (little endian: same bytes)
+    const size_t dw32 = ((n1 + 31) / 32 + 3) & ~(size_t)3;
+    std::vector<uint32_t> del(dw32, 0u);
+    uint32_t ndel = 0;
+    if (g->deleted_bits) {
+        for (uint32_t i = 1; i <= n; i++)
+            if ((g->deleted_bits[i >> 6] >> (i & 63)) & 1ull) {
+                del[i >> 5] |= 1u << (i & 31);
+                ndel++;
+            }
+    }
+    KDB_HIP(hipMemcpyAsync(idx->d_deleted, del.data(), dw32 * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    idx->n_deleted = ndel;
+    idx->count = n;
+    idx->entry = g->entry;
+    idx->max_level = g->max_level;
+    idx->has_graph = true;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_mark_deleted(kdb_index *idx, const uint32_t *ids, uint32_t n) {
+    KDB_CHECK_IDX(idx);
+    if (n == 0) return KDB_OK;
+    if (!ids) return KDB_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    const size_t n1 = (size_t)idx->cap + 1;
+    const size_t dw32 = ((n1 + 31) / 32 + 3) & ~(size_t)3;
+    std::vector<uint32_t> del(dw32);
+    KDB_HIP(hipMemcpyAsync(del.data(), idx->d_deleted, dw32 * 4, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        if (ids[i] == 0 || ids[i] > idx->count) continue;
+        uint32_t &w = del[ids[i] >> 5];
+        if (!(w & (1u << (ids[i] & 31)))) {
+            w |= 1u << (ids[i] & 31);
+            idx->n_deleted++;
+        }
+    }
+    KDB_HIP(hipMemcpyAsync(idx->d_deleted, del.data(), dw32 * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_graph_info(kdb_index *idx, uint32_t *count, uint32_t *entry, int32_t *max_level) {
+    KDB_CHECK_IDX(idx);
+    if (count) *count = idx->count;
+    if (entry) *entry = idx->entry;
+    if (max_level) *max_level = idx->max_level;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_download_graph(kdb_index *idx, uint8_t *levels, uint64_t *const *offsets,
+                                        uint32_t *const *neighbors, uint64_t *level_sizes) {
+    KDB_CHECK_IDX(idx);
+    if (!idx->has_graph) {
+        kdb_set_error("download_graph: no graph present");
+        return KDB_ERR_STATE;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    const uint32_t n = idx->count;
+    const size_t n1 = (size_t)n + 1;
+    std::vector<uint32_t> adj0(n1 * idx->deg0), up_idx(n1), adj_up(idx->up_slots * idx->deg_up + 1);
+    std::vector<uint8_t> lv(n1);
+    KDB_HIP(hipMemcpyAsync(adj0.data(), idx->d_adj0, adj0.size() * 4, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipMemcpyAsync(up_idx.data(), idx->d_up_idx, n1 * 4, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipMemcpyAsync(lv.data(), idx->d_levels, n1, hipMemcpyDeviceToHost, idx->stream));
+    if (idx->up_slots)
+        KDB_HIP(hipMemcpyAsync(adj_up.data(), idx->d_adj_up, idx->up_slots * idx->deg_up * 4, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    if (levels) memcpy(levels, lv.data(), n1);
+    for (int l = 0; l <= idx->max_level; l++) {
+        uint64_t tot = 0;
+        const uint32_t cap = l == 0 ? idx->deg0 : idx->deg_up;
+        for (uint32_t i = 0; i <= n; i++) {
+            if (offsets && offsets[l]) offsets[l][i] = tot;
+            if (i == 0 || (int)lv[i] < l) continue;
+            const uint32_t *src = l == 0 ? &adj0[(size_t)i * idx->deg0] : &adj_up[((size_t)up_idx[i] + (size_t)(l - 1)) * idx->deg_up];
+            for (uint32_t e = 0; e < cap && src[e] != 0; e++) {
+                if (neighbors && neighbors[l]) neighbors[l][tot] = src[e];
+                tot++;
+            }
+        }
+        if (offsets && offsets[l]) offsets[l][n + 1] = tot;
+        if (level_sizes) level_sizes[l] = tot;
+    }
+    return KDB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Search
+// ---------------------------------------------------------------------------------------------
+static size_t qrow_bytes(const kdb_index *idx) {
+    return idx->desc.precision == KDB_PREC_I8 ? ((size_t)idx->ld + 15) / 16 * 16 : (size_t)idx->ld * 4;
+}
+
+// prepared queries live in idx->d_qbuf: [Bpad rows][qrow_bytes] then qnorm [Bpad]
+static int prepare_queries(kdb_index *idx, const KdbView &v, const float *d_queries, uint32_t B, uint32_t Bpad,
+                           uint32_t flags, void **d_q, float **d_qnorm, hipStream_t s) {
+    const size_t qb = qrow_bytes(idx);
+    int rc = ensure_qbuf(idx, (size_t)Bpad * qb + (size_t)Bpad * 4 + 256);
+    if (rc) return rc;
+    *d_q = idx->d_qbuf;
+    *d_qnorm = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(idx->d_qbuf) + (((size_t)Bpad * qb + 255) & ~(size_t)255));
+    if (Bpad > B) KDB_HIP(hipMemsetAsync(reinterpret_cast<unsigned char *>(idx->d_qbuf) + (size_t)B * qb, 0, (size_t)(Bpad - B) * qb, s));
+    return kdb_launch_prep_queries(v, d_queries, B, *d_q, *d_qnorm, (flags & KDB_SEARCH_PREPARED) ? 0 : 1, s);
+}
+
+static uint32_t effective_ef(uint32_t ef, uint32_t flags) {
+    if (flags & KDB_SEARCH_NEEDS_REFINE) { // hnsw_index.go:387-399
+        uint32_t boosted = 2 * ef;
+        if (boosted < 80) boosted = 80;
+        if (boosted > 200) boosted = 200;
+        if (boosted > ef) ef = boosted;
+    }
+    return ef;
+}
+
+static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
+                             const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids, float *d_out_dist,
+                             uint32_t *d_out_count, hipStream_t s) {
+    KdbView v = kdb_make_view(idx);
+    if (B == 0) return KDB_OK;
+    if (k == 0) {
+        kdb_set_error("search: k must be >= 1");
+        return KDB_ERR_INVALID;
+    }
+    if (idx->max_level < 0 || idx->count == 0) { // empty index returns [] (hnsw_index.go:383-385)
+        KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
+        KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+        return KDB_OK;
+    }
+    if (!idx->has_graph) {
+        kdb_set_error("search: no graph uploaded or built");
+        return KDB_ERR_STATE;
+    }
+    uint32_t entry = idx->entry;
+    const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
+    if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447)
+        uint32_t first = 0xffffffffu;
+        int rc = kdb_launch_first_allowed(d_allow, 2 * ((idx->count >> 6) + 1), idx->d_work + 8, s);
+        if (rc) return rc;
+        uint32_t ep_word = 0;
+        KDB_HIP(hipMemcpyAsync(&first, idx->d_work + 8, 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipMemcpyAsync(&ep_word, d_allow + (entry >> 5), 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        const bool ep_allowed = ((ep_word >> (entry & 31)) & 1u) != 0;
+        // empty bitmap -> no results; an id-0 bit or ids beyond count never name a vector, so the
+        // reference's searchLayer would fail on the nil entry node and return [] as well
+        if (first == 0xffffffffu || (!ep_allowed && (first == 0 || first > idx->count))) {
+            KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
+            KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+            return KDB_OK;
+        }
+        if (!ep_allowed) entry = first;
+    }
+    void *d_q = nullptr;
+    float *d_qnorm = nullptr;
+    int rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_q, &d_qnorm, s);
+    if (rc) return rc;
+    uint32_t *tr_nd = nullptr, *tr_nh = nullptr;
+    if (idx->trace_ndist && idx->trace_on_device) {
+        tr_nd = idx->trace_ndist;
+        tr_nh = idx->trace_nhops;
+    } else if (idx->trace_ndist) {
+        rc = kdb_ensure_scratch(idx, (size_t)B * 8 + 64);
+        if (rc) return rc;
+        tr_nd = reinterpret_cast<uint32_t *>(idx->d_scratch);
+        tr_nh = tr_nd + B;
+    }
+    rc = kdb_launch_search(idx, v, d_q, d_qnorm, B, k, effective_ef(ef, flags), d_allow, entry, d_out_ids, d_out_dist,
+                           d_out_count, tr_nd, tr_nh, s);
+    if (rc) return rc;
+    if (idx->trace_ndist && !idx->trace_on_device) {
+        KDB_HIP(hipMemcpyAsync(idx->trace_ndist, tr_nd, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        if (idx->trace_nhops) KDB_HIP(hipMemcpyAsync(idx->trace_nhops, tr_nh, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    }
+    idx->last_kind = 1;
+    idx->last_B = B;
+    return KDB_OK;
+}
+
+extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
+                                    const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
+                                    float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B && (!d_queries || !d_out_ids || !d_out_dist || !d_out_count)) {
+        kdb_set_error("search: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    return search_dev_locked(idx, d_queries, B, k, ef, d_allow_bits, flags, d_out_ids, d_out_dist, d_out_count, s);
+}
+
+// host-pointer wrapper: stage in, run, stage out (inputs consumed before return)
+template <typename F>
+static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits,
+                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run) {
+    const size_t qbytes = (size_t)B * idx->desc.dim * 4;
+    const size_t aw = allow_bits ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
+    const size_t obytes = (size_t)B * k * 8 + (size_t)B * 4;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    int rc = ensure_iobuf(idx, al(qbytes) + al(aw) + al(obytes) + 1024);
+    if (rc) return rc;
+    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
+    float *d_q = reinterpret_cast<float *>(p);
+    uint64_t *d_allow = allow_bits ? reinterpret_cast<uint64_t *>(p + al(qbytes)) : nullptr;
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + al(qbytes) + al(aw));
+    float *d_dist = reinterpret_cast<float *>(d_ids + (size_t)B * k);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_dist + (size_t)B * k);
+    hipStream_t s = idx->stream;
+    KDB_HIP(hipMemcpyAsync(d_q, queries, qbytes, hipMemcpyHostToDevice, s));
+    if (allow_bits) KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, s));
+    rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
+    if (rc) return rc;
+    KDB_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    return KDB_OK;
+}
+
+extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                                uint32_t *out_count) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0) return KDB_OK;
+    if (!queries || !out_ids || !out_dist || !out_count || k == 0) {
+        kdb_set_error("search: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
+                          [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
+                              return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
+                          });
+}
+
+extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->trace_ndist = per_query_ndist;
+    idx->trace_nhops = per_query_nhops;
+    idx->trace_on_device = on_device;
+    return KDB_OK;
+}
+
+static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, const uint64_t *d_allow_bits,
+                           uint32_t flags, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
+    KdbView v = kdb_make_view(idx);
+    if (B == 0) return KDB_OK;
+    if (idx->count == 0) {
+        KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
+        KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+        return KDB_OK;
+    }
+    int filter = 0;
+    const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
+    if (d_allow) { // allowList.IsEmpty() => no filter (vector_index.go:130)
+        uint32_t first = 0xffffffffu;
+        int rc = kdb_launch_first_allowed(d_allow, 2 * ((idx->count >> 6) + 1), idx->d_work + 8, s);
+        if (rc) return rc;
+        KDB_HIP(hipMemcpyAsync(&first, idx->d_work + 8, 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        filter = first != 0xffffffffu;
+    }
+    const uint32_t Bpad = (B + 127u) & ~127u;
+    void *d_q = nullptr;
+    float *d_qnorm = nullptr;
+    int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
+    if (rc) return rc;
+    rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, filter, d_out_ids, d_out_dist, d_out_count, s);
+    if (rc) return rc;
+    idx->last_kind = 2;
+    idx->last_B = B;
+    return KDB_OK;
+}
+
+extern "C" int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k,
+                                       const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
+                                       float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B && (!d_queries || !d_out_ids || !d_out_dist || !d_out_count)) {
+        kdb_set_error("flat_scan: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    return flat_dev_locked(idx, d_queries, B, k, d_allow_bits, flags, d_out_ids, d_out_dist, d_out_count, s);
+}
+
+extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k,
+                                   const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                                   uint32_t *out_count) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0) return KDB_OK;
+    if (!queries || !out_ids || !out_dist || !out_count || k == 0) {
+        kdb_set_error("flat_scan: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
+                          [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
+                              return flat_dev_locked(idx, d_q, B, k, d_allow, flags, d_ids, d_dist, d_cnt, s);
+                          });
+}
+
+extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids,
+                                      uint32_t C, uint32_t flags, float *d_out, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0 || C == 0) return KDB_OK;
+    if (!d_queries || !d_ids || !d_out) {
+        kdb_set_error("distance_batch: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    KdbView v = kdb_make_view(idx);
+    void *d_q = nullptr;
+    float *d_qnorm = nullptr;
+    int rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_q, &d_qnorm, s);
+    if (rc) return rc;
+    KDB_HIP(hipEventRecord(idx->ev0, s));
+    rc = kdb_launch_distance(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
+    if (rc) return rc;
+    KDB_HIP(hipEventRecord(idx->ev1, s));
+    idx->last_kind = 3;
+    idx->last_B = B;
+    idx->last_C = C;
+    return KDB_OK;
+}
+
+extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t B, const uint32_t *ids, uint32_t C,
+                                  uint32_t flags, float *out) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0 || C == 0) return KDB_OK;
+    if (!queries || !ids || !out) {
+        kdb_set_error("distance_batch: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        KDB_HIP(hipSetDevice(idx->device));
+        const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
+        const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
+        int rc = ensure_iobuf(idx, qbytes + 2 * ibytes + 256);
+        if (rc) return rc;
+    }
+    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
+    const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
+    const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
+    float *d_q = reinterpret_cast<float *>(p);
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + qbytes);
+    float *d_out = reinterpret_cast<float *>(p + qbytes + ibytes);
+    KDB_HIP(hipMemcpyAsync(d_q, queries, (size_t)B * idx->desc.dim * 4, hipMemcpyHostToDevice, idx->stream));
+    KDB_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * C * 4, hipMemcpyHostToDevice, idx->stream));
+    int rc = kdb_distance_batch_dev(idx, d_q, B, d_ids, C, flags, d_out, idx->stream);
+    if (rc) return rc;
+    KDB_HIP(hipMemcpyAsync(out, d_out, (size_t)B * C * 4, hipMemcpyDeviceToHost, idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    return kdb_build_graph(idx, count, params);
+}
+
+extern "C" int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids,
+                              const float *in_dist, const uint32_t *in_count, uint32_t *out_ids, float *out_dist,
+                              uint32_t *out_count) {
+    // Host-side shard merge (G*k entries per query; no vector arithmetic).  Total order (key, id)
+    // with key = raw L2 sum, or -dot for cosine -- identical to merge_topk_kernel.
+    if (!in_ids || !in_dist || !in_count || !out_ids || !out_dist || !out_count || k == 0) {
+        kdb_set_error("merge_topk: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    struct E { float key; uint32_t id; float d; };
+    std::vector<E> buf;
+    for (uint32_t q = 0; q < B; q++) {
+        buf.clear();
+        for (uint32_t g = 0; g < G; g++) {
+            uint32_t c = in_count[(size_t)g * B + q];
+            if (c > k) c = k;
+            for (uint32_t i = 0; i < c; i++) {
+                const size_t off = ((size_t)g * B + q) * k + i;
+                buf.push_back({metric == KDB_METRIC_COSINE ? -in_dist[off] : in_dist[off], in_ids[off], in_dist[off]});
+            }
+        }
+        std::sort(buf.begin(), buf.end(), [](const E &a, const E &b) { return a.key < b.key || (a.key == b.key && a.id < b.id); });
+        const uint32_t n = buf.size() < k ? (uint32_t)buf.size() : k;
+        for (uint32_t i = 0; i < k; i++) {
+            out_ids[(size_t)q * k + i] = i < n ? buf[i].id : 0u;
+            out_dist[(size_t)q * k + i] = i < n ? buf[i].d : INFINITY;
+        }
+        out_count[q] = n;
+    }
+    return KDB_OK;
+}
+
+extern "C" int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
+                                  const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
+                                  float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    return kdb_launch_merge_topk(idx->desc.metric, G, B, k, d_in_ids, d_in_dist, d_in_count, d_out_ids, d_out_dist,
+                                 d_out_count, s);
+}
+
+extern "C" int kdb_get_counters(kdb_index *idx, kdb_counters *out) {
+    KDB_CHECK_IDX(idx);
+    if (!out) return KDB_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    unsigned long long c[2] = {0, 0};
+    KDB_HIP(hipMemcpy(c, idx->d_ctr, 16, hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    if (idx->last_kind && hipEventElapsedTime(&ms, idx->ev0, idx->ev1) != hipSuccess) ms = 0.f;
+    kdb_counters r{};
+    r.last_kernel_ms = ms;
+    const uint64_t row_bytes = (uint64_t)idx->desc.dim * idx->elem;
+    if (idx->last_kind == 1) { // n_dist*(dim*elem) + n_hops*(deg_cap*4) + n_dist*4
+        r.n_dist = c[0];
+        r.n_hops = c[1];
+        r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
+    } else if (idx->last_kind == 2) { // N_scanned*dim*elem + B*dim*elem (B*k*8 added by the caller)
+        r.bytes = (uint64_t)(idx->count - idx->n_deleted) * row_bytes + (uint64_t)idx->last_B * row_bytes;
+    } else if (idx->last_kind == 3) {
+        r.n_dist = (uint64_t)idx->last_B * idx->last_C;
+        r.bytes = r.n_dist * row_bytes + r.n_dist * 8 + (uint64_t)idx->last_B * row_bytes;
+    }
+    *out = r;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_sync(kdb_index *idx) {
+    KDB_CHECK_IDX(idx);
+    KDB_HIP(hipSetDevice(idx->device));
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}

@@ -1,0 +1,145 @@
+// kdb_device.cuh -- wave-level device primitives for gfx950 (wave64).  Compiled with
+// -ffp-contract=off: every rounding below is explicit, so the CPU oracle can restate the exact
+// accumulation order (oracle/kdb_oracle.c, ORC_ARITH_HIP_WAVE).
+#pragma once
+#include "kdb_internal.h"
+
+#define KDB_WAVE 64
+
+__device__ __forceinline__ int kdb_lane() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ unsigned kdb_mbcnt(unsigned long long m) {
+    // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// DPP row rotate inside each 16-lane row (row_ror:n), float payload.
+template <int N>
+__device__ __forceinline__ float kdb_row_ror(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
+// Sum over the 16 lanes of a DPP row; every lane of the row ends with the same value.
+// Order: p[t]+p[t^8], then ^4, ^2, ^1 (rotations pair the same lanes as the xor butterfly and
+// f32 add is commutative) -- oracle: hip_wave_reduce16().
+__device__ __forceinline__ float kdb_reduce16(float p) {
+    p = p + kdb_row_ror<8>(p);
+    p = p + kdb_row_ror<4>(p);
+    p = p + kdb_row_ror<2>(p);
+    p = p + kdb_row_ror<1>(p);
+    return p;
+}
+
+__device__ __forceinline__ int kdb_row_ror_i(int v, int n) {
+    switch (n) {
+    case 8: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    }
+}
+__device__ __forceinline__ int kdb_reduce16_i(int p) {
+    p += kdb_row_ror_i(p, 8);
+    p += kdb_row_ror_i(p, 4);
+    p += kdb_row_ror_i(p, 2);
+    p += kdb_row_ror_i(p, 1);
+    return p;
+}
+
+__device__ __forceinline__ int kdb_wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- one row against the query held in LDS, 16 lanes per row ---------------------------------
+// t = lane & 15.  Lane t visits the 16-byte chunks c = t, t+16, ...; component j of each chunk
+// feeds accumulator j (f16: j & 3); partial = (a0+a1)+(a2+a3).  The caller reduces with
+// kdb_reduce16().  `row` may point at row 0 (all zero) for inactive groups.
+template <int METRIC>
+__device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ row, const float *q, uint32_t ld,
+                                                     int t) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(row);
+    const float4 *q4 = reinterpret_cast<const float4 *>(q);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const uint32_t nch = ld >> 2;
+#pragma unroll 4
+    for (uint32_t c = (uint32_t)t; c < nch; c += 16) {
+        float4 x = r4[c];
+        float4 y = q4[c];
+        if (METRIC == KDB_METRIC_L2) {
+            float d0 = y.x - x.x, d1 = y.y - x.y, d2 = y.z - x.z, d3 = y.w - x.w;
+            a0 = __builtin_fmaf(d0, d0, a0);
+            a1 = __builtin_fmaf(d1, d1, a1);
+            a2 = __builtin_fmaf(d2, d2, a2);
+            a3 = __builtin_fmaf(d3, d3, a3);
+        } else {
+            a0 = __builtin_fmaf(y.x, x.x, a0);
+            a1 = __builtin_fmaf(y.y, x.y, a1);
+            a2 = __builtin_fmaf(y.z, x.z, a2);
+            a3 = __builtin_fmaf(y.w, x.w, a3);
+        }
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// f16 rows (IEEE binary16 bits), query kept in LDS as f32 values already rounded through f16
+// (hnsw_index.go:421-427).  8 elements per chunk.  Squared L2 only (hnsw_index.go:210-213).
+__device__ __forceinline__ float kdb_row_partial_f16(const uint16_t *__restrict__ row, const float *q, uint32_t ld,
+                                                     int t) {
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t nch = ld >> 3;
+#pragma unroll 2
+    for (uint32_t c = (uint32_t)t; c < nch; c += 16) {
+        uint4 xb = r4[c];
+        const float4 *q4 = reinterpret_cast<const float4 *>(q + 8 * c);
+        float4 y0 = q4[0], y1 = q4[1];
+        unsigned w[4] = {xb.x, xb.y, xb.z, xb.w};
+        float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned short hb = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+            float x = (float)__builtin_bit_cast(_Float16, hb);
+            float d = yy[j] - x;
+            a[j & 3] = __builtin_fmaf(d, d, a[j & 3]);
+        }
+    }
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+// int8 rows, query in LDS as packed int8: exact i32 dot (order irrelevant).
+__device__ __forceinline__ int kdb_row_partial_i8(const int8_t *__restrict__ row, const int8_t *q, uint32_t ld, int t) {
+    const int4 *r4 = reinterpret_cast<const int4 *>(row);
+    const int4 *q4 = reinterpret_cast<const int4 *>(q);
+    int acc = 0;
+    const uint32_t nch = ld >> 4;
+#pragma unroll 2
+    for (uint32_t c = (uint32_t)t; c < nch; c += 16) {
+        int4 x = r4[c];
+        int4 y = q4[c];
+        acc = __builtin_amdgcn_sdot4(x.x, y.x, acc, false);
+        acc = __builtin_amdgcn_sdot4(x.y, y.y, acc, false);
+        acc = __builtin_amdgcn_sdot4(x.z, y.z, acc, false);
+        acc = __builtin_amdgcn_sdot4(x.w, y.w, acc, false);
+    }
+    return acc;
+}
+
+// int8 cosine scaling (hnsw_index.go:2429-2454): f64 similarity, clamp, 1 - sim.
+__device__ __forceinline__ float kdb_i8_distance(int dot, float qnorm, float snorm) {
+    if (snorm == 0.f) return 1.0f;
+    double sim = (double)dot / ((double)qnorm * (double)snorm);
+    if (sim > 1.0) sim = 1.0;
+    if (sim < -1.0) sim = -1.0;
+    return (float)(1.0 - sim);
+}
+
+// Key used for ordering inside the kernels (ascending = nearer):
+//   f32/f16 L2: the raw sum;  f32 cosine: -dot (1-dot is monotone in -dot);  int8: the distance.
+template <int PREC, int METRIC>
+__device__ __forceinline__ float kdb_key_from_raw(float raw) {
+    if (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) return -raw;
+    return raw;
+}

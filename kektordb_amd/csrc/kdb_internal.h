@@ -1,0 +1,116 @@
+// kdb_internal.h -- host/device shared declarations of libkektor_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/kektor_hip.h"
+
+#define KDB_ID_MASK 0x3fffffffu
+#define KDB_F_EXPANDED 0x80000000u  // beam entry already expanded (popped)
+#define KDB_F_NORESULT 0x40000000u  // traversal-only entry: deleted node / entry point outside the allow-list
+#define KDB_MAX_DEG0 64u            // mMax0 = 2m <= 64
+#define KDB_UP_MARK_CAP 512u        // upper-layer visited un-mark list (per wave, LDS)
+
+// Device view of one index (passed by value to kernels).
+struct KdbView {
+    const void *rows;        // (cap+1) rows of `ld` elements; row 0 and the pad columns are zero
+    const float *norms;      // int8: quantizedNorms[id];  f32/L2: ||x||^2 for the flat scan; else null
+    const uint32_t *adj0;    // (cap+1) * deg0 neighbour ids at level 0, 0 = empty slot (packed from the front)
+    const uint32_t *adj_up;  // upper pool: slot s holds `deg_up` ids
+    const uint32_t *up_idx;  // (cap+1): first upper slot of a node (valid when levels[id] >= 1)
+    const uint8_t *levels;   // (cap+1)
+    const uint32_t *deleted; // bitset words, bit id
+    uint32_t dim, ld;        // ld = row stride in elements (dim rounded up to 16)
+    uint32_t deg0, deg_up;   // mMax0, m
+    uint32_t count;          // ids 1..count
+    uint32_t entry;
+    int32_t max_level;
+    uint32_t metric, precision;
+    uint32_t vis_words;      // words per visited bitset = (cap>>5)+1
+    float q_absmax;          // int8 quantizer
+};
+
+struct kdb_index {
+    kdb_index_desc desc;
+    uint32_t ld = 0, deg0 = 0, deg_up = 0, cap = 0;
+    size_t elem = 4;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // device buffers
+    void *d_rows = nullptr;
+    float *d_norms = nullptr;
+    uint32_t *d_adj0 = nullptr;
+    uint32_t *d_adj_up = nullptr;
+    uint32_t *d_up_idx = nullptr;
+    uint8_t *d_levels = nullptr;
+    uint32_t *d_deleted = nullptr;
+    size_t up_slots = 0, up_slots_cap = 0;
+    uint32_t count = 0, entry = 0;
+    int32_t max_level = -1;
+    bool has_graph = false;
+    bool norms_valid = false;   // L2 row norms for the flat scan
+    uint32_t n_deleted = 0;
+    float absmax = 0.f;
+    // scratch
+    uint32_t *d_visited = nullptr;  // slots * vis_words
+    uint32_t vis_slots = 0;
+    void *d_scratch = nullptr;      // general scratch (flat-scan partials, traces, ...)
+    size_t scratch_bytes = 0;
+    void *d_qbuf = nullptr;         // prepared queries (stored form, padded to ld) + query norms
+    size_t qbuf_bytes = 0;
+    void *d_iobuf = nullptr;        // staging for the host-pointer entry points
+    size_t iobuf_bytes = 0;
+    void *d_build = nullptr;        // graph-construction workspace
+    size_t build_bytes = 0;
+    int last_kind = 0;              // 1 search, 2 flat scan, 3 distance tile
+    uint32_t last_B = 0, last_C = 0;
+    uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words)
+    unsigned long long *d_ctr = nullptr; // n_dist, n_hops
+    // trace
+    uint32_t *trace_ndist = nullptr, *trace_nhops = nullptr;
+    int trace_on_device = 0;
+    kdb_counters last{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+};
+
+// ---- error plumbing --------------------------------------------------------------------------
+void kdb_set_error(const char *fmt, ...);
+#define KDB_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            kdb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                       \
+            return _e == hipErrorOutOfMemory ? KDB_ERR_OOM : KDB_ERR_HIP;                  \
+        }                                                                                  \
+    } while (0)
+
+KdbView kdb_make_view(const kdb_index *idx);
+int kdb_ensure_scratch(kdb_index *idx, size_t bytes);
+int kdb_ensure_visited(kdb_index *idx, uint32_t slots);
+
+// ---- kernel launchers (each defined next to its kernels) --------------------------------------
+// search.hip
+int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, void *d_out, float *d_qnorm,
+                            int normalize, hipStream_t s);
+int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                      uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                      float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
+                      hipStream_t s);
+int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                        const uint32_t *d_ids, uint32_t C, float *d_out, hipStream_t s);
+int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *d_out, hipStream_t s);
+int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, hipStream_t s);
+// flat_scan.hip
+int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                         uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
+                         uint32_t *d_out_count, hipStream_t s);
+int kdb_launch_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
+                          const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
+                          float *d_out_dist, uint32_t *d_out_count, hipStream_t s);
+// build.hip
+int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p);

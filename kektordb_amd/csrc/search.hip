@@ -1,0 +1,635 @@
+// search.hip -- batched HNSW search for gfx950: one wavefront (one 64-thread workgroup) per query.
+//
+// Follows pkg/core/hnsw/hnsw_index.go:369-468 (searchInternal) and :2351-2611
+// (searchLayerUnlocked) of the reference, re-designed for CDNA4:
+//   * the reference's two binary heaps (hnsw_heap.go) become ONE distance-sorted beam array in LDS;
+//     pop-min = first un-expanded entry, result set = the array itself.  With distinct distances
+//     this yields exactly the reference's traversal (same expansions, same n_dist / n_hops, same
+//     results); equal distances are ordered by id instead of by heap history;
+//   * each hop evaluates the <=32 neighbour rows as a tile: 4 rows per pass, 16 lanes per row,
+//     16-byte coalesced loads straight to VGPRs (rows are streamed once, never staged), the query
+//     stays in LDS, a DPP row reduction finishes each distance;
+//   * visited = a per-wave bitset in HBM (atomicOr test-and-set), cleared by the wave itself;
+//     upper layers un-mark what they marked instead of clearing;
+//   * queries are pulled from an atomic work counter by persistent waves.
+#include "kdb_device.cuh"
+#include <math.h>
+
+namespace {
+
+struct WaveLds {
+    float *q;          // query (f32 values, or packed int8)
+    float *beam_d;     // [cap]
+    uint32_t *beam_id; // [cap]  id | flags
+    uint32_t *nb_id;   // [64]
+    float *nb_d;       // [64]
+    uint32_t *marks;   // [KDB_UP_MARK_CAP]
+};
+
+struct Beam {
+    uint32_t count, n_res, n_nr, scan_from;
+    float worst;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // single-wave workgroup: LDS operations of a wave execute in order; only the compiler needs
+    // to be told not to move LDS accesses across this point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
+template <int PREC, int METRIC>
+__device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
+    const int lane = kdb_lane();
+    const int g = lane >> 4, t = lane & 15;
+    for (uint32_t base = 0; base < n; base += 4) {
+        const uint32_t r = base + (uint32_t)g;
+        const bool act = r < n;
+        const uint32_t id = act ? s.nb_id[r] : 0u; // row 0 is all zero
+        float key;
+        if (PREC == KDB_PREC_F32) {
+            const float *row = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
+            float p = kdb_row_partial_f32<METRIC>(row, s.q, v.ld, t);
+            key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p));
+        } else if (PREC == KDB_PREC_F16) {
+            const uint16_t *row = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld;
+            float p = kdb_row_partial_f16(row, s.q, v.ld, t);
+            key = kdb_reduce16(p);
+        } else {
+            const int8_t *row = reinterpret_cast<const int8_t *>(v.rows) + (size_t)id * v.ld;
+            int p = kdb_row_partial_i8(row, reinterpret_cast<const int8_t *>(s.q), v.ld, t);
+            p = kdb_reduce16_i(p);
+            key = kdb_i8_distance(p, qnorm, v.norms[id]);
+        }
+        if (act && t == 0) s.nb_d[r] = key;
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ void beam_insert(const WaveLds &s, Beam &b, float d, uint32_t idf) {
+    const int lane = kdb_lane();
+    const uint32_t id = idf & KDB_ID_MASK;
+    int cnt = 0;
+    for (uint32_t i = (uint32_t)lane; i < b.count; i += 64) {
+        float e = s.beam_d[i];
+        uint32_t eid = s.beam_id[i] & KDB_ID_MASK;
+        cnt += ((e < d) || (e == d && eid < id)) ? 1 : 0;
+    }
+    const uint32_t pos = (uint32_t)kdb_wave_sum_i(cnt);
+    for (int hi = (int)b.count - 1; hi >= (int)pos; hi -= 64) {
+        const int i = hi - lane;
+        const bool act = i >= (int)pos;
+        float e = 0.f;
+        uint32_t x = 0;
+        if (act) {
+            e = s.beam_d[i];
+            x = s.beam_id[i];
+        }
+        wave_lds_fence();
+        if (act) {
+            s.beam_d[i + 1] = e;
+            s.beam_id[i + 1] = x;
+        }
+        wave_lds_fence();
+    }
+    if (lane == 0) {
+        s.beam_d[pos] = d;
+        s.beam_id[pos] = idf;
+    }
+    wave_lds_fence();
+    b.count++;
+    if (pos < b.scan_from) b.scan_from = pos;
+}
+
+// index of the last entry with (flag & mask) == want, searching the last 64 entries; -1 if none
+__device__ __forceinline__ int beam_last_with(const WaveLds &s, const Beam &b, uint32_t mask, uint32_t want) {
+    const int i = (int)b.count - 1 - kdb_lane();
+    const bool f = i >= 0 && ((s.beam_id[i] & mask) == want);
+    const unsigned long long m = __ballot(f);
+    if (!m) return -1;
+    return (int)b.count - 1 - __builtin_ctzll(m);
+}
+
+// keep the invariants: n_res <= ef; when n_res == ef the last entry is a result (worst);
+// at most 63 traversal-only entries.
+__device__ __forceinline__ void beam_trim(const WaveLds &s, Beam &b, uint32_t ef) {
+    if (b.n_res > ef) {
+        int j = b.n_nr == 0 ? (int)b.count - 1 : beam_last_with(s, b, KDB_F_NORESULT, 0u);
+        // entries after j are traversal-only and farther than the evicted result: drop them too
+        b.n_nr -= (b.count - 1 - (uint32_t)j);
+        b.count = (uint32_t)j;
+        b.n_res--;
+    }
+    if (b.n_res >= ef && b.n_nr != 0) {
+        int j = beam_last_with(s, b, KDB_F_NORESULT, 0u);
+        if (j >= 0) {
+            b.n_nr -= (b.count - 1 - (uint32_t)j);
+            b.count = (uint32_t)j + 1;
+        }
+    }
+    while (b.n_nr > 63) { // pathological: >63 deleted nodes nearer than the worst result; drop the farthest
+        int j = -1;
+        for (int base = (int)b.count - 1; base >= 0 && j < 0; base -= 64) {
+            const int i = base - kdb_lane();
+            const bool f = i >= 0 && (s.beam_id[i] & KDB_F_NORESULT);
+            const unsigned long long m = __ballot(f);
+            if (m) j = base - __builtin_ctzll(m);
+        }
+        for (uint32_t lo = (uint32_t)j; lo + 1 < b.count; lo += 64) {
+            const uint32_t i = lo + (uint32_t)kdb_lane();
+            const bool act = i + 1 < b.count;
+            float e = 0.f;
+            uint32_t x = 0;
+            if (act) {
+                e = s.beam_d[i + 1];
+                x = s.beam_id[i + 1];
+            }
+            wave_lds_fence();
+            if (act) {
+                s.beam_d[i] = e;
+                s.beam_id[i] = x;
+            }
+            wave_lds_fence();
+        }
+        b.count--;
+        b.n_nr--;
+        if (b.scan_from > (uint32_t)j) b.scan_from--;
+    }
+    b.worst = (b.n_res >= ef && b.count > 0) ? s.beam_d[b.count - 1] : INFINITY;
+}
+
+__device__ __forceinline__ int beam_next(const WaveLds &s, Beam &b) {
+    for (uint32_t base = b.scan_from; base < b.count; base += 64) {
+        const uint32_t i = base + (uint32_t)kdb_lane();
+        const bool f = i < b.count && !(s.beam_id[i] & KDB_F_EXPANDED);
+        const unsigned long long m = __ballot(f);
+        if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
+    }
+    return -1;
+}
+
+struct QCtr {
+    uint32_t n_dist, n_hops;
+};
+
+// searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the beam in LDS.
+template <int PREC, int METRIC>
+__device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32_t *visited,
+                             const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm,
+                             bool record_marks, uint32_t &n_marks, QCtr &ctr) {
+    const int lane = kdb_lane();
+    b.count = 0;
+    b.n_res = 0;
+    b.n_nr = 0;
+    b.scan_from = 0;
+    b.worst = INFINITY;
+    // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
+    if (lane == 0) s.nb_id[0] = ep;
+    wave_lds_fence();
+    compute_dists<PREC, METRIC>(v, s, 1, qnorm);
+    ctr.n_dist++;
+    {
+        if (lane == 0) atomicOr(&visited[ep >> 5], 1u << (ep & 31));
+        if (record_marks) {
+            if (lane == 0 && n_marks < KDB_UP_MARK_CAP) s.marks[n_marks] = ep;
+            n_marks++;
+        }
+        bool nr = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
+        if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) nr = true;
+        beam_insert(s, b, s.nb_d[0], ep | (nr ? KDB_F_NORESULT : 0u));
+        if (nr) b.n_nr++; else b.n_res++;
+        beam_trim(s, b, ef);
+    }
+    const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
+    for (;;) {
+        const int idx = beam_next(s, b);
+        if (idx < 0) break;
+        const uint32_t cur = s.beam_id[idx] & KDB_ID_MASK;
+        const float cur_d = s.beam_d[idx];
+        if (b.n_res >= ef && cur_d > b.worst) break; // :2501-2506 (never true after trimming; kept for clarity)
+        if (lane == 0) s.beam_id[idx] |= KDB_F_EXPANDED;
+        b.scan_from = (uint32_t)idx + 1;
+        wave_lds_fence();
+        if (level > 0 && (int)v.levels[cur] < level) continue; // :2524-2527 node lacks this level
+        ctr.n_hops++;
+        const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
+                                         : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
+        uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        bool fresh = nb != 0u && nb <= v.count;
+        if (fresh) { // visited test-and-set (:2539-2542)
+            const uint32_t bit = 1u << (nb & 31);
+            const uint32_t old = atomicOr(&visited[nb >> 5], bit);
+            fresh = !(old & bit);
+        }
+        if (record_marks) {
+            const unsigned long long mm = __ballot(fresh);
+            if (fresh) {
+                const uint32_t p = n_marks + kdb_mbcnt(mm);
+                if (p < KDB_UP_MARK_CAP) s.marks[p] = nb;
+            }
+            n_marks += (uint32_t)__builtin_popcountll(mm);
+        }
+        if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
+        const unsigned long long m = __ballot(fresh);
+        const uint32_t n = (uint32_t)__builtin_popcountll(m);
+        if (n == 0) continue;
+        if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+        wave_lds_fence();
+        // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather
+        uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
+        const uint32_t delw = (uint32_t)lane < n ? v.deleted[my_id >> 5] : 0u;
+        compute_dists<PREC, METRIC>(v, s, n, qnorm);
+        ctr.n_dist += n;
+        const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
+        const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
+        // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
+        unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || my_d < b.worst));
+        while (pass) { // sequential, in stored order (:2577-2590)
+            const int j = __builtin_ctzll(pass);
+            pass &= pass - 1;
+            const float d = __shfl(my_d, j, 64);
+            if (!(b.n_res < ef || d < b.worst)) continue;
+            const uint32_t id = __shfl(my_id, j, 64);
+            const bool nr = __shfl((int)my_nr, j, 64) != 0;
+            beam_insert(s, b, d, id | (nr ? KDB_F_NORESULT : 0u));
+            if (nr) b.n_nr++; else b.n_res++;
+            beam_trim(s, b, ef);
+        }
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
+    return PREC == KDB_PREC_I8 ? ((size_t)ld + 15) / 16 * 16 : (size_t)ld * 4;
+}
+
+template <int PREC, int METRIC>
+__global__ void __launch_bounds__(64)
+hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
+                   uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
+                   uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work, unsigned long long *gctr,
+                   uint32_t *out_ids, float *out_dist, uint32_t *out_count, uint32_t *tr_ndist,
+                   uint32_t *tr_nhops) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WaveLds s;
+    size_t off = 0;
+    s.q = reinterpret_cast<float *>(smem + off);
+    off += q_lds_bytes<PREC>(v.ld);
+    s.beam_d = reinterpret_cast<float *>(smem + off);
+    off += (size_t)beam_cap * 4;
+    s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += (size_t)beam_cap * 4;
+    s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += 64 * 4;
+    s.nb_d = reinterpret_cast<float *>(smem + off);
+    off += 64 * 4;
+    s.marks = reinterpret_cast<uint32_t *>(smem + off);
+
+    const int lane = kdb_lane();
+    uint32_t *visited = visited_pool + (size_t)blockIdx.x * v.vis_words;
+    unsigned long long tot_dist = 0, tot_hops = 0;
+
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(work, 1u);
+        qi = __shfl(qi, 0, 64);
+        if (qi >= B) break;
+
+        // clear the visited bitset (reference: BitSet.Clear per layer call, bitset.go:44-48)
+        {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4 *v4 = reinterpret_cast<uint4 *>(visited);
+            const uint32_t n4 = v.vis_words >> 2;
+            for (uint32_t i = (uint32_t)lane; i < n4; i += 64) v4[i] = z;
+            for (uint32_t i = (n4 << 2) + (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
+        }
+        // query -> LDS
+        float qnorm = 1.f;
+        if (PREC == KDB_PREC_I8) {
+            const uint32_t nw = (uint32_t)(q_lds_bytes<PREC>(v.ld) / 4);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(queries) + (size_t)qi * nw;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
+            for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
+            qnorm = qnorms[qi];
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) +
+                                                                 (size_t)qi * v.ld);
+            float4 *dst = reinterpret_cast<float4 *>(s.q);
+            for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
+        }
+        __threadfence_block();
+        wave_lds_fence();
+
+        Beam b;
+        QCtr ctr{0, 0};
+        uint32_t ep = entry;
+        bool failed = false;
+        // greedy descent, ef = 1 (:450-459)
+        for (int l = v.max_level; l > 0 && !failed; l--) {
+            uint32_t n_marks = 0;
+            search_layer<PREC, METRIC>(v, s, b, visited, allow, ep, l, 1u, qnorm, true, n_marks, ctr);
+            // first result entry
+            int best = -1;
+            for (uint32_t base = 0; base < b.count && best < 0; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool f = i < b.count && !(s.beam_id[i] & KDB_F_NORESULT);
+                const unsigned long long m = __ballot(f);
+                if (m) best = (int)(base + (uint32_t)__builtin_ctzll(m));
+            }
+            if (best < 0) failed = true; // "search failed at level" (:455-457)
+            else ep = s.beam_id[best] & KDB_ID_MASK;
+            // un-mark what this layer marked (the reference clears the whole bitset per call)
+            if (n_marks <= KDB_UP_MARK_CAP) {
+                for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
+                    const uint32_t id = s.marks[i];
+                    atomicAnd(&visited[id >> 5], ~(1u << (id & 31)));
+                }
+            } else {
+                for (uint32_t i = (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
+            }
+            __threadfence_block();
+            wave_lds_fence();
+        }
+        uint32_t nout = 0;
+        if (!failed) {
+            uint32_t dummy = 0;
+            search_layer<PREC, METRIC>(v, s, b, visited, allow, ep, 0, ef, qnorm, false, dummy, ctr);
+            // results = non traversal-only entries, ascending (:2596-2610), first k
+            for (uint32_t base = 0; base < b.count && nout < k; base += 64) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool f = i < b.count && !(s.beam_id[i] & KDB_F_NORESULT);
+                const unsigned long long m = __ballot(f);
+                const uint32_t p = nout + kdb_mbcnt(m);
+                if (f && p < k) {
+                    out_ids[(size_t)qi * k + p] = s.beam_id[i] & KDB_ID_MASK;
+                    float key = s.beam_d[i];
+                    out_dist[(size_t)qi * k + p] = (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) ? -key : key;
+                }
+                nout += (uint32_t)__builtin_popcountll(m);
+            }
+            if (nout > k) nout = k;
+        }
+        for (uint32_t p = nout + (uint32_t)lane; p < k; p += 64) {
+            out_ids[(size_t)qi * k + p] = 0u;
+            out_dist[(size_t)qi * k + p] = INFINITY;
+        }
+        if (lane == 0) {
+            out_count[qi] = nout;
+            if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
+            if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
+        }
+        tot_dist += ctr.n_dist;
+        tot_hops += ctr.n_hops;
+        wave_lds_fence();
+    }
+    if (lane == 0 && gctr) {
+        atomicAdd(&gctr[0], tot_dist);
+        atomicAdd(&gctr[1], tot_hops);
+    }
+}
+
+// B x C gathered distance tile: block (64 threads) = (query b, chunk of 32 candidates).
+template <int PREC, int METRIC>
+__global__ void __launch_bounds__(64)
+distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
+                     const uint32_t *__restrict__ ids, uint32_t C, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WaveLds s;
+    size_t off = 0;
+    s.q = reinterpret_cast<float *>(smem + off);
+    off += q_lds_bytes<PREC>(v.ld);
+    s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += 64 * 4;
+    s.nb_d = reinterpret_cast<float *>(smem + off);
+    s.beam_d = nullptr;
+    s.beam_id = nullptr;
+    s.marks = nullptr;
+    const int lane = kdb_lane();
+    const uint32_t chunks = (C + 31) / 32;
+    const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    if (b >= B) return;
+    float qnorm = 1.f;
+    if (PREC == KDB_PREC_I8) {
+        const uint32_t nw = (uint32_t)(q_lds_bytes<PREC>(v.ld) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(queries) + (size_t)b * nw;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
+        for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
+        qnorm = qnorms[b];
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) + (size_t)b * v.ld);
+        float4 *dst = reinterpret_cast<float4 *>(s.q);
+        for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
+    }
+    const uint32_t c0 = ch * 32;
+    const uint32_t n = C - c0 < 32 ? C - c0 : 32;
+    uint32_t id = 0;
+    if ((uint32_t)lane < n) {
+        id = ids[(size_t)b * C + c0 + lane];
+        if (id > v.count) id = 0;
+        s.nb_id[lane] = id;
+    }
+    __threadfence_block();
+    wave_lds_fence();
+    compute_dists<PREC, METRIC>(v, s, n, qnorm);
+    if ((uint32_t)lane < n) {
+        float key = s.nb_d[lane];
+        float raw = (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) ? -key : key;
+        out[(size_t)b * C + c0 + lane] = id == 0 ? INFINITY : raw;
+    }
+}
+
+// Query preparation (searchInternal Phase 0, hnsw_index.go:404-434): one thread per query so the
+// normalisation reproduces normalize() (:3034-3045) exactly: sequential f32 sum of squares,
+// f64 sqrt, f32 reciprocal, f32 multiply.  Output rows are padded to `ld` with zeros.
+__global__ void prep_queries_kernel(KdbView v, const float *__restrict__ in, uint32_t B, void *out, float *qnorm_out,
+                                    int normalize) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *q = in + (size_t)b * v.dim;
+    float inv = 1.f;
+    bool scale = false;
+    if (normalize && v.metric == KDB_METRIC_COSINE) {
+        float nsq = 0.f;
+        for (uint32_t i = 0; i < v.dim; i++) {
+            float x = q[i];
+            float sq = x * x;
+            nsq = nsq + sq;
+        }
+        if (nsq > 0.f) {
+            inv = 1.0f / (float)sqrt((double)nsq);
+            scale = true;
+        }
+    }
+    if (v.precision == KDB_PREC_F32) {
+        float *o = reinterpret_cast<float *>(out) + (size_t)b * v.ld;
+        for (uint32_t i = 0; i < v.dim; i++) o[i] = scale ? q[i] * inv : q[i];
+        for (uint32_t i = v.dim; i < v.ld; i++) o[i] = 0.f;
+    } else if (v.precision == KDB_PREC_F16) {
+        float *o = reinterpret_cast<float *>(out) + (size_t)b * v.ld;
+        for (uint32_t i = 0; i < v.dim; i++) {
+            float x = scale ? q[i] * inv : q[i];
+            _Float16 h = (_Float16)x; // RNE, as float16.Fromfloat32 (hnsw_index.go:425)
+            o[i] = (float)h;
+        }
+        for (uint32_t i = v.dim; i < v.ld; i++) o[i] = 0.f;
+    } else {
+        // Quantizer.Quantize (quantizer.go:150-176) then the query norm (:2411-2418)
+        int8_t *o = reinterpret_cast<int8_t *>(out) + (size_t)b * ((v.ld + 15) / 16 * 16);
+        long long nsum = 0;
+        for (uint32_t i = 0; i < v.dim; i++) {
+            float x = scale ? q[i] * inv : q[i];
+            int8_t qv = 0;
+            if (v.q_absmax != 0.f) {
+                float r = x / v.q_absmax;
+                float sc = r * 127.0f;
+                if (sc > 127.0f) sc = 127.0f;
+                else if (sc < -127.0f) sc = -127.0f;
+                qv = (int8_t)round((double)sc);
+            }
+            o[i] = qv;
+            nsum += (long long)qv * (long long)qv;
+        }
+        for (uint32_t i = v.dim; i < (v.ld + 15) / 16 * 16; i++) o[i] = 0;
+        float qn = (float)sqrt((double)nsum);
+        qnorm_out[b] = qn == 0.f ? 1.f : qn;
+    }
+}
+
+// smallest id set in the allow bitmap (allowList.Iterator().Next(), hnsw_index.go:437-447); 0 if none
+__global__ void first_allowed_kernel(const uint32_t *allow, uint32_t words, uint32_t *out) {
+    uint32_t best = 0xffffffffu;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
+        uint32_t w = allow[i];
+        if (w) {
+            uint32_t id = i * 32 + (uint32_t)__builtin_ctz(w);
+            if (id < best) best = id;
+        }
+    }
+    if (best != 0xffffffffu) atomicMin(out, best);
+}
+
+// ||x||^2 per row in the wave order (used by the L2 flat scan for ranking only)
+__global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32_t n) {
+    const int lane = kdb_lane();
+    const int g = lane >> 4, t = lane & 15;
+    const uint32_t r = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (uint32_t)g;
+    const bool act = r < n;
+    const uint32_t id = act ? first + r : 0u;
+    const float4 *r4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (uint32_t c = (uint32_t)t; c < (v.ld >> 2); c += 16) {
+        float4 x = r4[c];
+        a0 = __builtin_fmaf(x.x, x.x, a0);
+        a1 = __builtin_fmaf(x.y, x.y, a1);
+        a2 = __builtin_fmaf(x.z, x.z, a2);
+        a3 = __builtin_fmaf(x.w, x.w, a3);
+    }
+    float p = kdb_reduce16((a0 + a1) + (a2 + a3));
+    if (act && t == 0) norms[id] = p;
+}
+
+template <typename K>
+int occupancy_blocks(K kern, int threads, size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+} // namespace
+
+int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, void *d_out, float *d_qnorm,
+                            int normalize, hipStream_t s) {
+    if (B == 0) return KDB_OK;
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((B + 63) / 64), dim3(64), 0, s, v, d_in, B, d_out, d_qnorm, normalize);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *d_out, hipStream_t s) {
+    KDB_HIP(hipMemsetAsync(d_out, 0xff, 4, s));
+    uint32_t blocks = (words + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(first_allowed_kernel, dim3(blocks), dim3(256), 0, s, d_allow, words, d_out);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, hipStream_t s) {
+    if (n == 0) return KDB_OK;
+    const uint32_t rows_per_block = 16; // 4 waves x 4 rows
+    hipLaunchKernelGGL(row_norms_kernel, dim3((n + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, v, d_norms,
+                       first, n);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+template <int PREC, int METRIC>
+static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                           uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                           float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
+                           hipStream_t s) {
+    const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
+    const uint32_t beam_cap = ((eff + 64 + 1) + 63) / 64 * 64;
+    const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
+    const size_t lds = qb + (size_t)beam_cap * 8 + 64 * 8 + KDB_UP_MARK_CAP * 4;
+    if (lds > 160 * 1024) {
+        kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    auto kern = hnsw_search_kernel<PREC, METRIC>;
+    if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipDeviceProp_t prop;
+    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
+    int per_cu = occupancy_blocks(kern, 64, lds);
+    uint32_t grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    if (grid > B) grid = B;
+    if (grid == 0) return KDB_OK;
+    int rc = kdb_ensure_visited(idx, grid);
+    if (rc) return rc;
+    KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
+    KDB_HIP(hipMemsetAsync(idx->d_ctr, 0, 16, s));
+    KDB_HIP(hipEventRecord(idx->ev0, s));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, B, k, eff, d_allow, entry, beam_cap,
+                       idx->d_visited, idx->d_work, idx->d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist,
+                       d_tr_nhops);
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipEventRecord(idx->ev1, s));
+    return KDB_OK;
+}
+
+int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                      uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                      float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
+                      hipStream_t s) {
+#define KDB_ARGS idx, v, d_q, d_qnorm, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F32, KDB_METRIC_L2>(KDB_ARGS);
+    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_F32, KDB_METRIC_COSINE>(KDB_ARGS);
+    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2>(KDB_ARGS);
+    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE>(KDB_ARGS);
+#undef KDB_ARGS
+    kdb_set_error("unsupported precision/metric combination");
+    return KDB_ERR_UNSUPPORTED;
+}
+
+template <int PREC, int METRIC>
+static int launch_distance_t(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, const uint32_t *d_ids,
+                             uint32_t C, float *d_out, hipStream_t s) {
+    const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
+    const size_t lds = qb + 64 * 8;
+    const uint32_t chunks = (C + 31) / 32;
+    hipLaunchKernelGGL((distance_tile_kernel<PREC, METRIC>), dim3(B * chunks), dim3(64), lds, s, v, d_q, d_qnorm, B, d_ids, C, d_out);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, const uint32_t *d_ids,
+                        uint32_t C, float *d_out, hipStream_t s) {
+    if (B == 0 || C == 0) return KDB_OK;
+    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_L2) return launch_distance_t<KDB_PREC_F32, KDB_METRIC_L2>(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
+    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE) return launch_distance_t<KDB_PREC_F32, KDB_METRIC_COSINE>(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
+    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) return launch_distance_t<KDB_PREC_F16, KDB_METRIC_L2>(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
+    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) return launch_distance_t<KDB_PREC_I8, KDB_METRIC_COSINE>(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
+    kdb_set_error("unsupported precision/metric combination");
+    return KDB_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's index interface for the search path.
+
+`HipIndex` plays the role of `hnsw.Index` (pkg/core/hnsw/hnsw_index.go:42-135) for everything on
+the hot path: SearchWithScores (:343), the graph/rows it searches, soft delete, plus the batch
+entry points a Go shim's micro-batcher would call.  Names, argument meaning and error behaviour
+follow the reference (`SearchWithScores(query, k, allowList, efSearch)` returns a possibly empty
+list and never raises for an empty index / empty allow-list).  All compute goes through the C ABI
+of include/kektor_hip.h into hand-written HIP kernels; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import KdbError, check
+
+L2, COSINE = 0, 1
+F32, F16, I8 = 0, 1, 2
+SEARCH_NEEDS_REFINE = 1
+SEARCH_PREPARED = 2
+
+_ELEM = {F32: np.float32, F16: np.uint16, I8: np.int8}
+
+
+@dataclass
+class SearchResult:
+    """types.SearchResult (pkg/core/types/types.go:12-15)."""
+    DocID: int
+    Score: float
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _tptr(t):
+    """device pointer of a torch tensor (plumbing only)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipIndex:
+    def __init__(self, dim: int, metric: int = COSINE, precision: int = F32, m: int = 16,
+                 ef_construction: int = 200, capacity: int = 1 << 20, device_id: int = 0):
+        self.L = _lib.load()
+        self.dim, self.metric, self.precision = int(dim), int(metric), int(precision)
+        self.m = m if m > 0 else 16
+        self.ef_construction = ef_construction if ef_construction > 0 else 200
+        self.capacity = int(capacity)
+        self.device_id = device_id
+        self.needs_refine = False
+        desc = _lib.IndexDesc(self.dim, self.metric, self.precision, self.m, self.ef_construction, self.capacity,
+                              device_id, 0)
+        h = C.c_void_p()
+        check(self.L.kdb_index_create(C.byref(desc), C.byref(h)), "kdb_index_create")
+        self.h = h
+        self._closed = False
+
+    # ---- lifecycle (Close, hnsw_index.go:3533-3586) -------------------------------------------
+    def Close(self):
+        if not self._closed and self.h:
+            self.L.kdb_index_destroy(self.h)
+            self.h = None
+            self._closed = True
+
+    close = Close
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+    def _live(self):
+        if self._closed:
+            raise KdbError("index is closed")
+
+    # ---- population ------------------------------------------------------------------------------
+    def upload_rows(self, rows, first_id: int = 1):
+        """rows: (n, dim) array already in STORED form (see kdb_index_upload_rows) or a torch device tensor."""
+        self._live()
+        if hasattr(rows, "data_ptr"):
+            assert rows.is_contiguous() and rows.shape[1] == self.dim
+            check(self.L.kdb_index_upload_rows_dev(self.h, first_id, rows.shape[0], _tptr(rows)), "upload_rows_dev")
+            return
+        a = np.ascontiguousarray(rows, dtype=_ELEM[self.precision])
+        assert a.ndim == 2 and a.shape[1] == self.dim
+        check(self.L.kdb_index_upload_rows(self.h, first_id, a.shape[0], _ptr(a)), "upload_rows")
+
+    def upload_norms(self, norms, first_id: int = 1):
+        a = np.ascontiguousarray(norms, dtype=np.float32)
+        check(self.L.kdb_index_upload_norms(self.h, first_id, a.shape[0], _ptr(a)), "upload_norms")
+
+    def set_quantizer(self, abs_max: float):
+        check(self.L.kdb_index_set_quantizer(self.h, float(abs_max)), "set_quantizer")
+
+    def set_count(self, count: int):
+        check(self.L.kdb_index_set_count(self.h, int(count)), "set_count")
+
+    def upload_graph(self, count, entry, max_level, levels, offsets, neighbors, deleted_bits=None):
+        """Per-level CSR in the layout of kdb_graph_view (lists keep the reference's stored order)."""
+        self._live()
+        nl = max_level + 1
+        levels = np.ascontiguousarray(levels, dtype=np.uint8)
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for o in offsets[:nl]]
+        nbrs = [np.ascontiguousarray(n if len(n) else np.zeros(1, np.uint32), dtype=np.uint32) for n in neighbors[:nl]]
+        op = (C.c_void_p * max(nl, 1))(*[o.ctypes.data for o in offs])
+        npp = (C.c_void_p * max(nl, 1))(*[n.ctypes.data for n in nbrs])
+        db = None if deleted_bits is None else np.ascontiguousarray(deleted_bits, dtype=np.uint64)
+        g = _lib.GraphView(int(count), int(entry), int(max_level), 0, levels.ctypes.data,
+                           C.cast(op, C.c_void_p), C.cast(npp, C.c_void_p), None if db is None else db.ctypes.data)
+        check(self.L.kdb_index_upload_graph(self.h, C.byref(g)), "upload_graph")
+
+    def upload_graph_obj(self, graph):
+        """graph: any object with count/entry/max_level/levels/offsets/neighbors/deleted_bits."""
+        self.upload_graph(graph.count, graph.entry, graph.max_level, graph.levels, graph.offsets, graph.neighbors,
+                          graph.deleted_bits)
+
+    def Delete(self, ids: Sequence[int]):
+        """soft delete by internal id (Node.Deleted, hnsw_index.go:2303)."""
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        check(self.L.kdb_index_mark_deleted(self.h, _ptr(a), a.size), "mark_deleted")
+
+    def build(self, count: int, batch: int = 0, ef_construction: int = 0, seed: int = 1):
+        """GPU batched construction over rows 1..count (addBatchInternal, hnsw_index.go:1479-2088)."""
+        p = _lib.BuildParams(batch, ef_construction, seed, 0, 0)
+        check(self.L.kdb_index_build(self.h, int(count), C.byref(p)), "kdb_index_build")
+
+    def graph_info(self):
+        c, e, ml = C.c_uint32(), C.c_uint32(), C.c_int32()
+        check(self.L.kdb_index_graph_info(self.h, C.byref(c), C.byref(e), C.byref(ml)), "graph_info")
+        return c.value, e.value, ml.value
+
+    def download_graph(self):
+        """-> (count, entry, max_level, levels, offsets[list], neighbors[list])"""
+        count, entry, max_level = self.graph_info()
+        nl = max_level + 1
+        sizes = np.zeros(max(nl, 1), dtype=np.uint64)
+        check(self.L.kdb_index_download_graph(self.h, None, None, None, _ptr(sizes)), "download_graph(sizes)")
+        levels = np.zeros(count + 1, dtype=np.uint8)
+        offs = [np.zeros(count + 2, dtype=np.uint64) for _ in range(nl)]
+        nbrs = [np.zeros(max(int(sizes[l]), 1), dtype=np.uint32) for l in range(nl)]
+        op = (C.c_void_p * max(nl, 1))(*[o.ctypes.data for o in offs])
+        npp = (C.c_void_p * max(nl, 1))(*[n.ctypes.data for n in nbrs])
+        check(self.L.kdb_index_download_graph(self.h, _ptr(levels), C.cast(op, C.c_void_p), C.cast(npp, C.c_void_p),
+                                              _ptr(sizes)), "download_graph")
+        nbrs = [nbrs[l][:int(sizes[l])] for l in range(nl)]
+        return count, entry, max_level, levels, offs, nbrs
+
+    def download_rows(self, first_id: int, n: int):
+        out = np.zeros((n, self.dim), dtype=_ELEM[self.precision])
+        check(self.L.kdb_index_download_rows(self.h, first_id, n, _ptr(out)), "download_rows")
+        return out
+
+    # ---- search ----------------------------------------------------------------------------------
+    def _flags(self, prepared=False):
+        return (SEARCH_NEEDS_REFINE if self.needs_refine else 0) | (SEARCH_PREPARED if prepared else 0)
+
+    def search_batch(self, queries, k: int, ef: int = 0, allow_bits=None, trace: bool = False, prepared=False):
+        """B queries -> (ids [B,k] u32, raw dist [B,k] f32, count [B] u32[, (n_dist[B], n_hops[B])])."""
+        self._live()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        assert q.ndim == 2 and q.shape[1] == self.dim
+        B = q.shape[0]
+        ids = np.zeros((B, k), dtype=np.uint32)
+        dist = np.full((B, k), np.inf, dtype=np.float32)
+        cnt = np.zeros(B, dtype=np.uint32)
+        ab = None if allow_bits is None else np.ascontiguousarray(allow_bits, dtype=np.uint64)
+        nd = nh = None
+        if trace:
+            nd = np.zeros(B, dtype=np.uint32)
+            nh = np.zeros(B, dtype=np.uint32)
+            check(self.L.kdb_search_set_trace(self.h, _ptr(nd), _ptr(nh), 0), "set_trace")
+        try:
+            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared), _ptr(ids),
+                                          _ptr(dist), _ptr(cnt)), "kdb_search_batch")
+        finally:
+            if trace:
+                self.L.kdb_search_set_trace(self.h, None, None, 0)
+        if trace:
+            return ids, dist, cnt, (nd, nh)
+        return ids, dist, cnt
+
+    def search_batch_dev(self, d_queries, k: int, ef: int, d_out_ids, d_out_dist, d_out_count, d_allow=None,
+                         stream=None, prepared=False):
+        """torch device tensors in, asynchronous on `stream` (a raw hipStream_t int or None)."""
+        self._live()
+        B = d_queries.shape[0]
+        check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared),
+                                          _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
+                                          C.c_void_p(stream) if stream else None), "kdb_search_batch_dev")
+
+    def flat_scan_batch(self, queries, k: int, allow_bits=None):
+        self._live()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        B = q.shape[0]
+        ids = np.zeros((B, k), dtype=np.uint32)
+        dist = np.full((B, k), np.inf, dtype=np.float32)
+        cnt = np.zeros(B, dtype=np.uint32)
+        ab = None if allow_bits is None else np.ascontiguousarray(allow_bits, dtype=np.uint64)
+        check(self.L.kdb_flat_scan_batch(self.h, _ptr(q), B, k, _ptr(ab), self._flags(), _ptr(ids), _ptr(dist),
+                                         _ptr(cnt)), "kdb_flat_scan_batch")
+        return ids, dist, cnt
+
+    def flat_scan_batch_dev(self, d_queries, k, d_out_ids, d_out_dist, d_out_count, d_allow=None, stream=None):
+        self._live()
+        B = d_queries.shape[0]
+        check(self.L.kdb_flat_scan_batch_dev(self.h, _tptr(d_queries), B, k, _tptr(d_allow), self._flags(),
+                                             _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
+                                             C.c_void_p(stream) if stream else None), "kdb_flat_scan_batch_dev")
+
+    def distance_batch(self, queries, ids, prepared=False):
+        """raw accumulates [B, C] of B queries against ids[B, C] (0 = skip -> +inf)."""
+        self._live()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        ii = np.ascontiguousarray(ids, dtype=np.uint32)
+        B, Cn = ii.shape
+        out = np.zeros((B, Cn), dtype=np.float32)
+        check(self.L.kdb_distance_batch(self.h, _ptr(q), B, _ptr(ii), Cn, self._flags(prepared), _ptr(out)),
+              "kdb_distance_batch")
+        return out
+
+    def distance_batch_dev(self, d_queries, d_ids, d_out, stream=None, prepared=False):
+        B, Cn = d_ids.shape
+        check(self.L.kdb_distance_batch_dev(self.h, _tptr(d_queries), B, _tptr(d_ids), Cn, self._flags(prepared),
+                                            _tptr(d_out), C.c_void_p(stream) if stream else None),
+              "kdb_distance_batch_dev")
+
+    def counters(self):
+        c = _lib.Counters()
+        check(self.L.kdb_get_counters(self.h, C.byref(c)), "get_counters")
+        return {"n_dist": int(c.n_dist), "n_hops": int(c.n_hops), "bytes": int(c.bytes),
+                "kernel_ms": float(c.last_kernel_ms)}
+
+    def sync(self):
+        check(self.L.kdb_index_sync(self.h), "sync")
+
+    # ---- the reference's per-query API --------------------------------------------------------------
+    def score(self, raw: float) -> float:
+        """The reference's f64 epilogue: float64(sum) (distance_go.go:67) / 1.0-float64(dot) (:127)."""
+        if self.precision == F32 and self.metric == COSINE:
+            return 1.0 - float(raw)
+        return float(raw)
+
+    def SearchWithScores(self, query, k: int, allowList=None, efSearch: int = 0) -> List[SearchResult]:
+        """core.VectorIndex.SearchWithScores (pkg/core/vector_index.go:35; hnsw_index.go:343-366).
+        allowList: None (nil) or a dense uint64 bitset over internal ids (the shim converts roaring)."""
+        if self._closed:
+            return []
+        try:
+            ids, dist, cnt = self.search_batch(np.asarray(query, dtype=np.float32)[None, :], k, efSearch, allowList)
+        except KdbError:
+            return []  # the reference logs and returns an empty slice (:356-359)
+        n = int(cnt[0])
+        return [SearchResult(int(ids[0, i]), self.score(dist[0, i])) for i in range(n)]
+
+
+def merge_topk(metric: int, ids, dist, count, k: int):
+    """Host shard merge through the C ABI (kdb_merge_topk): ids/dist [G,B,k], count [G,B]."""
+    L = _lib.load()
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    count = np.ascontiguousarray(count, dtype=np.uint32)
+    G, B = count.shape
+    o_ids = np.zeros((B, k), dtype=np.uint32)
+    o_dist = np.zeros((B, k), dtype=np.float32)
+    o_cnt = np.zeros(B, dtype=np.uint32)
+    check(L.kdb_merge_topk(metric, G, B, k, _ptr(ids), _ptr(dist), _ptr(count), _ptr(o_ids), _ptr(o_dist),
+                           _ptr(o_cnt)), "kdb_merge_topk")
+    return o_ids, o_dist, o_cnt
+
+
+def dense_bitset(ids: Sequence[int], count: int) -> np.ndarray:
+    """roaring.Bitmap -> dense uint64 words ((count>>6)+1), the form the allow-list crosses the ABI in."""
+    w = np.zeros((count >> 6) + 1, dtype=np.uint64)
+    a = np.asarray(list(ids), dtype=np.uint64)
+    if a.size:
+        np.bitwise_or.at(w, (a >> np.uint64(6)).astype(np.int64), np.uint64(1) << (a & np.uint64(63)))
+    return w

@@ -1,0 +1,1221 @@
+/*
+ * kdb_oracle.c -- CPU restatement of KektorDB's HNSW search / distance hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * `cpu_baseline` leg and __graft_entry__.smoke() may load it, and only as the
+ * checker / CPU baseline.  Nothing under kektordb_amd/ links or calls it.
+ *
+ * It is a from-scratch C restatement (no reference source is copied) of the
+ * reference algorithm; every function cites the reference file:line it follows
+ * (paths relative to the upstream repository root):
+ *
+ *   pkg/core/hnsw/hnsw_index.go    343-468   SearchWithScores / searchInternal
+ *   pkg/core/hnsw/hnsw_index.go    2351-2611 searchLayerUnlocked
+ *   pkg/core/hnsw/hnsw_index.go    2616-2701 randomLevel / selectNeighbors
+ *   pkg/core/hnsw/hnsw_index.go    472-809   Add (sequential insert)
+ *   pkg/core/hnsw/hnsw_index.go    297-340   distanceBetweenNodes
+ *   pkg/core/hnsw/hnsw_index.go    3030-3045 normalize / invSqrt
+ *   pkg/core/hnsw/hnsw_index.go    3371-3377 computeInt8Norm
+ *   pkg/core/hnsw/hnsw_heap.go     18-156    minHeap / maxHeap
+ *   pkg/core/hnsw/bitset.go        1-56      BitSet
+ *   pkg/core/distance/distance_go.go 57-128  scalar distance routines
+ *   pkg/core/distance/quantizer.go 49-198    Quantizer
+ *   native/compute/src/lib.rs      22-193    AVX2 accumulation order (-tags rust)
+ *   pkg/core/vector_index.go       104-162   BruteForceIndex flat scan
+ *
+ * PARITY PINNING.  The reference is Go + Rust; neither toolchain exists in the
+ * build container, so the reference itself cannot be executed here.  The oracle
+ * is pinned against every known-answer test the reference holds for this path
+ * (tests/test_oracle_kat.py):  distance KATs (distance_test.go:37-84,
+ * lib.rs:423-458), heap pop orders (hnsw_heap_test.go:9-54), self-match ranks
+ * first at ef=12/100 (pkg/client/client_test.go:171-236), recall@10 >= 0.95 on
+ * 10k x 64 uniform L2 (clients/python/stress_test_recall.py:11-87).
+ * Bit-level accumulation order of the cosine kernel (gonum v0.16.0 Sdot amd64
+ * assembly, a go.mod dependency absent from the reference tree) is PARITY
+ * UNPINNED; tolerance-level parity (1e-6) is pinned by distance_test.go:47-57.
+ *
+ * Arithmetic variants (`arith`): the reference has several f32 accumulation
+ * orders depending on build tags; the HIP kernels have their own.  All are
+ * restated so that (a) GPU-vs-oracle can be compared bit-exactly using the
+ * GPU's order and (b) the GPU order can be compared within tolerance against
+ * the reference orders.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+enum { ORC_L2 = 0, ORC_COSINE = 1 };
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_I8 = 2 };
+enum {
+    ORC_ARITH_GO = 0,       /* default build: scalar L2 loop; cosine = BLAS-style Sdot stand-in */
+    ORC_ARITH_RUST = 1,     /* -tags rust: AVX2 8-lane L2 for len>=128; cosine as GO          */
+    ORC_ARITH_GOPURE = 2,   /* pure-Go sequential dot (distance_go.go:80-89)                  */
+    ORC_ARITH_HIP_WAVE = 3, /* kektordb_amd traversal kernel order (16-lane groups)           */
+    ORC_ARITH_HIP_MFMA = 4  /* kektordb_amd flat-scan MFMA order (k-permuted fmaf chain)      */
+};
+
+typedef struct {
+    uint64_t n_dist;   /* distance evaluations (distFn calls) */
+    uint64_t n_hops;   /* candidates popped AND expanded      */
+} orc_counters;
+
+/* ------------------------------------------------------------------------- */
+/* f16 <-> f32 (x448/float16 v0.8.4 semantics: IEEE binary16, RNE)            */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+ORC_EXPORT float orc_f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t man = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return bits_f32(sign);
+        /* subnormal: value = man * 2^-24 */
+        float v = (float)man * (1.0f / 16777216.0f);
+        return sign ? -v : v;
+    }
+    if (exp == 31) return bits_f32(sign | 0x7f800000u | (man << 13));
+    return bits_f32(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+ORC_EXPORT uint16_t orc_f32_to_f16(float f) {
+    uint32_t x = f32_bits(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { /* inf / nan */
+        if (ax == 0x7f800000u) return (uint16_t)(sign | 0x7c00u);
+        return (uint16_t)(sign | 0x7c00u | 0x200u | ((ax >> 13) & 0x3ffu));
+    }
+    if (ax >= 0x477ff000u) { /* rounds to >= 65520 -> inf */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax < 0x33000001u) { /* < 2^-25 (or == 2^-25 ties to even zero) */
+        return (uint16_t)sign;
+    }
+    int32_t e = (int32_t)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    if (e < -14) { /* subnormal half */
+        int shift = -14 - e + 13; /* bits to drop from 24-bit mantissa */
+        uint32_t half = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1u))) half++;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3ffu);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;
+    return (uint16_t)(sign | half);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Distance routines                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* distance_go.go:57-68 squaredEuclideanDistanceGo: scalar, sequential, f32.  */
+ORC_EXPORT float orc_l2_f32_go(const float *a, const float *b, size_t n) {
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float diff = a[i] - b[i];
+        float sq = diff * diff;
+        sum = sum + sq;
+    }
+    return sum;
+}
+
+/* distance_go.go:80-89 dotProductGo: scalar sequential mul+add (Go/amd64 does
+ * not fuse). */
+ORC_EXPORT float orc_dot_f32_go(const float *a, const float *b, size_t n) {
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float p = a[i] * b[i];
+        sum = sum + p;
+    }
+    return sum;
+}
+
+/* Stand-in for gonum v0.16.0 blas/gonum Sdot -> internal/asm/f32.DotUnitary
+ * (amd64 assembly, NOT present under the reference tree; call sites
+ * distance_go.go:119-128).  Restated as a BLAS-style unrolled kernel: four
+ * 4-lane accumulators over 16 floats per iteration (mul then add, SSE has no
+ * FMA), accumulators summed pairwise, horizontal add, scalar tail.  Bit-level
+ * order is UNPINNED (see header).                                            */
+ORC_EXPORT float orc_dot_f32_blas(const float *a, const float *b, size_t n) {
+    float acc[4][4];
+    memset(acc, 0, sizeof acc);
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16)
+        for (int r = 0; r < 4; r++)
+            for (int l = 0; l < 4; l++) {
+                float p = a[i + 4 * r + l] * b[i + 4 * r + l];
+                acc[r][l] = acc[r][l] + p;
+            }
+    float v[4];
+    for (int l = 0; l < 4; l++) v[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+    float sum = (v[0] + v[1]) + (v[2] + v[3]);
+    for (; i < n; i++) {
+        float p = a[i] * b[i];
+        sum = sum + p;
+    }
+    return sum;
+}
+
+/* lib.rs:22-31 reduce_sum_ps: (lo+hi) -> movehl add -> shuffle add. */
+static inline float reduce8(const float v[8]) {
+    float s4[4];
+    for (int l = 0; l < 4; l++) s4[l] = v[l] + v[l + 4];
+    float s2[2];
+    s2[0] = s4[0] + s4[2];
+    s2[1] = s4[1] + s4[3];
+    return s2[0] + s2[1];
+}
+
+typedef float v8f __attribute__((vector_size(32)));
+
+/* lib.rs:34-71 squared_euclidean_f32_fma: 8 lanes, fused multiply-add, tree
+ * reduce, then scalar tail (mul + add, unfused). */
+ORC_EXPORT float orc_l2_f32_avx2(const float *a, const float *b, size_t n) {
+    v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        v8f x, y;
+        memcpy(&x, a + i, 32);
+        memcpy(&y, b + i, 32);
+        v8f d = x - y;
+#if defined(__FMA__) && defined(__AVX2__)
+        acc = (v8f)_mm256_fmadd_ps((__m256)d, (__m256)d, (__m256)acc);
+#else
+        for (int l = 0; l < 8; l++) acc[l] = fmaf(d[l], d[l], acc[l]);
+#endif
+    }
+    float lanes[8];
+    memcpy(lanes, &acc, 32);
+    float total = reduce8(lanes);
+    for (; i < n; i++) {
+        float d = a[i] - b[i];
+        float sq = d * d;
+        total = total + sq;
+    }
+    return total;
+}
+
+/* lib.rs:74-99 dot_product_f32_fma (exported by the Rust lib, not installed
+ * in any Go dispatch table -- SURVEY section 2). */
+ORC_EXPORT float orc_dot_f32_avx2(const float *a, const float *b, size_t n) {
+    v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        v8f x, y;
+        memcpy(&x, a + i, 32);
+        memcpy(&y, b + i, 32);
+#if defined(__FMA__) && defined(__AVX2__)
+        acc = (v8f)_mm256_fmadd_ps((__m256)x, (__m256)y, (__m256)acc);
+#else
+        for (int l = 0; l < 8; l++) acc[l] = fmaf(x[l], y[l], acc[l]);
+#endif
+    }
+    float lanes[8];
+    memcpy(lanes, &acc, 32);
+    float total = reduce8(lanes);
+    for (; i < n; i++) {
+        float p = a[i] * b[i];
+        total = total + p;
+    }
+    return total;
+}
+
+/* HIP traversal-kernel order (kektordb_amd/csrc/kdb_device.cuh
+ * row_partial/group_reduce16).  16 lanes share a row.  Lane t handles the
+ * float4 chunks c = t, t+16, t+32, ... ; component j of every chunk goes to
+ * accumulator j with fmaf; the four accumulators combine as (a0+a1)+(a2+a3);
+ * the 16 lane partials reduce by an xor-butterfly 8,4,2,1.  `ld` (row stride,
+ * multiple of 4) >= n; elements in [n, ld) are zero in device memory, which
+ * leaves every sum unchanged, so the oracle simply stops at n.              */
+static inline float hip_wave_reduce16(float p[16]) {
+    for (int t = 0; t < 8; t++) p[t] = p[t] + p[t + 8];
+    for (int t = 0; t < 4; t++) p[t] = p[t] + p[t + 4];
+    for (int t = 0; t < 2; t++) p[t] = p[t] + p[t + 2];
+    return p[0] + p[1];
+}
+
+ORC_EXPORT float orc_dot_f32_hipwave(const float *a, const float *b, size_t n) {
+    float p[16];
+    size_t nchunks = (n + 3) / 4;
+    for (int t = 0; t < 16; t++) {
+        float acc[4] = {0, 0, 0, 0};
+        for (size_t c = (size_t)t; c < nchunks; c += 16)
+            for (int j = 0; j < 4; j++) {
+                size_t k = 4 * c + (size_t)j;
+                float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
+                acc[j] = fmaf(x, y, acc[j]);
+            }
+        p[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    return hip_wave_reduce16(p);
+}
+
+ORC_EXPORT float orc_l2_f32_hipwave(const float *a, const float *b, size_t n) {
+    float p[16];
+    size_t nchunks = (n + 3) / 4;
+    for (int t = 0; t < 16; t++) {
+        float acc[4] = {0, 0, 0, 0};
+        for (size_t c = (size_t)t; c < nchunks; c += 16)
+            for (int j = 0; j < 4; j++) {
+                size_t k = 4 * c + (size_t)j;
+                float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
+                float d = x - y;
+                acc[j] = fmaf(d, d, acc[j]);
+            }
+        p[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    return hip_wave_reduce16(p);
+}
+
+/* HIP flat-scan MFMA order (kektordb_amd/csrc/flat_scan.hip): one fmaf chain
+ * per (query,row) pair, K visited in blocks of 16: for s, for j<4, for g<4:
+ * k = 16 s + 4 g + j   (v_mfma_f32_16x16x4_f32 consumes k-slots g = 0..3 in
+ * order; each lane feeds component j of a float4 it loaded at 16 s + 4 g).  */
+ORC_EXPORT float orc_dot_f32_hipmfma(const float *a, const float *b, size_t n) {
+    float acc = 0.0f;
+    size_t nb = (n + 15) / 16;
+    for (size_t s = 0; s < nb; s++)
+        for (int j = 0; j < 4; j++)
+            for (int g = 0; g < 4; g++) {
+                size_t k = 16 * s + 4 * (size_t)g + (size_t)j;
+                float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
+                acc = fmaf(x, y, acc);
+            }
+    return acc;
+}
+
+/* distance_go.go:92-104 squaredEuclideanGoFloat16 (and lib.rs:102-143: same
+ * f32 math after conversion; the AVX2 order is the f32 AVX2 order).          */
+ORC_EXPORT float orc_l2_f16_go(const uint16_t *a, const uint16_t *b, size_t n) {
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float d = orc_f16_to_f32(a[i]) - orc_f16_to_f32(b[i]);
+        float sq = d * d;
+        sum = sum + sq;
+    }
+    return sum;
+}
+
+ORC_EXPORT float orc_l2_f16_hipwave(const uint16_t *a, const uint16_t *b, size_t n) {
+    /* device order for f16 rows: 16 lanes per row, lane t handles 8-element
+     * chunks c = t, t+16, ...; component j -> accumulator j&3.               */
+    float p[16];
+    size_t nchunks = (n + 7) / 8;
+    for (int t = 0; t < 16; t++) {
+        float acc[4] = {0, 0, 0, 0};
+        for (size_t c = (size_t)t; c < nchunks; c += 16)
+            for (int j = 0; j < 8; j++) {
+                size_t k = 8 * c + (size_t)j;
+                float x = k < n ? orc_f16_to_f32(a[k]) : 0.0f;
+                float y = k < n ? orc_f16_to_f32(b[k]) : 0.0f;
+                float d = x - y;
+                acc[j & 3] = fmaf(d, d, acc[j & 3]);
+            }
+        p[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    return hip_wave_reduce16(p);
+}
+
+/* distance_go.go:107-116 dotProductGoInt8 / lib.rs:146-192: exact i32. */
+ORC_EXPORT int32_t orc_dot_i8(const int8_t *a, const int8_t *b, size_t n) {
+    int32_t sum = 0;
+    for (size_t i = 0; i < n; i++) sum += (int32_t)a[i] * (int32_t)b[i];
+    return sum;
+}
+
+/* hnsw_index.go:3030-3045 normalize + invSqrt. */
+ORC_EXPORT void orc_normalize(float *v, size_t n) {
+    float normSq = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float sq = v[i] * v[i];
+        normSq = normSq + sq;
+    }
+    if (normSq > 0.0f) {
+        float inv = 1.0f / (float)sqrt((double)normSq);
+        for (size_t i = 0; i < n; i++) v[i] = v[i] * inv;
+    }
+}
+
+/* hnsw_index.go:3371-3377 computeInt8Norm. */
+ORC_EXPORT float orc_int8_norm(const int8_t *v, size_t n) {
+    int64_t sum = 0;
+    for (size_t i = 0; i < n; i++) sum += (int64_t)v[i] * (int64_t)v[i];
+    return (float)sqrt((double)sum);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Quantizer (quantizer.go:49-198)                                            */
+/* ------------------------------------------------------------------------- */
+static int cmp_f32(const void *a, const void *b) {
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* quantizer.go:49-135 Train: strided sample when > 10k vectors, 99.9th
+ * percentile of |v|. Returns AbsMax (0 when the input is empty).            */
+ORC_EXPORT float orc_quantizer_train(const float *vectors, size_t total, size_t dim) {
+    if (total == 0 || dim == 0) return 0.0f;
+    size_t nsel = total;
+    size_t step = 1;
+    const size_t HardCap = 25000, MinThreshold = 10000;
+    if (total > MinThreshold) {
+        size_t target = total / 10;
+        if (target > HardCap) target = HardCap;
+        if (target < MinThreshold) target = MinThreshold;
+        step = total / target;
+        if (step < 1) step = 1;
+        nsel = 0;
+        for (size_t i = 0; i < total; i += step) {
+            nsel++;
+            if (nsel >= target) break;
+        }
+    }
+    float *vals = (float *)malloc(nsel * dim * sizeof(float));
+    size_t w = 0, cnt = 0;
+    for (size_t i = 0; i < total && cnt < nsel; i += step, cnt++)
+        for (size_t d = 0; d < dim; d++) vals[w++] = (float)fabs((double)vectors[i * dim + d]);
+    qsort(vals, w, sizeof(float), cmp_f32);
+    long qi = (long)((double)w * 0.999);
+    if (qi >= (long)w) qi = (long)w - 1;
+    if (qi < 0) qi = 0;
+    float r = vals[qi];
+    free(vals);
+    return r;
+}
+
+/* quantizer.go:150-176 Quantize: scale, clip to +-127, math.Round (half away
+ * from zero). */
+ORC_EXPORT void orc_quantize(const float *v, size_t n, float absmax, int8_t *out) {
+    if (absmax == 0.0f) {
+        memset(out, 0, n);
+        return;
+    }
+    for (size_t i = 0; i < n; i++) {
+        float q = v[i] / absmax;
+        float scaled = q * 127.0f;
+        if (scaled > 127.0f) scaled = 127.0f;
+        else if (scaled < -127.0f) scaled = -127.0f;
+        out[i] = (int8_t)round((double)scaled);
+    }
+}
+
+/* quantizer.go:181-198 Dequantize. */
+ORC_EXPORT void orc_dequantize(const int8_t *v, size_t n, float absmax, float *out) {
+    for (size_t i = 0; i < n; i++) {
+        if (absmax == 0.0f) { out[i] = 0.0f; continue; }
+        float t = (float)v[i] / 127.0f;
+        out[i] = t * absmax;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Heaps (hnsw_heap.go:18-156): value-type binary heaps, strict sift rules.   */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t id; double dist; } orc_cand; /* types.go:19-22 */
+
+typedef struct { orc_cand *a; size_t len, cap; int is_max; } orc_heap;
+
+static void heap_init(orc_heap *h, int is_max) { h->a = NULL; h->len = h->cap = 0; h->is_max = is_max; }
+static void heap_free(orc_heap *h) { free(h->a); h->a = NULL; h->len = h->cap = 0; }
+static inline int heap_before(const orc_heap *h, double x, double y) { return h->is_max ? (x > y) : (x < y); }
+
+static void heap_push(orc_heap *h, orc_cand x) { /* Push + up, :33-36,53-63 */
+    if (h->len == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : 64;
+        h->a = (orc_cand *)realloc(h->a, h->cap * sizeof(orc_cand));
+    }
+    h->a[h->len++] = x;
+    size_t j = h->len - 1;
+    for (;;) {
+        /* Go: i := (j-1)/2 with int division truncating toward zero: j=0 -> i=0 */
+        size_t i = j == 0 ? 0 : (j - 1) / 2;
+        if (i == j || !heap_before(h, h->a[j].dist, h->a[i].dist)) break;
+        orc_cand t = h->a[i]; h->a[i] = h->a[j]; h->a[j] = t;
+        j = i;
+    }
+}
+
+static orc_cand heap_pop(orc_heap *h) { /* Pop + down, :39-51,65-82 */
+    orc_cand x = h->a[0];
+    h->a[0] = h->a[h->len - 1];
+    h->len--;
+    size_t n = h->len, i = 0;
+    if (n > 0) {
+        for (;;) {
+            size_t j1 = 2 * i + 1;
+            if (j1 >= n) break;
+            size_t j = j1, j2 = j1 + 1;
+            if (j2 < n && heap_before(h, h->a[j2].dist, h->a[j1].dist)) j = j2;
+            if (!heap_before(h, h->a[j].dist, h->a[i].dist)) break;
+            orc_cand t = h->a[i]; h->a[i] = h->a[j]; h->a[j] = t;
+            i = j;
+        }
+    }
+    return x;
+}
+
+/* Test hook for hnsw_heap_test.go:9-54: push (id,dist) pairs, pop all. */
+ORC_EXPORT void orc_heap_order(int is_max, const uint32_t *ids, const double *dists, size_t n,
+                               uint32_t *out_ids, double *out_dists) {
+    orc_heap h;
+    heap_init(&h, is_max);
+    for (size_t i = 0; i < n; i++) { orc_cand c = {ids[i], dists[i]}; heap_push(&h, c); }
+    for (size_t i = 0; i < n; i++) { orc_cand c = heap_pop(&h); out_ids[i] = c.id; out_dists[i] = c.dist; }
+    heap_free(&h);
+}
+
+/* ------------------------------------------------------------------------- */
+/* BitSet (bitset.go:1-56)                                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint64_t *w; size_t nw; } orc_bitset;
+static void bs_ensure(orc_bitset *b, uint32_t maxv) {
+    size_t need = ((size_t)maxv >> 6) + 1;
+    if (b->nw < need) {
+        b->w = (uint64_t *)realloc(b->w, need * 8);
+        memset(b->w + b->nw, 0, (need - b->nw) * 8);
+        b->nw = need;
+    }
+}
+static inline void bs_add(orc_bitset *b, uint32_t n) {
+    if (((size_t)n >> 6) >= b->nw) bs_ensure(b, n);
+    b->w[n >> 6] |= 1ull << (n & 63);
+}
+static inline int bs_has(const orc_bitset *b, uint32_t n) {
+    if (((size_t)n >> 6) >= b->nw) return 0;
+    return (b->w[n >> 6] >> (n & 63)) & 1;
+}
+static void bs_clear(orc_bitset *b) { memset(b->w, 0, b->nw * 8); } /* :44-48, O(N/64) */
+
+/* ------------------------------------------------------------------------- */
+/* Index (hnsw_node.go:13-68 Node; hnsw_index.go:42-135 Index)                */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t *ids;
+    uint32_t len, cap;
+} orc_list;
+
+typedef struct {
+    int nlevels;      /* len(Connections) = level+1; 0 => nil node */
+    orc_list *conn;   /* [nlevels] */
+    uint8_t deleted;
+} orc_node;
+
+typedef struct orc_index {
+    int dim, metric, precision, m, mmax0, efc;
+    double ml;
+    size_t elem;            /* bytes per element                      */
+    uint8_t *rows;          /* (cap+1) rows, row 0 unused (ids 1-based, hnsw_index.go:590) */
+    int rows_borrowed;
+    float *norms;           /* int8 only: quantizedNorms[id]          */
+    orc_node *nodes;
+    size_t cap;
+    uint32_t counter;       /* nodeCounter                            */
+    uint32_t entry;
+    int max_level;          /* -1 when empty                          */
+    int needs_refine;
+    float absmax;           /* quantizer                              */
+    int arith;
+    uint64_t rng;
+    /* scratch (pooled in the reference, hnsw_index.go:169-190) */
+    orc_bitset visited;
+    orc_heap cands, results;
+    orc_counters ctr;
+} orc_index;
+
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+ORC_EXPORT orc_index *orc_index_new(int dim, int metric, int precision, int m, int efc, uint64_t seed) {
+    /* hnsw_index.go:138-232 New: defaults m=16, efC=200, mMax0=2m, ml=1/ln m;
+     * f16 only L2, int8 only cosine. */
+    if (m <= 0) m = 16;
+    if (efc <= 0) efc = 200;
+    if (precision == ORC_F16 && metric != ORC_L2) return NULL;
+    if (precision == ORC_I8 && metric != ORC_COSINE) return NULL;
+    orc_index *h = (orc_index *)calloc(1, sizeof *h);
+    h->dim = dim; h->metric = metric; h->precision = precision;
+    h->m = m; h->mmax0 = 2 * m; h->efc = efc;
+    h->ml = 1.0 / log((double)m);
+    h->elem = precision == ORC_F32 ? 4 : precision == ORC_F16 ? 2 : 1;
+    h->max_level = -1;
+    h->rng = seed;
+    h->arith = ORC_ARITH_GO;
+    heap_init(&h->cands, 0);
+    heap_init(&h->results, 1);
+    return h;
+}
+
+ORC_EXPORT void orc_index_free(orc_index *h) {
+    if (!h) return;
+    for (size_t i = 0; i <= h->cap && h->nodes; i++) {
+        for (int l = 0; l < h->nodes[i].nlevels; l++) free(h->nodes[i].conn[l].ids);
+        free(h->nodes[i].conn);
+    }
+    free(h->nodes);
+    if (!h->rows_borrowed) free(h->rows);
+    free(h->norms);
+    free(h->visited.w);
+    heap_free(&h->cands);
+    heap_free(&h->results);
+    free(h);
+}
+
+ORC_EXPORT void orc_index_set_arith(orc_index *h, int arith) { h->arith = arith; }
+ORC_EXPORT void orc_index_set_needs_refine(orc_index *h, int v) { h->needs_refine = v; }
+ORC_EXPORT void orc_index_set_absmax(orc_index *h, float a) { h->absmax = a; }
+ORC_EXPORT float orc_index_absmax(const orc_index *h) { return h->absmax; }
+ORC_EXPORT uint32_t orc_index_count(const orc_index *h) { return h->counter; }
+ORC_EXPORT uint32_t orc_index_entry(const orc_index *h) { return h->entry; }
+ORC_EXPORT int orc_index_max_level(const orc_index *h) { return h->max_level; }
+ORC_EXPORT const void *orc_index_rows(const orc_index *h) { return h->rows; }
+ORC_EXPORT const float *orc_index_norms(const orc_index *h) { return h->norms; }
+ORC_EXPORT void orc_index_mark_deleted(orc_index *h, uint32_t id) {
+    if (id >= 1 && id <= h->counter) h->nodes[id].deleted = 1;
+}
+
+static void index_grow(orc_index *h, uint32_t id) { /* growNodes, :2732-2768 */
+    if ((size_t)id <= h->cap && h->nodes) return;
+    size_t ncap = h->cap ? h->cap : 1024;
+    while (ncap <= id) ncap *= 2;
+    h->nodes = (orc_node *)realloc(h->nodes, (ncap + 1) * sizeof(orc_node));
+    memset(h->nodes + (h->cap ? h->cap + 1 : 0), 0, (ncap + 1 - (h->cap ? h->cap + 1 : 0)) * sizeof(orc_node));
+    if (!h->rows_borrowed) {
+        h->rows = (uint8_t *)realloc(h->rows, (ncap + 1) * (size_t)h->dim * h->elem);
+        if (h->cap == 0) memset(h->rows, 0, (size_t)h->dim * h->elem);
+    }
+    if (h->precision == ORC_I8) {
+        h->norms = (float *)realloc(h->norms, (ncap + 1) * sizeof(float));
+        for (size_t i = h->cap ? h->cap + 1 : 0; i <= ncap; i++) h->norms[i] = 0.0f;
+    }
+    h->cap = ncap;
+}
+
+static inline const void *row_ptr(const orc_index *h, uint32_t id) {
+    return h->rows + (size_t)id * (size_t)h->dim * h->elem;
+}
+
+/* f32 pair distance under the selected arithmetic. Returns the reference's
+ * f64 distance: float64(sum) for L2 (distance_go.go:67), 1.0-float64(dot) for
+ * cosine (distance_go.go:127).                                               */
+static double pair_f32(const orc_index *h, const float *a, const float *b) {
+    size_t n = (size_t)h->dim;
+    if (h->metric == ORC_L2) {
+        float s;
+        switch (h->arith) {
+        case ORC_ARITH_RUST: s = n >= 128 ? orc_l2_f32_avx2(a, b, n) : orc_l2_f32_go(a, b, n); break; /* distance_rust.go:166-171 */
+        case ORC_ARITH_HIP_WAVE: s = orc_l2_f32_hipwave(a, b, n); break;
+        case ORC_ARITH_HIP_MFMA: s = orc_l2_f32_hipwave(a, b, n); break; /* finalists are re-scored by the wave kernel */
+        default: s = orc_l2_f32_go(a, b, n); break;
+        }
+        return (double)s;
+    }
+    float d;
+    switch (h->arith) {
+    case ORC_ARITH_GOPURE: d = orc_dot_f32_go(a, b, n); break;
+    case ORC_ARITH_HIP_WAVE: d = orc_dot_f32_hipwave(a, b, n); break;
+    case ORC_ARITH_HIP_MFMA: d = orc_dot_f32_hipmfma(a, b, n); break;
+    default: d = orc_dot_f32_blas(a, b, n); break; /* gonum in both builds, distance_rust.go:186 */
+    }
+    return 1.0 - (double)d;
+}
+
+static double scale_i8(int32_t dot, float n1, float n2) { /* :317-336, :2429-2454 */
+    if (n1 == 0.0f || n2 == 0.0f) return 1.0;
+    double sim = (double)dot / ((double)n1 * (double)n2);
+    if (sim > 1.0) sim = 1.0;
+    if (sim < -1.0) sim = -1.0;
+    return 1.0 - sim;
+}
+
+/* hnsw_index.go:297-340 distanceBetweenNodes. */
+static double node_node(orc_index *h, uint32_t a, uint32_t b) {
+    h->ctr.n_dist++;
+    switch (h->precision) {
+    case ORC_F32: return pair_f32(h, (const float *)row_ptr(h, a), (const float *)row_ptr(h, b));
+    case ORC_F16: {
+        const uint16_t *x = (const uint16_t *)row_ptr(h, a), *y = (const uint16_t *)row_ptr(h, b);
+        float s = h->arith == ORC_ARITH_HIP_WAVE ? orc_l2_f16_hipwave(x, y, (size_t)h->dim) : orc_l2_f16_go(x, y, (size_t)h->dim);
+        return (double)s;
+    }
+    default: {
+        int32_t dot = orc_dot_i8((const int8_t *)row_ptr(h, a), (const int8_t *)row_ptr(h, b), (size_t)h->dim);
+        return scale_i8(dot, h->norms[a], h->norms[b]);
+    }
+    }
+}
+
+/* Prepared query (searchInternal Phase 0, :404-434). */
+typedef struct {
+    const float *f32;
+    const uint16_t *f16;
+    const int8_t *i8;
+    float qnorm; /* int8: sqrt(sum q^2), 0 -> 1 (:2411-2418) */
+} orc_query;
+
+static double query_node(orc_index *h, const orc_query *q, uint32_t id) { /* distFn, :2386-2458 */
+    h->ctr.n_dist++;
+    switch (h->precision) {
+    case ORC_F32: return pair_f32(h, q->f32, (const float *)row_ptr(h, id));
+    case ORC_F16: {
+        const uint16_t *y = (const uint16_t *)row_ptr(h, id);
+        float s = h->arith == ORC_ARITH_HIP_WAVE ? orc_l2_f16_hipwave(q->f16, y, (size_t)h->dim) : orc_l2_f16_go(q->f16, y, (size_t)h->dim);
+        return (double)s;
+    }
+    default: {
+        int32_t dot = orc_dot_i8(q->i8, (const int8_t *)row_ptr(h, id), (size_t)h->dim);
+        float sn = h->norms[id];
+        if (sn == 0.0f) return 1.0;
+        double sim = (double)dot / ((double)q->qnorm * (double)sn);
+        if (sim > 1.0) sim = 1.0;
+        if (sim < -1.0) sim = -1.0;
+        return 1.0 - sim;
+    }
+    }
+}
+
+/* Allow-list as a dense bitset standing in for *roaring.Bitmap:
+ *   words == NULL          -> nil bitmap
+ *   words != NULL, all 0   -> non-nil empty bitmap                           */
+typedef struct { const uint64_t *w; size_t nw; int empty; } orc_allow;
+static inline int allow_contains(const orc_allow *a, uint32_t id) {
+    size_t wi = (size_t)id >> 6;
+    if (wi >= a->nw) return 0;
+    return (a->w[wi] >> (id & 63)) & 1;
+}
+
+/* hnsw_index.go:2351-2611 searchLayerUnlocked. Returns count written to out
+ * (ascending distance, truncated to k), or -1 on "error".                   */
+static int search_layer(orc_index *h, const orc_query *q, uint32_t ep, int k, int level,
+                        const orc_allow *allow, int ef_search, uint32_t max_id,
+                        orc_cand *out, int out_cap) {
+    orc_bitset *visited = &h->visited;
+    orc_heap *cands = &h->cands, *results = &h->results;
+    cands->len = 0;
+    results->len = 0;
+    bs_ensure(visited, max_id);
+    int ef = ef_search < k ? k : ef_search; /* :2377-2380 */
+    int filt = allow && allow->w && !allow->empty; /* allowList != nil && !IsEmpty() */
+
+    if (ep == 0 || ep > h->counter || h->nodes[ep].nlevels == 0) { bs_clear(visited); return -1; } /* :2466-2468 */
+    double dist = query_node(h, q, ep);
+    orc_cand epc = {ep, dist};
+    heap_push(cands, epc);
+    bs_add(visited, ep);
+    int ep_valid = 1;
+    if (filt && !allow_contains(allow, ep)) ep_valid = 0;
+    if (ep_valid && !h->nodes[ep].deleted) heap_push(results, epc);
+
+    while (cands->len > 0) { /* HOT LOOP :2495-2593 */
+        orc_cand cur = heap_pop(cands);
+        if ((int)results->len >= ef) {
+            if (cur.dist > results->a[0].dist) break;
+        }
+        if (cur.id > h->counter) continue;
+        orc_node *cn = &h->nodes[cur.id];
+        if (cn->nlevels == 0 || level >= cn->nlevels) continue;
+        h->ctr.n_hops++;
+        const orc_list *nl = &cn->conn[level];
+        for (uint32_t t = 0; t < nl->len; t++) {
+            uint32_t nb = nl->ids[t];
+            if (bs_has(visited, nb)) continue;
+            bs_add(visited, nb);
+            if (filt && !allow_contains(allow, nb)) continue;
+            if (nb > h->counter) continue;
+            orc_node *nn = &h->nodes[nb];
+            if (nn->nlevels == 0) continue;
+            double d = query_node(h, q, nb);
+            double worst = 1.7976931348623157e308;
+            if (results->len > 0) worst = results->a[0].dist;
+            if ((int)results->len < ef || d < worst) {
+                orc_cand nc = {nb, d};
+                heap_push(cands, nc);
+                if (!nn->deleted) {
+                    heap_push(results, nc);
+                    if ((int)results->len > ef) (void)heap_pop(results);
+                }
+            }
+        }
+    }
+    int count = (int)results->len;
+    orc_cand *tmp = (orc_cand *)malloc((size_t)(count > 0 ? count : 1) * sizeof(orc_cand));
+    for (int i = count - 1; i >= 0; i--) tmp[i] = heap_pop(results); /* :2596-2604 */
+    int n = count > k ? k : count;
+    if (n > out_cap) n = out_cap;
+    memcpy(out, tmp, (size_t)n * sizeof(orc_cand));
+    free(tmp);
+    bs_clear(visited); /* deferred Clear, :2366-2371 */
+    return n;
+}
+
+/* hnsw_index.go:2616-2625 randomLevel. The reference draws from the process
+ * global math/rand; the oracle substitutes a seeded splitmix64 stream
+ * (documented divergence).                            */
+static int random_level(orc_index *h) {
+    double u;
+    do { u = (double)(splitmix64(&h->rng) >> 11) * (1.0 / 9007199254740992.0); } while (u <= 0.0);
+    int level = (int)floor(-log(u) * h->ml);
+    if (level > h->max_level + 1) return h->max_level + 1;
+    return level;
+}
+
+/* hnsw_index.go:2629-2701 selectNeighbors. cands in given order; returns
+ * count written to out (<= m, or the input unchanged when len <= m).        */
+static int select_neighbors(orc_index *h, const orc_cand *cands, int n, int m, orc_cand *out) {
+    if (n <= m) { memcpy(out, cands, (size_t)n * sizeof(orc_cand)); return n; }
+    orc_cand *disc = (orc_cand *)malloc((size_t)n * sizeof(orc_cand));
+    int nres = 0, ndisc = 0;
+    for (int w = 0; w < n && nres < m; w++) {
+        orc_cand e = cands[w];
+        if (nres == 0) { out[nres++] = e; continue; }
+        int good = 1;
+        for (int r = 0; r < nres; r++) {
+            if (h->nodes[e.id].nlevels == 0 || h->nodes[out[r].id].nlevels == 0) { good = 0; break; }
+            double d = node_node(h, e.id, out[r].id);
+            if (d < e.dist) { good = 0; break; }
+        }
+        if (good) out[nres++] = e; else disc[ndisc++] = e;
+    }
+    if (nres < m) {
+        int needed = m - nres;
+        for (int i = 0; i < ndisc && needed > 0; i++, needed--) out[nres++] = disc[i];
+    }
+    free(disc);
+    return nres;
+}
+
+static void list_set(orc_list *l, const uint32_t *ids, uint32_t n) {
+    if (l->cap < n) { l->ids = (uint32_t *)realloc(l->ids, (size_t)n * 4); l->cap = n; }
+    if (n) memcpy(l->ids, ids, (size_t)n * 4);
+    l->len = n;
+}
+
+static void node_ensure_levels(orc_node *nd, int nlevels) {
+    if (nd->nlevels >= nlevels) return;
+    nd->conn = (orc_list *)realloc(nd->conn, (size_t)nlevels * sizeof(orc_list));
+    memset(nd->conn + nd->nlevels, 0, (size_t)(nlevels - nd->nlevels) * sizeof(orc_list));
+    nd->nlevels = nlevels;
+}
+
+/* Store a vector as the index would (Add Phase 0, :485-526): cosine&f32 ->
+ * normalised copy; f16 -> RNE bits; int8 -> Quantize (auto-train on the first
+ * vector when untrained, :519-524 / ensureQuantizerTrained :3610-3620).      */
+static void store_vector(orc_index *h, uint32_t id, const float *vec) {
+    size_t n = (size_t)h->dim;
+    uint8_t *dst = h->rows + (size_t)id * n * h->elem;
+    if (h->precision == ORC_F32) {
+        memcpy(dst, vec, n * 4);
+        if (h->metric == ORC_COSINE) orc_normalize((float *)dst, n);
+    } else if (h->precision == ORC_F16) {
+        uint16_t *d16 = (uint16_t *)dst;
+        for (size_t i = 0; i < n; i++) d16[i] = orc_f32_to_f16(vec[i]);
+    } else {
+        if (h->absmax == 0.0f) h->absmax = orc_quantizer_train(vec, 1, n);
+        orc_quantize(vec, n, h->absmax, (int8_t *)dst);
+        h->norms[id] = orc_int8_norm((const int8_t *)dst, n);
+    }
+}
+
+static void make_query_from_row(orc_index *h, uint32_t id, orc_query *q) {
+    memset(q, 0, sizeof *q);
+    const void *p = row_ptr(h, id);
+    if (h->precision == ORC_F32) q->f32 = (const float *)p;
+    else if (h->precision == ORC_F16) q->f16 = (const uint16_t *)p;
+    else {
+        q->i8 = (const int8_t *)p;
+        float qn = orc_int8_norm(q->i8, (size_t)h->dim); /* :2411-2418 */
+        q->qnorm = qn == 0.0f ? 1.0f : qn;
+    }
+}
+
+/* hnsw_index.go:472-809 Add (sequential semantics). `forced_level` < 0 draws
+ * the level from the seeded generator.  Returns the internal id.            */
+ORC_EXPORT uint32_t orc_index_add(orc_index *h, const float *vec, int forced_level) {
+    uint32_t id = ++h->counter; /* ids start at 1, :590 */
+    index_grow(h, id);
+    store_vector(h, id, vec);
+    int level = forced_level >= 0 ? forced_level : random_level(h);
+    if (level > h->max_level + 1) level = h->max_level + 1;
+    orc_node *node = &h->nodes[id];
+    node_ensure_levels(node, level + 1);
+    if (h->max_level == -1) { /* first node, :656-670 */
+        h->entry = id;
+        h->max_level = level;
+        return id;
+    }
+    int cur_max = h->max_level;
+    uint32_t ep = h->entry;
+    orc_query q;
+    make_query_from_row(h, id, &q);
+    int efc = h->efc;
+    orc_cand *cands = (orc_cand *)malloc((size_t)(efc + 1) * sizeof(orc_cand));
+    orc_cand *sel = (orc_cand *)malloc((size_t)(efc + 1) * sizeof(orc_cand));
+    orc_cand *allc = (orc_cand *)malloc((size_t)(2 * h->mmax0 + 2) * sizeof(orc_cand));
+    orc_cand *best = (orc_cand *)malloc((size_t)(2 * h->mmax0 + 2) * sizeof(orc_cand));
+    uint32_t *tmpids = (uint32_t *)malloc((size_t)(2 * h->mmax0 + efc + 2) * 4);
+
+    for (int l = cur_max; l > level; l--) { /* zoom in, :685-690 */
+        int n = search_layer(h, &q, ep, 1, l, NULL, 1, id, cands, efc);
+        if (n > 0) ep = cands[0].id;
+    }
+    int top = level < cur_max ? level : cur_max;
+    for (int l = top; l >= 0; l--) { /* :698-789 */
+        int n = search_layer(h, &q, ep, efc, l, NULL, efc, id, cands, efc);
+        if (n < 0) continue;
+        int maxm = l == 0 ? h->mmax0 : h->m;
+        int ns = select_neighbors(h, cands, n, maxm, sel);
+        for (int i = 0; i < ns; i++) tmpids[i] = sel[i].id;
+        node = &h->nodes[id];
+        list_set(&node->conn[l], tmpids, (uint32_t)ns); /* forward links :717-722 */
+        for (int i = 0; i < ns; i++) { /* reverse links :725-783 */
+            uint32_t nid = sel[i].id;
+            orc_node *nn = &h->nodes[nid];
+            if (nn->nlevels == 0 || nn->deleted) continue;
+            uint32_t ncur = l < nn->nlevels ? nn->conn[l].len : 0;
+            const uint32_t *cur = l < nn->nlevels ? nn->conn[l].ids : NULL;
+            uint32_t nfinal;
+            if ((int)ncur < maxm) {
+                if (ncur) memcpy(tmpids, cur, (size_t)ncur * 4);
+                tmpids[ncur] = id;
+                nfinal = ncur + 1;
+            } else {
+                int na = 0;
+                for (uint32_t e = 0; e < ncur; e++) {
+                    uint32_t ex = cur[e];
+                    if (ex <= h->counter && h->nodes[ex].nlevels > 0 && !h->nodes[ex].deleted) {
+                        allc[na].id = ex;
+                        allc[na].dist = node_node(h, nid, ex);
+                        na++;
+                    }
+                }
+                allc[na].id = id;
+                allc[na].dist = node_node(h, nid, id);
+                na++;
+                int nb = select_neighbors(h, allc, na, maxm, best);
+                for (int e = 0; e < nb; e++) tmpids[e] = best[e].id;
+                nfinal = (uint32_t)nb;
+            }
+            node_ensure_levels(nn, l + 1);
+            list_set(&nn->conn[l], tmpids, nfinal);
+        }
+        if (n > 0) ep = cands[0].id; /* :786-788 */
+    }
+    if (level > cur_max) { /* :793-801 */
+        h->max_level = level;
+        h->entry = id;
+    }
+    free(cands); free(sel); free(allc); free(best); free(tmpids);
+    return id;
+}
+
+/* hnsw_index.go:369-468 searchInternal + :343-366 SearchWithScores.
+ * allow_words == NULL -> nil allow-list. Returns result count (<= k).       */
+ORC_EXPORT int orc_search(orc_index *h, const float *query, int k, const uint64_t *allow_words,
+                          size_t allow_nwords, int ef_search, uint32_t *out_ids, double *out_dist,
+                          orc_counters *ctr) {
+    h->ctr.n_dist = 0;
+    h->ctr.n_hops = 0;
+    if (ctr) { ctr->n_dist = 0; ctr->n_hops = 0; }
+    if (h->max_level == -1 || k <= 0) return 0;
+    uint32_t ep = h->entry;
+    int max_level = h->max_level;
+    uint32_t counter = h->counter;
+    int actual_ef = ef_search;
+    if (h->needs_refine) { /* :387-399 */
+        int boosted = (int)((double)ef_search * 2);
+        if (boosted < 80) boosted = 80;
+        if (boosted > 200) boosted = 200;
+        if (boosted > actual_ef) actual_ef = boosted;
+    }
+    size_t n = (size_t)h->dim;
+    float *qf = (float *)malloc(n * 4);
+    memcpy(qf, query, n * 4);
+    if (h->metric == ORC_COSINE) orc_normalize(qf, n); /* :407-411 */
+    orc_query q;
+    memset(&q, 0, sizeof q);
+    uint16_t *q16 = NULL;
+    int8_t *q8 = NULL;
+    if (h->precision == ORC_F32) q.f32 = qf;
+    else if (h->precision == ORC_F16) {
+        q16 = (uint16_t *)malloc(n * 2);
+        for (size_t i = 0; i < n; i++) q16[i] = orc_f32_to_f16(qf[i]);
+        q.f16 = q16;
+    } else {
+        q8 = (int8_t *)malloc(n);
+        orc_quantize(qf, n, h->absmax, q8);
+        q.i8 = q8;
+        float qn = orc_int8_norm(q8, n);
+        q.qnorm = qn == 0.0f ? 1.0f : qn;
+    }
+    orc_allow al = {allow_words, allow_nwords, 1};
+    int result = 0;
+    if (allow_words) {
+        for (size_t i = 0; i < allow_nwords; i++) if (allow_words[i]) { al.empty = 0; break; }
+        if (!allow_contains(&al, ep)) { /* :437-447 smallest id in the bitmap */
+            uint32_t first = 0;
+            int found = 0;
+            for (size_t i = 0; i < allow_nwords && !found; i++)
+                if (allow_words[i]) { first = (uint32_t)(i * 64 + (size_t)__builtin_ctzll(allow_words[i])); found = 1; }
+            if (!found) goto done;
+            ep = first;
+        }
+    }
+    {
+        int cap = actual_ef > k ? actual_ef : k;
+        orc_cand *out = (orc_cand *)malloc((size_t)(cap + 1) * sizeof(orc_cand));
+        int fail = 0;
+        for (int l = max_level; l > 0; l--) { /* :450-459 */
+            int c = search_layer(h, &q, ep, 1, l, allow_words ? &al : NULL, 0, counter, out, cap);
+            if (c <= 0) { fail = 1; break; }
+            ep = out[0].id;
+        }
+        if (!fail) {
+            int c = search_layer(h, &q, ep, k, 0, allow_words ? &al : NULL, actual_ef, counter, out, cap);
+            if (c > 0) {
+                for (int i = 0; i < c; i++) { out_ids[i] = out[i].id; out_dist[i] = out[i].dist; }
+                result = c;
+            }
+        }
+        free(out);
+    }
+done:
+    if (ctr) *ctr = h->ctr;
+    free(qf); free(q16); free(q8);
+    return result;
+}
+
+/* Layer-level entry for tests (searchLayerUnlocked with a prepared f32 query
+ * that is used as-is: no normalisation).                                    */
+ORC_EXPORT int orc_search_layer_raw(orc_index *h, const float *query, uint32_t ep, int k, int level,
+                                    int ef, uint32_t *out_ids, double *out_dist) {
+    if (h->precision != ORC_F32) return -1;
+    orc_query q;
+    memset(&q, 0, sizeof q);
+    q.f32 = query;
+    int cap = ef > k ? ef : k;
+    orc_cand *out = (orc_cand *)malloc((size_t)(cap + 1) * sizeof(orc_cand));
+    int c = search_layer(h, &q, ep, k, level, NULL, ef, h->counter, out, cap);
+    for (int i = 0; i < c; i++) { out_ids[i] = out[i].id; out_dist[i] = out[i].dist; }
+    free(out);
+    return c;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Exact flat scan                                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct { double d; uint32_t id; } scan_ent;
+static int cmp_scan(const void *a, const void *b) {
+    const scan_ent *x = (const scan_ent *)a, *y = (const scan_ent *)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* pkg/core/vector_index.go:104-140 BruteForceIndex.SearchWithScores: squared
+ * L2 in f64 (helper :150-162) over every stored vector, full sort, allow-list
+ * post-filter to k.  (The reference iterates a Go map, so equal distances come
+ * out in arbitrary order; the oracle orders ties by id.)                    */
+ORC_EXPORT int orc_bruteforce_l2_f64(const float *rows, uint32_t n, int dim, const float *query, int k,
+                                     const uint64_t *allow_words, size_t allow_nwords,
+                                     uint32_t *out_ids, double *out_dist) {
+    scan_ent *e = (scan_ent *)malloc((size_t)(n ? n : 1) * sizeof(scan_ent));
+    for (uint32_t i = 1; i <= n; i++) {
+        const float *r = rows + (size_t)i * (size_t)dim;
+        double sum = 0.0;
+        for (int d = 0; d < dim; d++) {
+            double diff = (double)(query[d] - r[d]);
+            sum += diff * diff;
+        }
+        e[i - 1].d = sum;
+        e[i - 1].id = i;
+    }
+    qsort(e, n, sizeof(scan_ent), cmp_scan);
+    orc_allow al = {allow_words, allow_nwords, 1};
+    if (allow_words) for (size_t i = 0; i < allow_nwords; i++) if (allow_words[i]) { al.empty = 0; break; }
+    int c = 0;
+    for (uint32_t i = 0; i < n && c < k; i++)
+        if (!allow_words || al.empty || allow_contains(&al, e[i].id)) { out_ids[c] = e[i].id; out_dist[c] = e[i].d; c++; }
+    free(e);
+    return c;
+}
+
+/* Exact scan with the index's own metric/precision/arithmetics: the oracle
+ * for kdb_flat_scan_batch (same distance function as the graph search, every
+ * non-deleted allowed row, ties by id).                                      */
+ORC_EXPORT int orc_flat_scan(orc_index *h, const float *query, int k, const uint64_t *allow_words,
+                             size_t allow_nwords, uint32_t *out_ids, double *out_dist) {
+    size_t n = (size_t)h->dim;
+    float *qf = (float *)malloc(n * 4);
+    memcpy(qf, query, n * 4);
+    if (h->metric == ORC_COSINE) orc_normalize(qf, n);
+    orc_query q;
+    memset(&q, 0, sizeof q);
+    uint16_t *q16 = NULL;
+    int8_t *q8 = NULL;
+    if (h->precision == ORC_F32) q.f32 = qf;
+    else if (h->precision == ORC_F16) {
+        q16 = (uint16_t *)malloc(n * 2);
+        for (size_t i = 0; i < n; i++) q16[i] = orc_f32_to_f16(qf[i]);
+        q.f16 = q16;
+    } else {
+        q8 = (int8_t *)malloc(n);
+        orc_quantize(qf, n, h->absmax, q8);
+        q.i8 = q8;
+        float qn = orc_int8_norm(q8, n);
+        q.qnorm = qn == 0.0f ? 1.0f : qn;
+    }
+    orc_allow al = {allow_words, allow_nwords, 1};
+    if (allow_words) for (size_t i = 0; i < allow_nwords; i++) if (allow_words[i]) { al.empty = 0; break; }
+    scan_ent *e = (scan_ent *)malloc((size_t)(h->counter ? h->counter : 1) * sizeof(scan_ent));
+    uint32_t cnt = 0;
+    for (uint32_t i = 1; i <= h->counter; i++) {
+        if (h->nodes[i].nlevels == 0 || h->nodes[i].deleted) continue;
+        if (allow_words && !al.empty && !allow_contains(&al, i)) continue;
+        e[cnt].d = query_node(h, &q, i);
+        e[cnt].id = i;
+        cnt++;
+    }
+    qsort(e, cnt, sizeof(scan_ent), cmp_scan);
+    int c = 0;
+    for (uint32_t i = 0; i < cnt && c < k; i++) { out_ids[c] = e[i].id; out_dist[c] = e[i].d; c++; }
+    free(e); free(qf); free(q16); free(q8);
+    return c;
+}
+
+/* Distance from a (raw, un-normalised) query to a list of ids: oracle for
+ * kdb_distance_batch. Returns raw accumulates converted by the reference's
+ * f64 epilogue.                                                              */
+ORC_EXPORT void orc_distances(orc_index *h, const float *query, int normalize_query, const uint32_t *ids,
+                              size_t n_ids, double *out) {
+    size_t n = (size_t)h->dim;
+    float *qf = (float *)malloc(n * 4);
+    memcpy(qf, query, n * 4);
+    if (normalize_query && h->metric == ORC_COSINE) orc_normalize(qf, n);
+    orc_query q;
+    memset(&q, 0, sizeof q);
+    uint16_t *q16 = NULL;
+    int8_t *q8 = NULL;
+    if (h->precision == ORC_F32) q.f32 = qf;
+    else if (h->precision == ORC_F16) {
+        q16 = (uint16_t *)malloc(n * 2);
+        for (size_t i = 0; i < n; i++) q16[i] = orc_f32_to_f16(qf[i]);
+        q.f16 = q16;
+    } else {
+        q8 = (int8_t *)malloc(n);
+        orc_quantize(qf, n, h->absmax, q8);
+        q.i8 = q8;
+        float qn = orc_int8_norm(q8, n);
+        q.qnorm = qn == 0.0f ? 1.0f : qn;
+    }
+    for (size_t i = 0; i < n_ids; i++) out[i] = query_node(h, &q, ids[i]);
+    free(qf); free(q16); free(q8);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Graph export / import (neutral CSR container)      */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT void orc_index_levels(const orc_index *h, uint8_t *levels /*[count+1]*/) {
+    levels[0] = 0;
+    for (uint32_t i = 1; i <= h->counter; i++) levels[i] = (uint8_t)(h->nodes[i].nlevels ? h->nodes[i].nlevels - 1 : 0);
+}
+ORC_EXPORT void orc_index_deleted_bits(const orc_index *h, uint64_t *bits /*[(count>>6)+1]*/) {
+    memset(bits, 0, (((size_t)h->counter >> 6) + 1) * 8);
+    for (uint32_t i = 1; i <= h->counter; i++) if (h->nodes[i].deleted) bits[i >> 6] |= 1ull << (i & 63);
+}
+/* offsets has count+2 entries; offsets[i]..offsets[i+1] spans node i's list. */
+ORC_EXPORT uint64_t orc_index_export_level(const orc_index *h, int level, uint64_t *offsets, uint32_t *neighbors) {
+    uint64_t off = 0;
+    offsets[0] = 0;
+    for (uint32_t i = 0; i <= h->counter; i++) {
+        offsets[i] = off;
+        if (i >= 1 && level < h->nodes[i].nlevels) {
+            const orc_list *l = &h->nodes[i].conn[level];
+            if (neighbors && l->len) memcpy(neighbors + off, l->ids, (size_t)l->len * 4);
+            off += l->len;
+        }
+    }
+    offsets[h->counter + 1] = off;
+    return off;
+}
+
+/* Build an index around an existing graph (e.g. one constructed on the GPU)
+ * so the oracle can search it.  `rows` is BORROWED ((count+1) rows, row 0
+ * unused, already in stored form: normalised / f16 bits / int8).            */
+ORC_EXPORT orc_index *orc_index_from_graph(int dim, int metric, int precision, int m, int efc,
+                                           const void *rows, const float *norms, uint32_t count,
+                                           const uint8_t *levels, int max_level, uint32_t entry,
+                                           const uint64_t *const *level_offsets,
+                                           const uint32_t *const *level_neighbors,
+                                           const uint64_t *deleted_bits, float absmax) {
+    orc_index *h = orc_index_new(dim, metric, precision, m, efc, 1);
+    if (!h) return NULL;
+    h->rows = (uint8_t *)(uintptr_t)rows;
+    h->rows_borrowed = 1;
+    index_grow(h, count ? count : 1);
+    h->counter = count;
+    h->entry = entry;
+    h->max_level = max_level;
+    h->absmax = absmax;
+    if (precision == ORC_I8 && norms) memcpy(h->norms, norms, ((size_t)count + 1) * 4);
+    for (uint32_t i = 1; i <= count; i++) {
+        orc_node *nd = &h->nodes[i];
+        node_ensure_levels(nd, (int)levels[i] + 1);
+        for (int l = 0; l <= (int)levels[i] && l <= max_level; l++) {
+            uint64_t a = level_offsets[l][i], b = level_offsets[l][i + 1];
+            list_set(&nd->conn[l], level_neighbors[l] + a, (uint32_t)(b - a));
+        }
+        if (deleted_bits && ((deleted_bits[i >> 6] >> (i & 63)) & 1)) nd->deleted = 1;
+    }
+    return h;
+}
+
+/* Batch helper used by the CPU baseline: run `nq` searches back to back on
+ * one thread (each query independent); returns total results written.       */
+ORC_EXPORT int orc_search_many(orc_index *h, const float *queries, int nq, int k, int ef,
+                               uint32_t *out_ids, double *out_dist, int *out_count, orc_counters *total) {
+    orc_counters t = {0, 0}, c;
+    int tot = 0;
+    for (int i = 0; i < nq; i++) {
+        int n = orc_search(h, queries + (size_t)i * (size_t)h->dim, k, NULL, 0, ef,
+                           out_ids + (size_t)i * (size_t)k, out_dist + (size_t)i * (size_t)k, &c);
+        out_count[i] = n;
+        tot += n;
+        t.n_dist += c.n_dist;
+        t.n_hops += c.n_hops;
+    }
+    if (total) *total = t;
+    return tot;
+}
+
+/* Thread-safe clone of the search-side state so several host threads can
+ * search one graph concurrently (mirrors the Go server's goroutine-per-request
+ * model): shares rows/nodes, owns its scratch.                               */
+ORC_EXPORT orc_index *orc_index_clone_view(const orc_index *src) {
+    orc_index *h = (orc_index *)malloc(sizeof *h);
+    memcpy(h, src, sizeof *h);
+    h->visited.w = NULL; h->visited.nw = 0;
+    heap_init(&h->cands, 0);
+    heap_init(&h->results, 1);
+    return h;
+}
+ORC_EXPORT void orc_index_free_view(orc_index *h) {
+    free(h->visited.w);
+    heap_free(&h->cands);
+    heap_free(&h->results);
+    free(h);
+}

@@ -1,0 +1,295 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU restatement oracle on identical
+graph + rows + queries.
+
+Bars:  * traversal / index / counter work is BIT-EXACT against the oracle run with the GPU's own
+         f32 accumulation order (ORC_ARITH_HIP_WAVE): same ids, same raw f32 distances, same
+         n_dist / n_hops per query;
+       * against the reference's arithmetic orders (scalar Go loop, AVX2, BLAS-style Sdot) the
+         distances agree within 1e-4 relative (+1e-6 absolute, the reference's own test tolerance,
+         distance_test.go:26-29) and ids agree except where two distances tie within that tolerance.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+REL, ABS = 1e-4, 1e-6
+
+
+def build_pair(O, hip, X, metric, precision=0, m=16, efc=100, seed=7, deleted=()):
+    n, dim = X.shape
+    orc = O.OracleIndex(dim, metric, precision, m, efc, seed=seed)
+    orc.add_many(X)
+    for d in deleted:
+        orc.mark_deleted(int(d))
+    g = orc.export_graph()
+    idx = hip.HipIndex(dim, metric, precision, m, efc, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    if precision == O.I8:
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(g)
+    return orc, idx
+
+
+def raw_to_score(idx, raw):
+    return np.array([idx.score(r) for r in raw], dtype=np.float64)
+
+
+def assert_same_results_tol(ids_a, d_a, ids_b, d_b):
+    """same ids, distances within tolerance; swaps/differences allowed only between near-ties"""
+    n = min(len(ids_a), len(ids_b))
+    assert len(ids_a) == len(ids_b)
+    np.testing.assert_allclose(d_a, d_b, rtol=REL, atol=ABS)
+    for i in range(n):
+        if ids_a[i] != ids_b[i]:
+            # must be a near-tie: the other list contains this id at a position whose distance ties
+            tol = REL * abs(d_a[i]) + ABS
+            assert np.any(np.abs(d_b - d_a[i]) <= tol), (i, ids_a, ids_b)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("dim", [128, 96, 20])
+def test_distance_tile_bit_exact(oracle, hip, metric, dim):
+    O = oracle
+    X = make_corpus(600, dim, "uniform", seed=3)
+    orc, idx = build_pair(O, hip, X, metric, efc=40)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(1)
+    Q = rng.random((9, dim), dtype=np.float32)
+    ids = rng.integers(0, 601, size=(9, 70)).astype(np.uint32)  # includes id 0 = skip
+    got = idx.distance_batch(Q, ids)
+    for b in range(9):
+        live = ids[b] != 0
+        want = orc.distances(Q[b], ids[b][live])
+        score = raw_to_score(idx, got[b][live])
+        assert np.array_equal(score, want), (metric, dim, b)
+        assert np.all(np.isinf(got[b][~live]))
+    # and within tolerance of the reference's own arithmetic orders
+    for arith in (O.ARITH_GO, O.ARITH_RUST, O.ARITH_GOPURE):
+        orc.set_arith(arith)
+        want = orc.distances(Q[0], ids[0][ids[0] != 0])
+        np.testing.assert_allclose(raw_to_score(idx, got[0][ids[0] != 0]), want, rtol=REL, atol=ABS)
+
+
+@pytest.mark.parametrize("metric,law,n,dim,ef", [
+    (1, "uniform", 3000, 128, 0), (1, "uniform", 3000, 128, 64), (0, "uniform", 3000, 64, 100),
+    (1, "clustered", 4000, 96, 200), (0, "normal", 2000, 40, 10), (1, "normal", 1500, 768, 50),
+])
+def test_search_bit_exact_vs_oracle(oracle, hip, metric, law, n, dim, ef):
+    O = oracle
+    X = make_corpus(n, dim, law, seed=11)
+    orc, idx = build_pair(O, hip, X, metric)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(5)
+    Q = np.concatenate([X[rng.choice(n, 20, replace=False)], make_corpus(44, dim, law, seed=99)])
+    k = 10
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, trace=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = orc.search(Q[b], k, ef=ef, counters=True)
+        c = int(cnt[b])
+        assert c == len(oi)
+        assert np.array_equal(ids[b, :c], oi), (b, ids[b, :c], oi)
+        assert np.array_equal(raw_to_score(idx, dist[b, :c]), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh), (b, nd[b], nh[b], ond, onh)
+    # against the reference's arithmetic: tolerance + tie-aware id parity
+    orc.set_arith(O.ARITH_GO)
+    for b in range(Q.shape[0]):
+        oi, od = orc.search(Q[b], k, ef=ef)
+        assert_same_results_tol(ids[b, :int(cnt[b])], raw_to_score(idx, dist[b, :int(cnt[b])]), oi, od)
+
+
+def test_search_self_match_first(oracle, hip):
+    # pkg/client/client_test.go:171-236: 100x16 uniform, euclidean, m=8 efC=20; a stored vector ranks itself
+    # first at ef=12 and ef=100
+    O = oracle
+    X = make_corpus(100, 16, "uniform", seed=2)
+    orc, idx = build_pair(O, hip, X, 0, m=8, efc=20)
+    for ef in (12, 100):
+        ids, dist, cnt = idx.search_batch(X[:50], 5, ef)
+        assert np.array_equal(ids[:, 0], np.arange(1, 51, dtype=np.uint32))
+        assert np.all(dist[:, 0] == 0.0)
+    r = idx.SearchWithScores(X[7], 3, None, 12)
+    assert r[0].DocID == 8 and r[0].Score == 0.0 and len(r) == 3
+
+
+def test_search_allow_list_and_deleted(oracle, hip):
+    O = oracle
+    n, dim = 2500, 64
+    X = make_corpus(n, dim, "uniform", seed=21)
+    deleted = list(range(5, n, 7))
+    orc, idx = build_pair(O, hip, X, 1, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(8)
+    Q = make_corpus(24, dim, "uniform", seed=77)
+    from kektordb_amd.index import dense_bitset
+    for frac in (0.5, 0.05):
+        allowed = np.nonzero(rng.random(n + 1) < frac)[0]
+        allowed = allowed[allowed >= 1]
+        ab = dense_bitset(allowed, n)
+        ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 80, allow_bits=ab, trace=True)
+        for b in range(Q.shape[0]):
+            oi, od, (ond, onh) = orc.search(Q[b], 10, allow=ab, ef=80, counters=True)
+            c = int(cnt[b])
+            assert c == len(oi)
+            assert np.array_equal(ids[b, :c], oi)
+            assert np.array_equal(raw_to_score(idx, dist[b, :c]), od)
+            assert (int(nd[b]), int(nh[b])) == (ond, onh)
+            assert not (set(ids[b, :c].tolist()) & set(deleted))
+            assert set(ids[b, :c].tolist()) <= set(allowed.tolist())
+    # non-nil EMPTY allow list -> [] (hnsw_index.go:437-447); nil -> unfiltered
+    empty = np.zeros((n >> 6) + 1, dtype=np.uint64)
+    ids, dist, cnt = idx.search_batch(Q[:3], 10, 50, allow_bits=empty)
+    assert np.all(cnt == 0)
+    assert idx.SearchWithScores(Q[0], 10, empty, 50) == []
+
+
+def test_search_edge_cases(oracle, hip):
+    O = oracle
+    # empty index returns [] (hnsw_index.go:383-385)
+    idx = hip.HipIndex(8, 0, 0, 16, 50, capacity=16)
+    assert idx.SearchWithScores(np.ones(8, np.float32), 5, None, 0) == []
+    # single node; k larger than the graph; ef < k
+    X = make_corpus(3, 8, "uniform", seed=1)
+    orc, idx = build_pair(O, hip, X, 0, efc=10)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    ids, dist, cnt = idx.search_batch(X, 10, 2)
+    for b in range(3):
+        oi, od = orc.search(X[b], 10, ef=2)
+        assert int(cnt[b]) == len(oi) == 3
+        assert np.array_equal(ids[b, :3], oi)
+    # needsRefine boost (hnsw_index.go:387-399)
+    X = make_corpus(1500, 32, "uniform", seed=4)
+    orc, idx = build_pair(O, hip, X, 0)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    orc.set_needs_refine(True)
+    idx.needs_refine = True
+    Q = make_corpus(8, 32, "uniform", seed=5)
+    ids, dist, cnt = idx.search_batch(Q, 10, 10)
+    for b in range(8):
+        oi, od = orc.search(Q[b], 10, ef=10)
+        assert np.array_equal(ids[b, :int(cnt[b])], oi)
+    # closed index returns [] (hnsw_index.go:344-351)
+    idx.Close()
+    assert idx.SearchWithScores(Q[0], 3, None, 0) == []
+
+
+def test_search_f16_and_int8(oracle, hip):
+    O = oracle
+    n, dim = 2000, 64
+    X = make_corpus(n, dim, "normal", seed=31)
+    Q = make_corpus(16, dim, "normal", seed=32)
+    # float16 / euclidean
+    orc, idx = build_pair(O, hip, X, 0, precision=O.F16)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 60, trace=True)
+    for b in range(16):
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=60, counters=True)
+        assert np.array_equal(ids[b, :int(cnt[b])], oi)
+        assert np.array_equal(dist[b, :int(cnt[b])].astype(np.float64), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    # int8 / cosine: exact integer dot, f64 scaling; distances compared within tolerance
+    orc = O.OracleIndex(dim, 1, O.I8, 16, 100, seed=7)
+    orc.set_absmax(float(np.quantile(np.abs(X), 0.999)))
+    orc.add_many(X)
+    g = orc.export_graph()
+    idx = hip.HipIndex(dim, 1, O.I8, 16, 100, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_norms(orc.norms()[1:], 1)
+    idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(g)
+    ids, dist, cnt = idx.search_batch(Q, 10, 60)
+    for b in range(16):
+        oi, od = orc.search(Q[b], 10, ef=60)
+        assert_same_results_tol(ids[b, :int(cnt[b])], dist[b, :int(cnt[b])].astype(np.float64), oi, od)
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("n,dim,k,B", [(5000, 128, 10, 70), (3000, 100, 100, 5), (700, 768, 10, 130)])
+def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
+    O = oracle
+    X = make_corpus(n, dim, "normal", seed=41)
+    deleted = list(range(3, n, 50))
+    orc, idx = build_pair(O, hip, X, metric, efc=20, deleted=deleted)
+    Q = make_corpus(B, dim, "normal", seed=42)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    orc.set_arith(O.ARITH_HIP_MFMA if metric == 1 else O.ARITH_HIP_WAVE)
+    exact = 0
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k)
+        c = int(cnt[b])
+        assert c == len(oi)
+        got = raw_to_score(idx, dist[b, :c])
+        assert_same_results_tol(ids[b, :c], got, oi, od)
+        exact += int(np.array_equal(ids[b, :c], oi) and np.array_equal(got, od))
+        assert not (set(ids[b, :c].tolist()) & set(deleted))
+    # the MFMA / wave accumulation orders restated in the oracle should reproduce the bits
+    assert exact == B, f"only {exact}/{B} queries bit-exact"
+    # filtered scan: allowed subset only; EMPTY list = no filter (vector_index.go:130)
+    from kektordb_amd.index import dense_bitset
+    rng = np.random.default_rng(3)
+    allowed = np.nonzero(rng.random(n + 1) < 0.03)[0]
+    allowed = allowed[allowed >= 1]
+    ab = dense_bitset(allowed, n)
+    ids, dist, cnt = idx.flat_scan_batch(Q[:4], k, allow_bits=ab)
+    for b in range(4):
+        oi, od = orc.flat_scan(Q[b], k, allow=ab)
+        c = int(cnt[b])
+        assert c == len(oi)
+        assert_same_results_tol(ids[b, :c], raw_to_score(idx, dist[b, :c]), oi, od)
+    ids2, dist2, cnt2 = idx.flat_scan_batch(Q[:4], k, allow_bits=np.zeros((n >> 6) + 1, np.uint64))
+    ids3, dist3, cnt3 = idx.flat_scan_batch(Q[:4], k)
+    assert np.array_equal(ids2, ids3) and np.array_equal(cnt2, cnt3)
+
+
+def test_bruteforce_f64_reference_semantics(oracle, hip):
+    # BruteForceIndex (vector_index.go:104-162) scores squared L2 in f64: the f32 GPU scan must agree
+    # within the stated tolerance
+    O = oracle
+    n, dim = 1500, 48
+    X = make_corpus(n, dim, "uniform", seed=51)
+    orc, idx = build_pair(O, hip, X, 0, efc=20)
+    Q = make_corpus(10, dim, "uniform", seed=52)
+    ids, dist, cnt = idx.flat_scan_batch(Q, 10)
+    rows = orc.rows()
+    for b in range(10):
+        bi, bd = O.bruteforce_l2_f64(rows, Q[b], 10)
+        assert_same_results_tol(ids[b], dist[b].astype(np.float64), bi, bd)
+
+
+def test_merge_topk_device_and_host(oracle, hip):
+    import torch
+    from kektordb_amd.index import merge_topk
+    rng = np.random.default_rng(0)
+    G, B, k = 4, 33, 10
+    for metric in (0, 1):
+        dist = np.sort(rng.random((G, B, k)).astype(np.float32), axis=2)
+        if metric == 1:
+            dist = dist[:, :, ::-1].copy()  # dot products: descending
+        ids = rng.permutation(G * B * k).reshape(G, B, k).astype(np.uint32) + 1
+        cnt = rng.integers(0, k + 1, size=(G, B)).astype(np.uint32)
+        hi, hd, hc = merge_topk(metric, ids, dist, cnt, k)
+        idx = hip.HipIndex(8, metric, 0, 16, 50, capacity=16)
+        t = lambda a: torch.from_numpy(a).cuda()
+        oi = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+        od = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+        oc = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        import ctypes as C
+        rc = idx.L.kdb_merge_topk_dev(idx.h, G, B, k, C.c_void_p(t(ids.view(np.int32)).data_ptr()),
+                                      C.c_void_p(t(dist).data_ptr()), C.c_void_p(t(cnt.view(np.int32)).data_ptr()),
+                                      C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), C.c_void_p(oc.data_ptr()), None)
+        assert rc == 0
+        idx.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(oc.cpu().numpy().view(np.uint32), hc)
+        for b in range(B):
+            c = int(hc[b])
+            assert np.array_equal(oi[b, :c].cpu().numpy().view(np.uint32), hi[b, :c])
+            assert np.array_equal(od[b, :c].cpu().numpy(), hd[b, :c])
+            # reference merge: concatenate valid entries, order by (key, id)
+            ent = [(-(dist[g, b, i]) if metric == 1 else dist[g, b, i], ids[g, b, i], dist[g, b, i])
+                   for g in range(G) for i in range(int(cnt[g, b]))]
+            ent.sort(key=lambda e: (e[0], e[1]))
+            assert [e[1] for e in ent[:k]] == hi[b, :c].tolist()
