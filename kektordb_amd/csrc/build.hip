@@ -1,7 +1,668 @@
-// build.hip -- GPU batched graph construction (placeholder until the builder lands).
-#include "kdb_internal.h"
+// build.hip -- GPU batched HNSW construction for gfx950.
+//
+// Follows the phases of the reference's batch insert, addBatchInternal
+// (pkg/core/hnsw/hnsw_index.go:1479-2088):
+//   phase 1  every new node of a batch searches the frozen graph in parallel (:1766-1855):
+//            greedy zoom-in with ef=1 above its level, then searchLayer(ef=efConstruction) per level
+//            -- here one wavefront per new node, the same search_layer() as the query path;
+//   phase 2  neighbour selection + link requests (:1864-1890): the new node keeps
+//            selectNeighbors(candidates, maxM) (:2629-2701) and sends one reverse request to each
+//            neighbour it kept -- the link rule of the sequential Add (:711-783); the reference's
+//            batch path instead requests all efConstruction candidates, which costs ~6x more
+//            prunes for the same graph degree (documented divergence);
+//   phase 3  per-target commit (:1902-2060): existing links + requesters; if they fit in maxM they
+//            are appended, otherwise the union is sorted by distance to the target and pruned with
+//            selectNeighbors -- one workgroup per touched (target, level);
+//   phase 4  entry point / maxLevel update (:2066-2080), on the host.
+// Levels are drawn on the host as randomLevel() does (:2616-2625): floor(-ln U / ln m), capped at
+// currentMax+1, from a seeded splitmix64 stream (the reference uses the auto-seeded global RNG).
+//
+// selectNeighbors on the GPU: candidates are visited in blocks of 32; the block's rows and the rows
+// selected so far are staged through LDS in K-chunks, every (candidate, selected) and
+// (candidate, earlier candidate) distance of the block is accumulated by the 256 threads, then one
+// wave resolves the block sequentially from those matrices -- exactly the reference's rule: keep e
+// unless some kept r has d(e,r) < d(e,centre); stop at m; back-fill from the discarded in order.
+#include "kdb_search_core.cuh"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+using namespace kdbcore;
+
+namespace {
+
+constexpr int PR_KC = 128;            // K-chunk (floats) staged per step
+constexpr int PR_STRIDE = PR_KC + 4;  // LDS row stride: 33 sixteen-byte slots -> conflict-free b128 reads
+constexpr int PR_BLK = 32;            // candidates resolved per step
+constexpr int PR_U = 10;              // pair slots per thread: 32*63 + 496 pairs <= 10*256
+constexpr int PR_MAXSEL = 64;         // maxM <= 64
+constexpr int PR_MAXC = 320;          // max candidates per prune task (efC <= 256, 64 existing + requests)
+constexpr uint32_t RCAP = 16;         // reverse requests kept per (target, level) per batch
+constexpr uint32_t UP_FLAG = 0x80000000u;
+
+struct BuildView {
+    uint32_t *adj0;      // writable graph
+    uint32_t *adj_up;
+    float *adj0_key;     // distance (key) of every stored link to its owner
+    float *adj_up_key;
+    uint32_t *rev0_cnt;  // [(cap+1)]
+    uint32_t *revup_cnt; // [up slots]
+    uint32_t *rev0_id;   // [(cap+1) * RCAP]
+    float *rev0_key;
+    uint32_t *revup_id;  // [up slots * RCAP]
+    float *revup_key;
+    uint32_t *touched;   // touched (target, level) codes
+    uint32_t *n_touched;
+    uint32_t *cand_id;   // [tasks * efc]
+    float *cand_key;
+    uint32_t *cand_cnt;  // [tasks]
+    uint32_t *up_task;   // [batch] first upper task of a batch node
+    uint32_t efc;
+    uint32_t first;      // first id of the batch
+    uint32_t nb;         // batch size
+    uint32_t n_tasks;
+};
+
+// ---- phase 1 ------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WaveLds s;
+    size_t off = 0;
+    s.q = reinterpret_cast<float *>(smem + off);
+    off += (size_t)v.ld * 4;
+    s.beam_d = reinterpret_cast<float *>(smem + off);
+    off += (size_t)beam_cap * 4;
+    s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += (size_t)beam_cap * 4;
+    s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += 64 * 4;
+    s.nb_d = reinterpret_cast<float *>(smem + off);
+    off += 64 * 4;
+    s.marks = reinterpret_cast<uint32_t *>(smem + off);
+    const int lane = kdb_lane();
+    uint32_t *visited = visited_pool + (size_t)blockIdx.x * v.vis_words;
+    for (;;) {
+        uint32_t bi = 0;
+        if (lane == 0) bi = atomicAdd(work, 1u);
+        bi = __shfl(bi, 0, 64);
+        if (bi >= bv.nb) break;
+        const uint32_t node = bv.first + bi;
+        const int L = (int)v.levels[node];
+        {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4 *v4 = reinterpret_cast<uint4 *>(visited);
+            for (uint32_t i = (uint32_t)lane; i < (v.vis_words >> 2); i += 64) v4[i] = z;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)node * v.ld);
+            float4 *dst = reinterpret_cast<float4 *>(s.q);
+            for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
+        }
+        __threadfence_block();
+        wave_lds_fence();
+        Beam b;
+        QCtr ctr{0, 0};
+        uint32_t ep = v.entry;
+        for (int l = v.max_level; l >= 0; l--) {
+            const bool insert = l <= L;
+            uint32_t n_marks = 0;
+            search_layer<KDB_PREC_F32, METRIC>(v, s, b, visited, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, l > 0, n_marks, ctr);
+            if (insert) {
+                const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
+                for (uint32_t i = (uint32_t)lane; i < b.count; i += 64) {
+                    bv.cand_id[(size_t)task * bv.efc + i] = s.beam_id[i] & KDB_ID_MASK;
+                    bv.cand_key[(size_t)task * bv.efc + i] = s.beam_d[i];
+                }
+                if (lane == 0) bv.cand_cnt[task] = b.count;
+            }
+            if (b.count > 0) ep = s.beam_id[0] & KDB_ID_MASK; // nearest (:786-788 / :1849)
+            if (l > 0) {
+                if (n_marks <= KDB_UP_MARK_CAP) {
+                    for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
+                        const uint32_t id = s.marks[i];
+                        atomicAnd(&visited[id >> 5], ~(1u << (id & 31)));
+                    }
+                } else {
+                    for (uint32_t i = (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __threadfence_block();
+                wave_lds_fence();
+            }
+        }
+    }
+}
+
+// ---- selectNeighbors on a workgroup ---------------------------------------------------------------
+struct PruneLds {
+    uint32_t *c_id;    // [PR_MAXC] candidates ascending by (key,id)
+    float *c_key;      // [PR_MAXC]
+    uint32_t *s_id;    // [PR_MAXSEL]
+    float *s_key;      // [PR_MAXSEL]
+    uint16_t *disc;    // [PR_MAXC] discarded candidate indices, in order
+    float *rows;       // [(PR_BLK + PR_MAXSEL) * PR_STRIDE]
+    float *m1;         // [PR_BLK][PR_MAXSEL]
+    float *m2;         // [PR_BLK][PR_BLK]
+    uint32_t *misc;    // [8]: 0 n_sel, 1 n_disc
+};
+
+__device__ __forceinline__ size_t prune_lds_bytes() {
+    return (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
+           (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
+}
+
+__device__ __forceinline__ void prune_carve(unsigned char *smem, PruneLds &p) {
+    size_t off = 0;
+    p.rows = reinterpret_cast<float *>(smem + off);
+    off += (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4;
+    p.m1 = reinterpret_cast<float *>(smem + off);
+    off += (size_t)PR_BLK * PR_MAXSEL * 4;
+    p.m2 = reinterpret_cast<float *>(smem + off);
+    off += (size_t)PR_BLK * PR_BLK * 4;
+    p.c_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += (size_t)PR_MAXC * 4;
+    p.c_key = reinterpret_cast<float *>(smem + off);
+    off += (size_t)PR_MAXC * 4;
+    p.s_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += PR_MAXSEL * 4;
+    p.s_key = reinterpret_cast<float *>(smem + off);
+    off += PR_MAXSEL * 4;
+    p.misc = reinterpret_cast<uint32_t *>(smem + off);
+    off += 32;
+    p.disc = reinterpret_cast<uint16_t *>(smem + off);
+}
+
+// candidates c_id/c_key[0..n) sorted ascending -> s_id/s_key[0..n_sel). Whole workgroup (256 threads).
+template <int METRIC>
+__device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_t n, uint32_t maxm) {
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) {
+        p.misc[0] = 0;
+        p.misc[1] = 0;
+    }
+    __syncthreads();
+    if (n <= maxm) { // "len(candidates) <= m: return candidates" (:2634-2636)
+        for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+            p.s_id[i] = p.c_id[i];
+            p.s_key[i] = p.c_key[i];
+        }
+        if (tid == 0) p.misc[0] = n;
+        __syncthreads();
+        return;
+    }
+    const float *rows = reinterpret_cast<const float *>(v.rows);
+    for (uint32_t b0 = 0; b0 < n; b0 += PR_BLK) {
+        const uint32_t nb = n - b0 < PR_BLK ? n - b0 : PR_BLK;
+        const uint32_t ns = p.misc[0];
+        const uint32_t p1 = nb * ns, p2 = nb * (nb - 1) / 2, np = p1 + p2;
+        float acc[PR_U];
+        uint32_t ra[PR_U], rb[PR_U];
+#pragma unroll
+        for (int u = 0; u < PR_U; u++) {
+            const uint32_t q = (uint32_t)tid + 256u * (uint32_t)u;
+            acc[u] = 0.f;
+            ra[u] = 0;
+            rb[u] = 0;
+            if (q < p1) {
+                ra[u] = q / ns;              // block candidate
+                rb[u] = PR_BLK + q % ns;     // selected row
+            } else if (q < np) {
+                const uint32_t t = q - p1;   // triangular: i > i'
+                uint32_t i = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)t)) * 0.5f);
+                while (i * (i - 1) / 2 > t) i--;
+                while ((i + 1) * i / 2 <= t) i++;
+                ra[u] = i;
+                rb[u] = t - i * (i - 1) / 2;
+            }
+        }
+        for (uint32_t kc = 0; kc < v.ld; kc += PR_KC) {
+            __syncthreads();
+            const uint32_t nrow = nb + ns; // staged rows: block candidates then selected
+            for (uint32_t e = (uint32_t)tid; e < nrow * (PR_KC / 4); e += 256) {
+                const uint32_t r = e / (PR_KC / 4), c4 = e % (PR_KC / 4);
+                const uint32_t id = r < nb ? p.c_id[b0 + r] : p.s_id[r - nb];
+                const uint32_t lr = r < nb ? r : PR_BLK + (r - nb);
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kc + c4 * 4 < v.ld) x = *reinterpret_cast<const float4 *>(rows + (size_t)id * v.ld + kc + c4 * 4);
+                *reinterpret_cast<float4 *>(p.rows + (size_t)lr * PR_STRIDE + c4 * 4) = x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PR_U; u++) {
+                if ((uint32_t)tid + 256u * (uint32_t)u >= np) continue;
+                const float4 *a4 = reinterpret_cast<const float4 *>(p.rows + (size_t)ra[u] * PR_STRIDE);
+                const float4 *b4 = reinterpret_cast<const float4 *>(p.rows + (size_t)rb[u] * PR_STRIDE);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < PR_KC / 4; c++) {
+                    const float4 x = a4[c], y = b4[c];
+                    if (METRIC == KDB_METRIC_L2) {
+                        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+                        a0 = __builtin_fmaf(d0, d0, a0);
+                        a1 = __builtin_fmaf(d1, d1, a1);
+                        a2 = __builtin_fmaf(d2, d2, a2);
+                        a3 = __builtin_fmaf(d3, d3, a3);
+                    } else {
+                        a0 = __builtin_fmaf(x.x, y.x, a0);
+                        a1 = __builtin_fmaf(x.y, y.y, a1);
+                        a2 = __builtin_fmaf(x.z, y.z, a2);
+                        a3 = __builtin_fmaf(x.w, y.w, a3);
+                    }
+                }
+                acc[u] += (a0 + a1) + (a2 + a3);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PR_U; u++) {
+            const uint32_t q = (uint32_t)tid + 256u * (uint32_t)u;
+            if (q >= np) continue;
+            const float key = METRIC == KDB_METRIC_COSINE ? -acc[u] : acc[u];
+            if (q < p1) p.m1[ra[u] * PR_MAXSEL + (rb[u] - PR_BLK)] = key;
+            else p.m2[ra[u] * PR_BLK + rb[u]] = key;
+        }
+        __syncthreads();
+        if (tid < 64) { // one wave resolves the block in order
+            uint32_t nsel = ns, ndisc = p.misc[1];
+            unsigned selmask = 0; // block candidates kept so far
+            for (uint32_t i = 0; i < nb && nsel < maxm; i++) {
+                const float ek = p.c_key[b0 + i];
+                bool rej = false;
+                if ((uint32_t)tid < ns) rej = p.m1[i * PR_MAXSEL + (uint32_t)tid] < ek;
+                if ((uint32_t)tid < i && ((selmask >> tid) & 1u)) rej = rej || (p.m2[i * PR_BLK + (uint32_t)tid] < ek);
+                const bool any = __ballot(rej) != 0ull;
+                if (!any) {
+                    if (tid == 0) {
+                        p.s_id[nsel] = p.c_id[b0 + i];
+                        p.s_key[nsel] = ek;
+                    }
+                    nsel++;
+                    selmask |= 1u << i;
+                } else {
+                    if (tid == 0) p.disc[ndisc] = (uint16_t)(b0 + i);
+                    ndisc++;
+                }
+            }
+            if (tid == 0) {
+                p.misc[0] = nsel;
+                p.misc[1] = ndisc;
+            }
+        }
+        __syncthreads();
+        if (p.misc[0] >= maxm) break;
+    }
+    if (tid == 0) { // back-fill from the discarded, in order (:2688-2698)
+        uint32_t nsel = p.misc[0];
+        const uint32_t ndisc = p.misc[1];
+        for (uint32_t i = 0; i < ndisc && nsel < maxm; i++) {
+            p.s_id[nsel] = p.c_id[p.disc[i]];
+            p.s_key[nsel] = p.c_key[p.disc[i]];
+            nsel++;
+        }
+        p.misc[0] = nsel;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool key_before(float k1, uint32_t i1, float k2, uint32_t i2) {
+    return (k1 < k2) || (k1 == k2 && i1 < i2);
+}
+
+// ---- phase 2: new node keeps selectNeighbors(cands); emits reverse requests ---------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+build_select_kernel(KdbView v, BuildView bv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLds p;
+    prune_carve(smem, p);
+    const int tid = (int)threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    // decode task -> (node, level)
+    uint32_t node, level;
+    if (task < bv.nb) {
+        node = bv.first + task;
+        level = 0;
+    } else {
+        // upper task: find owner by binary search over up_task (non-decreasing)
+        const uint32_t ut = task - bv.nb;
+        uint32_t lo = 0, hi = bv.nb - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (bv.up_task[mid] <= ut) lo = mid; else hi = mid - 1;
+        }
+        // several batch nodes without upper levels share the same up_task value: take the one that owns it
+        while (lo + 1 < bv.nb && bv.up_task[lo + 1] <= ut) lo++;
+        node = bv.first + lo;
+        level = ut - bv.up_task[lo] + 1;
+    }
+    const uint32_t n = bv.cand_cnt[task];
+    const uint32_t maxm = level == 0 ? v.deg0 : v.deg_up;
+    for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+        p.c_id[i] = bv.cand_id[(size_t)task * bv.efc + i];
+        p.c_key[i] = bv.cand_key[(size_t)task * bv.efc + i];
+    }
+    __syncthreads();
+    select_neighbors_wg<METRIC>(v, p, n, maxm);
+    const uint32_t nsel = p.misc[0];
+    uint32_t *adj;
+    float *akey;
+    uint32_t slot_up = 0;
+    if (level == 0) {
+        adj = bv.adj0 + (size_t)node * v.deg0;
+        akey = bv.adj0_key + (size_t)node * v.deg0;
+    } else {
+        slot_up = v.up_idx[node] + (level - 1);
+        adj = bv.adj_up + (size_t)slot_up * v.deg_up;
+        akey = bv.adj_up_key + (size_t)slot_up * v.deg_up;
+    }
+    if ((uint32_t)tid < maxm) {
+        adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
+        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : 0.f;
+    }
+    if ((uint32_t)tid < nsel) { // reverse link requests (:1883-1889)
+        const uint32_t t = p.s_id[tid];
+        uint32_t *cnt;
+        uint32_t *rid;
+        float *rkey;
+        uint32_t code;
+        if (level == 0) {
+            cnt = bv.rev0_cnt + t;
+            rid = bv.rev0_id + (size_t)t * RCAP;
+            rkey = bv.rev0_key + (size_t)t * RCAP;
+            code = t;
+        } else {
+            const uint32_t ts = v.up_idx[t] + (level - 1);
+            cnt = bv.revup_cnt + ts;
+            rid = bv.revup_id + (size_t)ts * RCAP;
+            rkey = bv.revup_key + (size_t)ts * RCAP;
+            code = UP_FLAG | ts;
+        }
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < RCAP) {
+            rid[slot] = node;
+            rkey[slot] = p.s_key[tid];
+        }
+        if (slot == 0) bv.touched[atomicAdd(bv.n_touched, 1u)] = code;
+    }
+}
+
+// ---- phase 3: per-target commit -----------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLds p;
+    prune_carve(smem, p);
+    const int tid = (int)threadIdx.x;
+    if (blockIdx.x >= n_touched) return;
+    const uint32_t code = bv.touched[blockIdx.x];
+    uint32_t *adj, *cnt, *rid;
+    float *akey, *rkey;
+    uint32_t maxm;
+    if (code & UP_FLAG) {
+        const uint32_t ts = code & ~UP_FLAG;
+        adj = bv.adj_up + (size_t)ts * v.deg_up;
+        akey = bv.adj_up_key + (size_t)ts * v.deg_up;
+        cnt = bv.revup_cnt + ts;
+        rid = bv.revup_id + (size_t)ts * RCAP;
+        rkey = bv.revup_key + (size_t)ts * RCAP;
+        maxm = v.deg_up;
+    } else {
+        adj = bv.adj0 + (size_t)code * v.deg0;
+        akey = bv.adj0_key + (size_t)code * v.deg0;
+        cnt = bv.rev0_cnt + code;
+        rid = bv.rev0_id + (size_t)code * RCAP;
+        rkey = bv.rev0_key + (size_t)code * RCAP;
+        maxm = v.deg0;
+    }
+    uint32_t &sh_ne = p.misc[2], &sh_nr = p.misc[3];
+    if (tid == 0) {
+        uint32_t ne = 0;
+        while (ne < maxm && adj[ne] != 0u) ne++;
+        uint32_t nr = *cnt;
+        if (nr > RCAP) nr = RCAP;
+        sh_ne = ne;
+        sh_nr = nr;
+        *cnt = 0; // ready for the next batch
+    }
+    __syncthreads();
+    const uint32_t ne = sh_ne, nr = sh_nr;
+    const uint32_t n = ne + nr;
+    // gather E then R; requesters ordered by id so the result does not depend on atomic order
+    uint32_t my_id = 0;
+    float my_key = 0.f;
+    if ((uint32_t)tid < ne) {
+        my_id = adj[tid];
+        my_key = akey[tid];
+    } else if ((uint32_t)tid < n) {
+        my_id = rid[tid - ne];
+        my_key = rkey[tid - ne];
+    }
+    if (n <= maxm) { // fast path: append (Add, :746-751)
+        if ((uint32_t)tid >= ne && (uint32_t)tid < n) {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nr; j++) rank += rid[j] < my_id ? 1u : 0u;
+            adj[ne + rank] = my_id;
+            akey[ne + rank] = my_key;
+        }
+        return;
+    }
+    // prune: union sorted by distance to the target (:2019-2033), then selectNeighbors
+    uint32_t *sh_id = reinterpret_cast<uint32_t *>(p.m1);      // m1/m2 are free until select_neighbors_wg
+    float *sh_key = p.m2;
+    if ((uint32_t)tid < n) {
+        sh_id[tid] = my_id;
+        sh_key[tid] = my_key;
+    }
+    __syncthreads();
+    if ((uint32_t)tid < n) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += key_before(sh_key[j], sh_id[j], my_key, my_id) ? 1u : 0u;
+        p.c_id[rank] = my_id;
+        p.c_key[rank] = my_key;
+    }
+    __syncthreads();
+    select_neighbors_wg<METRIC>(v, p, n, maxm);
+    const uint32_t nsel = p.misc[0];
+    if ((uint32_t)tid < maxm) {
+        adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
+        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : 0.f;
+    }
+}
+
+uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+template <typename K>
+int occupancy_blocks(K kern, int threads, size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+template <int METRIC>
+int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
+    hipStream_t s = idx->stream;
+    const uint32_t efc = bp && bp->ef_construction ? bp->ef_construction : idx->desc.ef_construction;
+    if (efc > 256 || efc < 1) {
+        kdb_set_error("build: ef_construction must be in 1..256 (got %u)", efc);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    const uint32_t max_batch = bp && bp->batch ? bp->batch : 16384u;
+    uint64_t seed = bp ? bp->seed : 1ull;
+    const uint32_t m = idx->desc.m;
+    const double ml = 1.0 / std::log((double)m);
+    // ---- levels (randomLevel, :2616-2625), upper-slot prefix, entry/maxLevel trajectory
+    const size_t n1 = (size_t)count + 1;
+    std::vector<uint8_t> levels(n1, 0);
+    std::vector<uint32_t> up_idx(n1, 0);
+    size_t slots = 0;
+    int curmax = -1;
+    for (uint32_t i = 1; i <= count; i++) {
+        double u;
+        do { u = (double)(splitmix64(seed) >> 11) * (1.0 / 9007199254740992.0); } while (u <= 0.0);
+        int lv = (int)std::floor(-std::log(u) * ml);
+        if (lv > curmax + 1) lv = curmax + 1;
+        if (lv > 250) lv = 250;
+        levels[i] = (uint8_t)lv;
+        if (lv > curmax) curmax = lv;
+        up_idx[i] = (uint32_t)slots;
+        slots += (size_t)lv;
+    }
+    // ---- graph storage
+    if (slots > idx->up_slots_cap || !idx->d_adj_up) {
+        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
+        idx->d_adj_up = nullptr;
+        KDB_HIP(hipMalloc(&idx->d_adj_up, (slots * idx->deg_up + 4) * 4));
+        idx->up_slots_cap = slots;
+    }
+    idx->up_slots = slots;
+    KDB_HIP(hipMemsetAsync(idx->d_adj0, 0, ((size_t)idx->cap + 1) * idx->deg0 * 4, s));
+    KDB_HIP(hipMemsetAsync(idx->d_adj_up, 0, (slots * idx->deg_up + 4) * 4, s));
+    KDB_HIP(hipMemcpyAsync(idx->d_levels, levels.data(), n1, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(idx->d_up_idx, up_idx.data(), n1 * 4, hipMemcpyHostToDevice, s));
+    // ---- workspace
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t max_tasks = (size_t)max_batch * 2 + 64; // level-0 tasks + upper tasks (<< batch)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_adj0k = take(n1 * idx->deg0 * 4), o_adjupk = take((slots * idx->deg_up + 4) * 4);
+    const size_t o_r0c = take(n1 * 4), o_ruc = take((slots + 1) * 4);
+    const size_t o_r0i = take(n1 * RCAP * 4), o_r0k = take(n1 * RCAP * 4);
+    const size_t o_rui = take((slots + 1) * RCAP * 4), o_ruk = take((slots + 1) * RCAP * 4);
+    const size_t o_touch = take(((size_t)max_tasks * PR_MAXSEL + 64) * 4), o_ntouch = take(256);
+    const size_t o_cid = take(max_tasks * efc * 4), o_ckey = take(max_tasks * efc * 4), o_ccnt = take(max_tasks * 4);
+    const size_t o_uptask = take((size_t)max_batch * 4 + 64);
+    if (idx->build_bytes < off) {
+        if (idx->d_build) KDB_HIP(hipFree(idx->d_build));
+        idx->d_build = nullptr;
+        idx->build_bytes = 0;
+        KDB_HIP(hipMalloc(&idx->d_build, off));
+        idx->build_bytes = off;
+    }
+    unsigned char *w = reinterpret_cast<unsigned char *>(idx->d_build);
+    KDB_HIP(hipMemsetAsync(w + o_r0c, 0, n1 * 4, s));
+    KDB_HIP(hipMemsetAsync(w + o_ruc, 0, (slots + 1) * 4, s));
+    BuildView bv;
+    bv.adj0 = idx->d_adj0;
+    bv.adj_up = idx->d_adj_up;
+    bv.adj0_key = reinterpret_cast<float *>(w + o_adj0k);
+    bv.adj_up_key = reinterpret_cast<float *>(w + o_adjupk);
+    bv.rev0_cnt = reinterpret_cast<uint32_t *>(w + o_r0c);
+    bv.revup_cnt = reinterpret_cast<uint32_t *>(w + o_ruc);
+    bv.rev0_id = reinterpret_cast<uint32_t *>(w + o_r0i);
+    bv.rev0_key = reinterpret_cast<float *>(w + o_r0k);
+    bv.revup_id = reinterpret_cast<uint32_t *>(w + o_rui);
+    bv.revup_key = reinterpret_cast<float *>(w + o_ruk);
+    bv.touched = reinterpret_cast<uint32_t *>(w + o_touch);
+    bv.n_touched = reinterpret_cast<uint32_t *>(w + o_ntouch);
+    bv.cand_id = reinterpret_cast<uint32_t *>(w + o_cid);
+    bv.cand_key = reinterpret_cast<float *>(w + o_ckey);
+    bv.cand_cnt = reinterpret_cast<uint32_t *>(w + o_ccnt);
+    bv.up_task = reinterpret_cast<uint32_t *>(w + o_uptask);
+    bv.efc = efc;
+
+    // ---- launch geometry
+    const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
+    const size_t lds_search = (size_t)idx->ld * 4 + (size_t)beam_cap * 8 + 64 * 8 + KDB_UP_MARK_CAP * 4;
+    const size_t lds_prune = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
+                             (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
+    auto ksearch = build_search_kernel<METRIC>;
+    auto kselect = build_select_kernel<METRIC>;
+    auto krev = build_reverse_kernel<METRIC>;
+    if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
+    hipDeviceProp_t prop;
+    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
+    const uint32_t slots_vis = (uint32_t)prop.multiProcessorCount * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
+    int rc = kdb_ensure_visited(idx, slots_vis);
+    if (rc) return rc;
+
+    // first node: entry point, no links (:656-670)
+    idx->count = count;
+    idx->entry = 1;
+    idx->max_level = (int)levels[1];
+    idx->has_graph = true;
+    idx->n_deleted = 0;
+    KDB_HIP(hipMemsetAsync(idx->d_deleted, 0, ((((size_t)idx->cap + 1 + 31) / 32 + 3) & ~(size_t)3) * 4, s));
+    std::vector<uint32_t> up_task;
+    uint32_t next = 2;
+    while (next <= count) {
+        const uint32_t have = next - 1;
+        uint32_t nb = have / 4; // a batch never exceeds a quarter of the graph it searches
+        if (nb < 1) nb = 1;
+        if (nb > max_batch) nb = max_batch;
+        if (nb > count - have) nb = count - have;
+        // tasks
+        up_task.assign(nb, 0);
+        uint32_t nup = 0;
+        const int frozen_max = idx->max_level;
+        for (uint32_t i = 0; i < nb; i++) {
+            up_task[i] = nup;
+            int lv = (int)levels[next + i];
+            if (lv > frozen_max) lv = frozen_max; // links only up to the current top (:694-697)
+            nup += (uint32_t)lv;
+        }
+        const uint32_t n_tasks = nb + nup;
+        if (n_tasks > max_tasks) {
+            kdb_set_error("build: task overflow (%u > %zu)", n_tasks, max_tasks);
+            return KDB_ERR_STATE;
+        }
+        bv.first = next;
+        bv.nb = nb;
+        bv.n_tasks = n_tasks;
+        KDB_HIP(hipMemcpyAsync(bv.up_task, up_task.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+        KDB_HIP(hipMemsetAsync(bv.cand_cnt, 0, (size_t)n_tasks * 4, s));
+        KDB_HIP(hipMemsetAsync(bv.n_touched, 0, 4, s));
+        KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
+        KdbView v = kdb_make_view(idx);
+        v.count = next + nb - 1;
+        uint32_t grid = slots_vis < nb ? slots_vis : nb;
+        hipLaunchKernelGGL(ksearch, dim3(grid), dim3(64), lds_search, s, v, bv, beam_cap, idx->d_visited, idx->d_work);
+        KDB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(kselect, dim3(n_tasks), dim3(256), lds_prune, s, v, bv);
+        KDB_HIP(hipGetLastError());
+        uint32_t n_touched = 0;
+        KDB_HIP(hipMemcpyAsync(&n_touched, bv.n_touched, 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        if (n_touched) {
+            hipLaunchKernelGGL(krev, dim3(n_touched), dim3(256), lds_prune, s, v, bv, n_touched);
+            KDB_HIP(hipGetLastError());
+        }
+        // phase 4: entry point / maxLevel (:2066-2080)
+        for (uint32_t i = 0; i < nb; i++) {
+            const int lv = (int)levels[next + i];
+            if (lv > idx->max_level) {
+                idx->max_level = lv;
+                idx->entry = next + i;
+            }
+        }
+        next += nb;
+    }
+    KDB_HIP(hipStreamSynchronize(s));
+    return KDB_OK;
+}
+
+} // namespace
+
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
-    (void)idx; (void)count; (void)p;
-    kdb_set_error("kdb_index_build: not implemented yet");
-    return KDB_ERR_UNSUPPORTED;
+    if (count == 0 || count > idx->cap) {
+        kdb_set_error("build: count %u outside 1..%u", count, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    if (idx->desc.precision != KDB_PREC_F32) {
+        kdb_set_error("build: GPU construction supports float32 rows only in this version");
+        return KDB_ERR_UNSUPPORTED;
+    }
+    if (idx->deg0 > PR_MAXSEL) {
+        kdb_set_error("build: mMax0 %u exceeds %d", idx->deg0, PR_MAXSEL);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    return idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE>(idx, count, p)
+                                                 : build_impl<KDB_METRIC_L2>(idx, count, p);
 }

@@ -1,0 +1,94 @@
+"""GPU graph construction (kdb_index_build): structural invariants, search quality against the exact
+scan, and search parity: the CPU oracle searching the GPU-built graph returns exactly what the HIP
+search returns (graph + rows + query identical)."""
+import numpy as np
+import pytest
+
+from conftest import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+class G:
+    pass
+
+
+def as_graph(dl):
+    g = G()
+    g.count, g.entry, g.max_level, g.levels, g.offsets, g.neighbors = dl
+    g.deleted_bits = np.zeros((g.count >> 6) + 1, dtype=np.uint64)
+    return g
+
+
+@pytest.mark.parametrize("metric,law,n,dim", [(1, "clustered", 6000, 96), (0, "uniform", 5000, 64), (1, "normal", 3000, 768)])
+def test_build_invariants_recall_and_parity(oracle, hip, metric, law, n, dim):
+    O = oracle
+    X = make_corpus(n, dim, law, seed=13)
+    if metric == 1:
+        X = X / np.linalg.norm(X, axis=1, keepdims=True)
+    X = X.astype(np.float32)
+    idx = hip.HipIndex(dim, metric, 0, 16, 100, capacity=n)
+    idx.upload_rows(X, 1)
+    idx.build(n, batch=1024, ef_construction=100, seed=5)
+    g = as_graph(idx.download_graph())
+    assert g.count == n and 1 <= g.entry <= n and g.max_level >= 1
+    assert int(g.levels[g.entry]) == g.max_level
+    # structural invariants
+    for l in range(g.max_level + 1):
+        off, nb = g.offsets[l], g.neighbors[l]
+        deg = np.diff(off[:n + 2].astype(np.int64))
+        cap = 32 if l == 0 else 16
+        assert deg.max() <= cap
+        assert nb.min() >= 1 and nb.max() <= n
+        owner = np.repeat(np.arange(n + 1), deg)
+        assert not np.any(owner == nb), "self loop"
+        assert np.all(g.levels[nb] >= l) and np.all(g.levels[owner] >= l)
+        key = owner.astype(np.int64) * (n + 1) + nb
+        assert np.unique(key).size == key.size, "duplicate link"
+        if l == 0:
+            assert (deg[1:] > 0).mean() > 0.999
+    # level population ~ geometric with p = 1/16
+    frac1 = (g.levels[1:] >= 1).mean()
+    assert 0.03 < frac1 < 0.10
+    # quality: recall@10 at ef=100 against the exact scan
+    Q = make_corpus(100, dim, law, seed=14).astype(np.float32)
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 100, trace=True)
+    fi, fd, fc = idx.flat_scan_batch(Q, 10)
+    rec = np.mean([len(set(ids[b].tolist()) & set(fi[b].tolist())) / 10 for b in range(Q.shape[0])])
+    assert rec >= 0.90, rec
+    # parity on the GPU-built graph: oracle (GPU accumulation order) == HIP search, incl. counters
+    rows = np.zeros((n + 1, dim), dtype=np.float32)
+    rows[1:] = idx.download_rows(1, n)
+    assert np.array_equal(rows[1:], X)
+    from oracle.oracle import Graph
+    og = Graph(g.count, g.levels, g.max_level, g.entry, g.offsets, g.neighbors, g.deleted_bits)
+    orc = O.OracleIndex.from_graph(dim, metric, 0, 16, 100, rows, og)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    for b in range(40):
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=100, counters=True)
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], oi)
+        assert np.array_equal(np.array([idx.score(x) for x in dist[b, :c]]), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+
+
+def test_build_quality_close_to_sequential_add(oracle, hip):
+    """recall of the GPU batched build vs the oracle's sequential Add (reference semantics) on the same data"""
+    O = oracle
+    n, dim = 4000, 48
+    X = make_corpus(n, dim, "uniform", seed=23)
+    Q = make_corpus(100, dim, "uniform", seed=24)
+    orc = O.OracleIndex(dim, 0, 0, 16, 100, seed=5)
+    orc.add_many(X)
+    a = hip.HipIndex(dim, 0, 0, 16, 100, capacity=n)
+    a.upload_rows(X, 1)
+    a.upload_graph_obj(orc.export_graph())
+    b = hip.HipIndex(dim, 0, 0, 16, 100, capacity=n)
+    b.upload_rows(X, 1)
+    b.build(n, batch=512, ef_construction=100, seed=5)
+    fi, _, _ = a.flat_scan_batch(Q, 10)
+    rec = []
+    for idx in (a, b):
+        ids, _, _ = idx.search_batch(Q, 10, 50)
+        rec.append(np.mean([len(set(ids[i].tolist()) & set(fi[i].tolist())) / 10 for i in range(100)]))
+    assert rec[1] >= rec[0] - 0.03, rec

@@ -272,13 +272,13 @@ def test_merge_topk_device_and_host(oracle, hip):
         cnt = rng.integers(0, k + 1, size=(G, B)).astype(np.uint32)
         hi, hd, hc = merge_topk(metric, ids, dist, cnt, k)
         idx = hip.HipIndex(8, metric, 0, 16, 50, capacity=16)
-        t = lambda a: torch.from_numpy(a).cuda()
+        t_ids, t_dist, t_cnt = (torch.from_numpy(a).cuda() for a in (ids.view(np.int32), dist, cnt.view(np.int32)))
         oi = torch.zeros((B, k), dtype=torch.int32, device="cuda")
         od = torch.zeros((B, k), dtype=torch.float32, device="cuda")
         oc = torch.zeros((B,), dtype=torch.int32, device="cuda")
         import ctypes as C
-        rc = idx.L.kdb_merge_topk_dev(idx.h, G, B, k, C.c_void_p(t(ids.view(np.int32)).data_ptr()),
-                                      C.c_void_p(t(dist).data_ptr()), C.c_void_p(t(cnt.view(np.int32)).data_ptr()),
+        rc = idx.L.kdb_merge_topk_dev(idx.h, G, B, k, C.c_void_p(t_ids.data_ptr()),
+                                      C.c_void_p(t_dist.data_ptr()), C.c_void_p(t_cnt.data_ptr()),
                                       C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), C.c_void_p(oc.data_ptr()), None)
         assert rc == 0
         idx.sync()
