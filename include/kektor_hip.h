@@ -176,15 +176,17 @@ KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint3
 /* GPU batched graph construction over rows 1..count already uploaded.                             */
 KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
 
-/* Shard merge: G per-shard results for B queries -> global top-k.  ids are already global ids.
- * in_ids/in_dist: [G][B][k], in_count: [G][B]; keys ascend by (raw L2 sum) or descend by (dot)
- * according to `metric`.  Host pointers.                                                          */
-KDB_API int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids,
-                   const float *in_dist, const uint32_t *in_count, uint32_t *out_ids, float *out_dist,
-                   uint32_t *out_count);
+/* Shard merge: G per-shard results for B queries -> global top-k.  in_ids/in_dist: [G][B][k],
+ * in_count: [G][B]; id_base: NULL or [G] offsets added to shard g's (local, 1-based) ids so that
+ * global id = id_base[g] + local id (shard g owns the contiguous id range that starts at id_base[g]+1).
+ * Ordering: ascending raw L2 sum, or descending dot for cosine/f32, ties by global id.
+ * kdb_merge_topk takes host pointers (host-side glue of the shim); *_dev device pointers.           */
+KDB_API int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, uint32_t B, uint32_t k,
+                   const uint32_t *in_ids, const float *in_dist, const uint32_t *in_count,
+                   const uint32_t *id_base, uint32_t *out_ids, float *out_dist, uint32_t *out_count);
 KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
-                       const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
-                       float *d_out_dist, uint32_t *d_out_count, void *stream);
+                       const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
+                       uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Block until all work queued on the index's internal stream has finished. */

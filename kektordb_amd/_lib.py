@@ -94,8 +94,8 @@ def load():
     L.kdb_distance_batch.argtypes = [vp, vp, u32, vp, u32, u32, vp]
     L.kdb_distance_batch_dev.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
     L.kdb_index_build.argtypes = [vp, u32, C.POINTER(BuildParams)]
-    L.kdb_merge_topk.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp]
-    L.kdb_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.kdb_merge_topk.argtypes = [u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.kdb_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.kdb_index_sync.argtypes = [vp]
     _lib = L

@@ -750,15 +750,16 @@ extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_p
     return kdb_build_graph(idx, count, params);
 }
 
-extern "C" int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids,
-                              const float *in_dist, const uint32_t *in_count, uint32_t *out_ids, float *out_dist,
-                              uint32_t *out_count) {
+extern "C" int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, uint32_t B, uint32_t k,
+                              const uint32_t *in_ids, const float *in_dist, const uint32_t *in_count,
+                              const uint32_t *id_base, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
     // Host-side shard merge (G*k entries per query; no vector arithmetic).  Total order (key, id)
-    // with key = raw L2 sum, or -dot for cosine -- identical to merge_topk_kernel.
+    // with key = raw value, or -dot for the f32 cosine path -- identical to merge_topk_kernel.
     if (!in_ids || !in_dist || !in_count || !out_ids || !out_dist || !out_count || k == 0) {
         kdb_set_error("merge_topk: null buffer or k == 0");
         return KDB_ERR_INVALID;
     }
+    const bool negate = metric == KDB_METRIC_COSINE && precision == KDB_PREC_F32;
     struct E { float key; uint32_t id; float d; };
     std::vector<E> buf;
     for (uint32_t q = 0; q < B; q++) {
@@ -768,7 +769,7 @@ extern "C" int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t 
             if (c > k) c = k;
             for (uint32_t i = 0; i < c; i++) {
                 const size_t off = ((size_t)g * B + q) * k + i;
-                buf.push_back({metric == KDB_METRIC_COSINE ? -in_dist[off] : in_dist[off], in_ids[off], in_dist[off]});
+                buf.push_back({negate ? -in_dist[off] : in_dist[off], in_ids[off] + (id_base ? id_base[g] : 0u), in_dist[off]});
             }
         }
         std::sort(buf.begin(), buf.end(), [](const E &a, const E &b) { return a.key < b.key || (a.key == b.key && a.id < b.id); });
@@ -783,13 +784,14 @@ extern "C" int kdb_merge_topk(uint32_t metric, uint32_t G, uint32_t B, uint32_t 
 }
 
 extern "C" int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
-                                  const float *d_in_dist, const uint32_t *d_in_count, uint32_t *d_out_ids,
-                                  float *d_out_dist, uint32_t *d_out_count, void *stream) {
+                                  const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
+                                  uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream) {
     KDB_CHECK_IDX(idx);
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
-    return kdb_launch_merge_topk(idx->desc.metric, G, B, k, d_in_ids, d_in_dist, d_in_count, d_out_ids, d_out_dist,
+    const int negate = idx->desc.metric == KDB_METRIC_COSINE && idx->desc.precision == KDB_PREC_F32;
+    return kdb_launch_merge_topk(negate, G, B, k, d_in_ids, d_in_dist, d_in_count, d_id_base, d_out_ids, d_out_dist,
                                  d_out_count, s);
 }
 

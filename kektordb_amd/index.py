@@ -240,6 +240,12 @@ class HipIndex:
     def sync(self):
         check(self.L.kdb_index_sync(self.h), "sync")
 
+    def merge_topk_dev(self, G, B, k, d_in_ids, d_in_dist, d_in_count, d_id_base, d_out_ids, d_out_dist, d_out_count,
+                       stream=None):
+        check(self.L.kdb_merge_topk_dev(self.h, G, B, k, _tptr(d_in_ids), _tptr(d_in_dist), _tptr(d_in_count),
+                                        _tptr(d_id_base), _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
+                                        C.c_void_p(stream) if stream else None), "kdb_merge_topk_dev")
+
     # ---- the reference's per-query API --------------------------------------------------------------
     def score(self, raw: float) -> float:
         """The reference's f64 epilogue: float64(sum) (distance_go.go:67) / 1.0-float64(dot) (:127)."""
@@ -260,18 +266,19 @@ class HipIndex:
         return [SearchResult(int(ids[0, i]), self.score(dist[0, i])) for i in range(n)]
 
 
-def merge_topk(metric: int, ids, dist, count, k: int):
-    """Host shard merge through the C ABI (kdb_merge_topk): ids/dist [G,B,k], count [G,B]."""
+def merge_topk(metric: int, ids, dist, count, k: int, id_base=None, precision: int = F32):
+    """Host shard merge through the C ABI (kdb_merge_topk): ids/dist [G,B,k], count [G,B], id_base [G]."""
     L = _lib.load()
     ids = np.ascontiguousarray(ids, dtype=np.uint32)
     dist = np.ascontiguousarray(dist, dtype=np.float32)
     count = np.ascontiguousarray(count, dtype=np.uint32)
+    base = None if id_base is None else np.ascontiguousarray(id_base, dtype=np.uint32)
     G, B = count.shape
     o_ids = np.zeros((B, k), dtype=np.uint32)
     o_dist = np.zeros((B, k), dtype=np.float32)
     o_cnt = np.zeros(B, dtype=np.uint32)
-    check(L.kdb_merge_topk(metric, G, B, k, _ptr(ids), _ptr(dist), _ptr(count), _ptr(o_ids), _ptr(o_dist),
-                           _ptr(o_cnt)), "kdb_merge_topk")
+    check(L.kdb_merge_topk(metric, precision, G, B, k, _ptr(ids), _ptr(dist), _ptr(count), _ptr(base), _ptr(o_ids),
+                           _ptr(o_dist), _ptr(o_cnt)), "kdb_merge_topk")
     return o_ids, o_dist, o_cnt
 
 

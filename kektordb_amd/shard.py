@@ -1,0 +1,124 @@
+"""Id-range sharding across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Shard g owns the
+contiguous global ids [base_g + 1, base_g + n_g]; it holds its rows and its OWN HNSW graph built
+over only those rows.  A query batch is replicated on every rank; each rank searches its shard; ONE
+all-gather of the per-shard top-k (B*k ids + B*k raw distances + B counts: 84 B/query at k=10) is
+the only exchange step; every rank then merges G*k candidates per query with kdb_merge_topk(_dev).
+The reference has no counterpart (single process); the oracle for a G-shard result is
+"G restatement indexes over the same ranges + merge" (tests/test_shard_gloo.py).
+
+torch is plumbing here: device/host buffers and the collective.  The local search is supplied by the
+caller (HipIndex.search_batch_dev on the GPU path) and the merge goes through the C ABI.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import index as _index
+
+
+def shard_ranges(n_total: int, n_shards: int):
+    """contiguous id ranges: shard g owns ids [base+1, base+n]; sizes ceil(N/G) except the tail"""
+    per = -(-n_total // n_shards)
+    out = []
+    for g in range(n_shards):
+        lo = min(g * per, n_total)
+        hi = min(lo + per, n_total)
+        out.append((lo, hi - lo))  # (id_base, count)
+    return out
+
+
+def slice_allow_bits(allow_bits: np.ndarray, id_base: int, count: int) -> np.ndarray:
+    """dense global allow bitset -> the shard's local bitset (local id i <-> global id base+i)"""
+    out = np.zeros((count >> 6) + 1, dtype=np.uint64)
+    g = np.arange(1, count + 1, dtype=np.uint64) + np.uint64(id_base)
+    w = (g >> np.uint64(6)).astype(np.int64)
+    ok = w < allow_bits.shape[0]
+    bit = np.zeros(count, dtype=bool)
+    bit[ok] = ((allow_bits[w[ok]] >> (g[ok] & np.uint64(63))) & np.uint64(1)).astype(bool)
+    loc = np.nonzero(bit)[0].astype(np.uint64) + np.uint64(1)
+    np.bitwise_or.at(out, (loc >> np.uint64(6)).astype(np.int64), np.uint64(1) << (loc & np.uint64(63)))
+    return out
+
+
+class ShardedSearch:
+    """Top-k exchange + merge around a per-rank local search."""
+
+    def __init__(self, metric: int, precision: int, id_base: int, group=None,
+                 hip_index: Optional["_index.HipIndex"] = None):
+        self.metric, self.precision = metric, precision
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.hip_index = hip_index
+        # every rank needs every shard's id base
+        mine = torch.tensor([id_base], dtype=torch.int64)
+        if self.world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if hip_index is not None else torch.device("cpu")
+            mine = mine.to(dev)
+            allb = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(allb, mine, group=group)
+            self.bases = torch.cat(allb).cpu().numpy().astype(np.uint32)
+        else:
+            self.bases = np.array([id_base], dtype=np.uint32)
+        self._dev_bases = None
+        self._bufs = {}
+
+    # ---- GPU path: device tensors, RCCL all-gather, merge kernel -------------------------------------
+    def search_dev(self, d_queries, k: int, ef: int, out_ids, out_dist, out_cnt, d_allow=None, flat=False):
+        idx = self.hip_index
+        B = d_queries.shape[0]
+        dev = d_queries.device
+        key = (B, k)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros((B, k), dtype=torch.int32, device=dev),
+                               torch.zeros((B, k), dtype=torch.float32, device=dev),
+                               torch.zeros((B,), dtype=torch.int32, device=dev),
+                               torch.zeros((self.world, B, k), dtype=torch.int32, device=dev),
+                               torch.zeros((self.world, B, k), dtype=torch.float32, device=dev),
+                               torch.zeros((self.world, B), dtype=torch.int32, device=dev))
+        l_ids, l_dist, l_cnt, g_ids, g_dist, g_cnt = self._bufs[key]
+        stream = torch.cuda.current_stream().cuda_stream
+        if flat:
+            idx.flat_scan_batch_dev(d_queries, k, l_ids, l_dist, l_cnt, d_allow, stream=stream)
+        else:
+            idx.search_batch_dev(d_queries, k, ef, l_ids, l_dist, l_cnt, d_allow, stream=stream)
+        if self.world == 1:
+            out_ids.copy_(l_ids)
+            out_dist.copy_(l_dist)
+            out_cnt.copy_(l_cnt)
+            return
+        # the one exchange step: all-gather of per-shard top-k over xGMI
+        dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
+        dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
+        dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
+        if self._dev_bases is None:
+            self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
+        idx.merge_topk_dev(self.world, B, k, g_ids, g_dist, g_cnt, self._dev_bases, out_ids, out_dist, out_cnt,
+                           stream=stream)
+
+    # ---- host path (what a Go shim does with host buffers; also the gloo test path) -------------------
+    def merge_host(self, l_ids: np.ndarray, l_dist: np.ndarray, l_cnt: np.ndarray, k: int
+                   ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        B = l_ids.shape[0]
+        if self.world == 1:
+            g_ids, g_dist, g_cnt = l_ids[None], l_dist[None], l_cnt[None]
+        else:
+            t_ids = torch.from_numpy(np.ascontiguousarray(l_ids).view(np.int32))
+            t_dist = torch.from_numpy(np.ascontiguousarray(l_dist))
+            t_cnt = torch.from_numpy(np.ascontiguousarray(l_cnt).view(np.int32))
+            a_ids = [torch.zeros_like(t_ids) for _ in range(self.world)]
+            a_dist = [torch.zeros_like(t_dist) for _ in range(self.world)]
+            a_cnt = [torch.zeros_like(t_cnt) for _ in range(self.world)]
+            dist.all_gather(a_ids, t_ids, group=self.group)
+            dist.all_gather(a_dist, t_dist, group=self.group)
+            dist.all_gather(a_cnt, t_cnt, group=self.group)
+            g_ids = torch.stack(a_ids).numpy().view(np.uint32)
+            g_dist = torch.stack(a_dist).numpy()
+            g_cnt = torch.stack(a_cnt).numpy().view(np.uint32)
+        return _index.merge_topk(self.metric, g_ids, g_dist, g_cnt, k, id_base=self.bases, precision=self.precision)

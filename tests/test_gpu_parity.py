@@ -278,7 +278,7 @@ def test_merge_topk_device_and_host(oracle, hip):
         oc = torch.zeros((B,), dtype=torch.int32, device="cuda")
         import ctypes as C
         rc = idx.L.kdb_merge_topk_dev(idx.h, G, B, k, C.c_void_p(t_ids.data_ptr()),
-                                      C.c_void_p(t_dist.data_ptr()), C.c_void_p(t_cnt.data_ptr()),
+                                      C.c_void_p(t_dist.data_ptr()), C.c_void_p(t_cnt.data_ptr()), None,
                                       C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), C.c_void_p(oc.data_ptr()), None)
         assert rc == 0
         idx.sync()
