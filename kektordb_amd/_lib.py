@@ -67,6 +67,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # ONE HIP runtime per process: PyTorch wheels bundle libamdhip64/libhsa-runtime64 with the same
+    # SONAMEs as /opt/rocm's.  Whichever is mapped first serves both, and device pointers / streams are
+    # shared between torch (plumbing) and this library, so torch's copy must be mapped first.
+    try:
+        import torch  # noqa: F401
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise KdbError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")

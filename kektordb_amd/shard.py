@@ -68,6 +68,9 @@ class ShardedSearch:
             self.bases = np.array([id_base], dtype=np.uint32)
         self._dev_bases = None
         self._bufs = {}
+        # the whole search path (library kernels, RCCL all-gather, merge kernel) is ordered on ONE
+        # dedicated HIP stream; callers synchronise with torch.cuda.synchronize() / stream.synchronize()
+        self.stream = torch.cuda.Stream() if hip_index is not None else None
 
     # ---- GPU path: device tensors, RCCL all-gather, merge kernel -------------------------------------
     def search_dev(self, d_queries, k: int, ef: int, out_ids, out_dist, out_cnt, d_allow=None, flat=False):
@@ -83,24 +86,24 @@ class ShardedSearch:
                                torch.zeros((self.world, B, k), dtype=torch.float32, device=dev),
                                torch.zeros((self.world, B), dtype=torch.int32, device=dev))
         l_ids, l_dist, l_cnt, g_ids, g_dist, g_cnt = self._bufs[key]
-        stream = torch.cuda.current_stream().cuda_stream
-        if flat:
-            idx.flat_scan_batch_dev(d_queries, k, l_ids, l_dist, l_cnt, d_allow, stream=stream)
-        else:
-            idx.search_batch_dev(d_queries, k, ef, l_ids, l_dist, l_cnt, d_allow, stream=stream)
-        if self.world == 1:
-            out_ids.copy_(l_ids)
-            out_dist.copy_(l_dist)
-            out_cnt.copy_(l_cnt)
-            return
-        # the one exchange step: all-gather of per-shard top-k over xGMI
-        dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
-        dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
-        dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
-        if self._dev_bases is None:
-            self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
-        idx.merge_topk_dev(self.world, B, k, g_ids, g_dist, g_cnt, self._dev_bases, out_ids, out_dist, out_cnt,
-                           stream=stream)
+        self.stream.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
+        with torch.cuda.stream(self.stream):
+            raw = self.stream.cuda_stream
+            tgt = (out_ids, out_dist, out_cnt) if self.world == 1 else (l_ids, l_dist, l_cnt)
+            if flat:
+                idx.flat_scan_batch_dev(d_queries, k, *tgt, d_allow, stream=raw)
+            else:
+                idx.search_batch_dev(d_queries, k, ef, *tgt, d_allow, stream=raw)
+            if self.world == 1:
+                return
+            # the one exchange step: all-gather of per-shard top-k over xGMI
+            dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
+            dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
+            dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
+            if self._dev_bases is None:
+                self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
+            idx.merge_topk_dev(self.world, B, k, g_ids, g_dist, g_cnt, self._dev_bases, out_ids, out_dist, out_cnt,
+                               stream=raw)
 
     # ---- host path (what a Go shim does with host buffers; also the gloo test path) -------------------
     def merge_host(self, l_ids: np.ndarray, l_dist: np.ndarray, l_cnt: np.ndarray, k: int
