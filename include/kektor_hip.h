@@ -189,6 +189,10 @@ KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t 
                        uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
+/* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each
+ * launch records its own HIP event pair on the launch stream and its own counter slot, so a timed
+ * loop can run unsynchronised and be read afterwards.                                             */
+KDB_API int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counters *out);
 /* Block until all work queued on the index's internal stream has finished. */
 KDB_API int kdb_index_sync(kdb_index *idx);
 

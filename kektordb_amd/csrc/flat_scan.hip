@@ -506,6 +506,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 8 + (size_t)FS_QCAP * 12 + 16;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
+    (void)kdb_stats_begin(idx, 2, B, 0);
     KDB_HIP(hipEventRecord(idx->ev0, s));
     if (v.metric == KDB_METRIC_COSINE) {
         KDB_HIP(hipFuncSetAttribute((const void *)flat_scan_kernel<KDB_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

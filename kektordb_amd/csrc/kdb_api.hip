@@ -111,6 +111,20 @@ int kdb_ensure_visited(kdb_index *idx, uint32_t slots) {
     return KDB_OK;
 }
 
+unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32_t C) {
+    const uint32_t slot = (uint32_t)(idx->launch_seq % kdb_index::RING);
+    idx->launch_seq++;
+    idx->ev0 = idx->ring_ev0[slot];
+    idx->ev1 = idx->ring_ev1[slot];
+    idx->ring_kind[slot] = kind;
+    idx->ring_B[slot] = B;
+    idx->ring_C[slot] = C;
+    idx->last_kind = kind;
+    idx->last_B = B;
+    idx->last_C = C;
+    return idx->d_ctr + (size_t)slot * 2;
+}
+
 static int ensure_qbuf(kdb_index *idx, size_t bytes) {
     if (idx->qbuf_bytes >= bytes) return KDB_OK;
     if (idx->d_qbuf) {
@@ -193,8 +207,12 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     } while (0)
     const size_t n1 = (size_t)idx->cap + 1;
     KDB_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
-    KDB_TRY(hipEventCreate(&idx->ev0));
-    KDB_TRY(hipEventCreate(&idx->ev1));
+    for (uint32_t i = 0; i < kdb_index::RING; i++) {
+        KDB_TRY(hipEventCreate(&idx->ring_ev0[i]));
+        KDB_TRY(hipEventCreate(&idx->ring_ev1[i]));
+    }
+    idx->ev0 = idx->ring_ev0[0];
+    idx->ev1 = idx->ring_ev1[0];
     KDB_TRY(hipMalloc(&idx->d_rows, n1 * idx->ld * idx->elem));
     KDB_TRY(hipMemsetAsync(idx->d_rows, 0, (size_t)idx->ld * idx->elem, idx->stream)); // row 0
     KDB_TRY(hipMalloc(&idx->d_norms, n1 * 4));
@@ -210,8 +228,8 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     KDB_TRY(hipMemsetAsync(idx->d_deleted, 0, dw * 4, idx->stream));
     KDB_TRY(hipMalloc(&idx->d_work, 64 * 4));
     KDB_TRY(hipMemsetAsync(idx->d_work, 0, 64 * 4, idx->stream));
-    KDB_TRY(hipMalloc(&idx->d_ctr, 64));
-    KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, 64, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 16));
+    KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 16, idx->stream));
     KDB_TRY(hipStreamSynchronize(idx->stream));
 #undef KDB_TRY
     *out = idx;
@@ -227,8 +245,10 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
                     idx->d_iobuf, idx->d_build};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
-    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    for (uint32_t i = 0; i < kdb_index::RING; i++) {
+        if (idx->ring_ev0[i]) (void)hipEventDestroy(idx->ring_ev0[i]);
+        if (idx->ring_ev1[i]) (void)hipEventDestroy(idx->ring_ev1[i]);
+    }
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
 }
@@ -551,8 +571,6 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         KDB_HIP(hipMemcpyAsync(idx->trace_ndist, tr_nd, (size_t)B * 4, hipMemcpyDeviceToHost, s));
         if (idx->trace_nhops) KDB_HIP(hipMemcpyAsync(idx->trace_nhops, tr_nh, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     }
-    idx->last_kind = 1;
-    idx->last_B = B;
     return KDB_OK;
 }
 
@@ -650,8 +668,6 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
     if (rc) return rc;
     rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, filter, d_out_ids, d_out_dist, d_out_count, s);
     if (rc) return rc;
-    idx->last_kind = 2;
-    idx->last_B = B;
     return KDB_OK;
 }
 
@@ -702,13 +718,11 @@ extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, ui
     float *d_qnorm = nullptr;
     int rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
+    (void)kdb_stats_begin(idx, 3, B, C);
     KDB_HIP(hipEventRecord(idx->ev0, s));
     rc = kdb_launch_distance(v, d_q, d_qnorm, B, d_ids, C, d_out, s);
     if (rc) return rc;
     KDB_HIP(hipEventRecord(idx->ev1, s));
-    idx->last_kind = 3;
-    idx->last_B = B;
-    idx->last_C = C;
     return KDB_OK;
 }
 
@@ -795,30 +809,56 @@ extern "C" int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32
                                  d_out_count, s);
 }
 
+static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
+    unsigned long long c[2] = {0, 0};
+    float ms = 0.f;
+    if (hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
+        hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess)
+        ms = 0.f;
+    KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 2, 16, hipMemcpyDeviceToHost));
+    kdb_counters r{};
+    r.last_kernel_ms = ms;
+    const uint64_t row_bytes = (uint64_t)idx->desc.dim * idx->elem;
+    const int kind = idx->ring_kind[slot];
+    if (kind == 1) { // n_dist*(dim*elem) + n_hops*(deg_cap*4) + n_dist*4
+        r.n_dist = c[0];
+        r.n_hops = c[1];
+        r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
+    } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
+        r.bytes = (uint64_t)(idx->count - idx->n_deleted) * row_bytes + (uint64_t)idx->ring_B[slot] * row_bytes;
+    } else if (kind == 3) {
+        r.n_dist = (uint64_t)idx->ring_B[slot] * idx->ring_C[slot];
+        r.bytes = r.n_dist * row_bytes + r.n_dist * 8 + (uint64_t)idx->ring_B[slot] * row_bytes;
+    }
+    *out = r;
+    return KDB_OK;
+}
+
 extern "C" int kdb_get_counters(kdb_index *idx, kdb_counters *out) {
     KDB_CHECK_IDX(idx);
     if (!out) return KDB_ERR_INVALID;
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
-    KDB_HIP(hipStreamSynchronize(idx->stream));
-    unsigned long long c[2] = {0, 0};
-    KDB_HIP(hipMemcpy(c, idx->d_ctr, 16, hipMemcpyDeviceToHost));
-    float ms = 0.f;
-    if (idx->last_kind && hipEventElapsedTime(&ms, idx->ev0, idx->ev1) != hipSuccess) ms = 0.f;
-    kdb_counters r{};
-    r.last_kernel_ms = ms;
-    const uint64_t row_bytes = (uint64_t)idx->desc.dim * idx->elem;
-    if (idx->last_kind == 1) { // n_dist*(dim*elem) + n_hops*(deg_cap*4) + n_dist*4
-        r.n_dist = c[0];
-        r.n_hops = c[1];
-        r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
-    } else if (idx->last_kind == 2) { // N_scanned*dim*elem + B*dim*elem (B*k*8 added by the caller)
-        r.bytes = (uint64_t)(idx->count - idx->n_deleted) * row_bytes + (uint64_t)idx->last_B * row_bytes;
-    } else if (idx->last_kind == 3) {
-        r.n_dist = (uint64_t)idx->last_B * idx->last_C;
-        r.bytes = r.n_dist * row_bytes + r.n_dist * 8 + (uint64_t)idx->last_B * row_bytes;
+    if (idx->launch_seq == 0) {
+        *out = kdb_counters{};
+        return KDB_OK;
     }
-    *out = r;
+    return stats_of_slot(idx, (uint32_t)((idx->launch_seq - 1) % kdb_index::RING), out);
+}
+
+extern "C" int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counters *out) {
+    KDB_CHECK_IDX(idx);
+    if (!out || last_n == 0 || last_n > kdb_index::RING || last_n > idx->launch_seq) {
+        kdb_set_error("get_launch_stats: last_n must be 1..min(%u, launches so far)", kdb_index::RING);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    for (uint32_t i = 0; i < last_n; i++) {
+        const uint64_t seq = idx->launch_seq - last_n + i;
+        int rc = stats_of_slot(idx, (uint32_t)(seq % kdb_index::RING), out + i);
+        if (rc) return rc;
+    }
     return KDB_OK;
 }
 

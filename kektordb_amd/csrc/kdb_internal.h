@@ -73,7 +73,13 @@ struct kdb_index {
     uint32_t *trace_ndist = nullptr, *trace_nhops = nullptr;
     int trace_on_device = 0;
     kdb_counters last{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // aliases of the current ring slot
+    // per-launch statistics ring: HIP events around the dominant kernel + counter slots
+    static constexpr uint32_t RING = 64;
+    hipEvent_t ring_ev0[RING] = {}, ring_ev1[RING] = {};
+    int ring_kind[RING] = {};
+    uint32_t ring_B[RING] = {}, ring_C[RING] = {};
+    uint64_t launch_seq = 0;
     std::mutex mu;
 };
 
@@ -92,6 +98,8 @@ void kdb_set_error(const char *fmt, ...);
 KdbView kdb_make_view(const kdb_index *idx);
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes);
 int kdb_ensure_visited(kdb_index *idx, uint32_t slots);
+// start a new statistics slot: selects ring events (idx->ev0/ev1) and returns the slot's counter words
+unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32_t C);
 
 // ---- kernel launchers (each defined next to its kernels) --------------------------------------
 // search.hip

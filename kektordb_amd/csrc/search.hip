@@ -349,10 +349,11 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
     int rc = kdb_ensure_visited(idx, grid);
     if (rc) return rc;
     KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
-    KDB_HIP(hipMemsetAsync(idx->d_ctr, 0, 16, s));
+    unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
+    KDB_HIP(hipMemsetAsync(d_ctr, 0, 16, s));
     KDB_HIP(hipEventRecord(idx->ev0, s));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, B, k, eff, d_allow, entry, beam_cap,
-                       idx->d_visited, idx->d_work, idx->d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist,
+                       idx->d_visited, idx->d_work, d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist,
                        d_tr_nhops);
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
