@@ -57,12 +57,36 @@ __device__ __forceinline__ int kdb_wave_sum_i(int v) {
 // t = lane & 15.  Lane t visits the 16-byte chunks c = t, t+16, ...; component j of each chunk
 // feeds accumulator j (f16: j & 3); partial = (a0+a1)+(a2+a3).  The caller reduces with
 // kdb_reduce16().  `row` may point at row 0 (all zero) for inactive groups.
-template <int METRIC>
+template <int METRIC, int NCH = 0>
 __device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ row, const float *q, uint32_t ld,
                                                      int t) {
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
     const float4 *q4 = reinterpret_cast<const float4 *>(q);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if constexpr (NCH > 0) {
+        // ld == 64*NCH known at compile time: every 16-byte load of the row is issued before the first
+        // FMA (one HBM round trip per 4-row pass instead of NCH/4).  Same accumulation order as below.
+        float4 x[NCH > 0 ? NCH : 1];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) x[i] = r4[t + 16 * i];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const float4 y = q4[t + 16 * i];
+            if (METRIC == KDB_METRIC_L2) {
+                float d0 = y.x - x[i].x, d1 = y.y - x[i].y, d2 = y.z - x[i].z, d3 = y.w - x[i].w;
+                a0 = __builtin_fmaf(d0, d0, a0);
+                a1 = __builtin_fmaf(d1, d1, a1);
+                a2 = __builtin_fmaf(d2, d2, a2);
+                a3 = __builtin_fmaf(d3, d3, a3);
+            } else {
+                a0 = __builtin_fmaf(y.x, x[i].x, a0);
+                a1 = __builtin_fmaf(y.y, x[i].y, a1);
+                a2 = __builtin_fmaf(y.z, x[i].z, a2);
+                a3 = __builtin_fmaf(y.w, x[i].w, a3);
+            }
+        }
+        return (a0 + a1) + (a2 + a3);
+    }
     const uint32_t nch = ld >> 2;
 #pragma unroll 4
     for (uint32_t c = (uint32_t)t; c < nch; c += 16) {

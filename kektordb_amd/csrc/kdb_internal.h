@@ -12,7 +12,7 @@
 #define KDB_F_EXPANDED 0x80000000u  // beam entry already expanded (popped)
 #define KDB_F_NORESULT 0x40000000u  // traversal-only entry: deleted node / entry point outside the allow-list
 #define KDB_MAX_DEG0 64u            // mMax0 = 2m <= 64
-#define KDB_UP_MARK_CAP 512u        // upper-layer visited un-mark list (per wave, LDS)
+#define KDB_UP_MARK_CAP 256u        // upper-layer visited un-mark list (per wave, LDS); overflow -> full clear
 
 // Device view of one index (passed by value to kernels).
 struct KdbView {
@@ -31,6 +31,7 @@ struct KdbView {
     uint32_t metric, precision;
     uint32_t vis_words;      // words per visited bitset = (cap>>5)+1
     float q_absmax;          // int8 quantizer
+    uint32_t dbg;            // experiment flags (KDB_DBG env), 0 in production
 };
 
 struct kdb_index {

@@ -28,7 +28,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
-template <int PREC, int METRIC>
+template <int PREC, int METRIC, int NCH = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         float key;
         if (PREC == KDB_PREC_F32) {
             const float *row = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
-            float p = kdb_row_partial_f32<METRIC>(row, s.q, v.ld, t);
+            float p = kdb_row_partial_f32<METRIC, NCH>(row, s.q, v.ld, t);
             key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p));
         } else if (PREC == KDB_PREC_F16) {
             const uint16_t *row = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld;
@@ -163,7 +163,7 @@ struct QCtr {
 };
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the beam in LDS.
-template <int PREC, int METRIC>
+template <int PREC, int METRIC, int NCH = 0>
 __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32_t *visited,
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm,
                              bool record_marks, uint32_t &n_marks, QCtr &ctr) {
@@ -176,7 +176,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     if (lane == 0) s.nb_id[0] = ep;
     wave_lds_fence();
-    compute_dists<PREC, METRIC>(v, s, 1, qnorm);
+    compute_dists<PREC, METRIC, NCH>(v, s, 1, qnorm);
     ctr.n_dist++;
     {
         if (lane == 0) atomicOr(&visited[ep >> 5], 1u << (ep & 31));
@@ -191,6 +191,9 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         beam_trim(s, b, ef);
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
+    // level-0 adjacency prefetch: while a hop's rows are in flight, the neighbour list of the candidate
+    // that will be expanded next (unless this hop inserts a nearer one) is already being fetched
+    uint32_t pf_id = 0, pf_nb = 0;
     for (;;) {
         const int idx = beam_next(s, b);
         if (idx < 0) break;
@@ -204,11 +207,16 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         ctr.n_hops++;
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
                                          : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
-        uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        uint32_t nb;
+        if (level == 0 && pf_id == cur) nb = pf_nb;
+        else nb = (uint32_t)lane < deg ? adj[lane] : 0u;
         bool fresh = nb != 0u && nb <= v.count;
         if (fresh) { // visited test-and-set (:2539-2542)
             const uint32_t bit = 1u << (nb & 31);
-            const uint32_t old = atomicOr(&visited[nb >> 5], bit);
+            uint32_t old;
+            if (v.dbg & 2u) { old = visited[nb >> 5]; visited[nb >> 5] = old | bit; }
+            else if (v.dbg & 8u) old = atomicOr(&visited[(nb >> 5) & 1023u], bit); // timing experiment: 4 KB window
+            else old = atomicOr(&visited[nb >> 5], bit);
             fresh = !(old & bit);
         }
         if (record_marks) {
@@ -222,13 +230,20 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
         const unsigned long long m = __ballot(fresh);
         const uint32_t n = (uint32_t)__builtin_popcountll(m);
+        if (level == 0) {
+            const int nidx = beam_next(s, b);
+            if (nidx >= 0) {
+                pf_id = s.beam_id[nidx] & KDB_ID_MASK;
+                pf_nb = (uint32_t)lane < deg ? v.adj0[(size_t)pf_id * v.deg0 + lane] : 0u;
+            }
+        }
         if (n == 0) continue;
         if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
         wave_lds_fence();
         // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather
         uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
-        const uint32_t delw = (uint32_t)lane < n ? v.deleted[my_id >> 5] : 0u;
-        compute_dists<PREC, METRIC>(v, s, n, qnorm);
+        const uint32_t delw = ((uint32_t)lane < n && !(v.dbg & 16u)) ? v.deleted[my_id >> 5] : 0u;
+        compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;

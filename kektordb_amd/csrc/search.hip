@@ -23,8 +23,11 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
     return PREC == KDB_PREC_I8 ? ((size_t)ld + 15) / 16 * 16 : (size_t)ld * 4;
 }
 
-template <int PREC, int METRIC>
-__global__ void __launch_bounds__(64)
+#ifndef KDB_SEARCH_MINW
+#define KDB_SEARCH_MINW 4
+#endif
+template <int PREC, int METRIC, int NCH>
+__global__ void __launch_bounds__(64, KDB_SEARCH_MINW)
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
                    uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work, unsigned long long *gctr,
@@ -56,7 +59,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         if (qi >= B) break;
 
         // clear the visited bitset (reference: BitSet.Clear per layer call, bitset.go:44-48)
-        {
+        if (!(v.dbg & 1u)) {
             uint4 z = make_uint4(0, 0, 0, 0);
             uint4 *v4 = reinterpret_cast<uint4 *>(visited);
             const uint32_t n4 = v.vis_words >> 2;
@@ -88,7 +91,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
             uint32_t n_marks = 0;
-            search_layer<PREC, METRIC>(v, s, b, visited, allow, ep, l, 1u, qnorm, true, n_marks, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, l, 1u, qnorm, true, n_marks, ctr);
             // first result entry
             int best = -1;
             for (uint32_t base = 0; base < b.count && best < 0; base += 64) {
@@ -115,7 +118,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         uint32_t nout = 0;
         if (!failed) {
             uint32_t dummy = 0;
-            search_layer<PREC, METRIC>(v, s, b, visited, allow, ep, 0, ef, qnorm, false, dummy, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, 0, ef, qnorm, false, dummy, ctr);
             // results = non traversal-only entries, ascending (:2596-2610), first k
             for (uint32_t base = 0; base < b.count && nout < k; base += 64) {
                 const uint32_t i = base + (uint32_t)lane;
@@ -325,7 +328,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
     return KDB_OK;
 }
 
-template <int PREC, int METRIC>
+template <int PREC, int METRIC, int NCH>
 static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                            uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                            float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
@@ -338,7 +341,7 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
         return KDB_ERR_UNSUPPORTED;
     }
-    auto kern = hnsw_search_kernel<PREC, METRIC>;
+    auto kern = hnsw_search_kernel<PREC, METRIC, NCH>;
     if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipDeviceProp_t prop;
     KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
@@ -365,10 +368,21 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s) {
 #define KDB_ARGS idx, v, d_q, d_qnorm, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
-    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F32, KDB_METRIC_L2>(KDB_ARGS);
-    if (v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_F32, KDB_METRIC_COSINE>(KDB_ARGS);
-    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2>(KDB_ARGS);
-    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE>(KDB_ARGS);
+    if (v.precision == KDB_PREC_F32) { // common row widths get fully unrolled row loads (NCH = ld/64)
+#define KDB_F32(M)                                                                            \
+    switch (v.ld) {                                                                           \
+    case 128: return launch_search_t<KDB_PREC_F32, M, 2>(KDB_ARGS);                           \
+    case 384: return launch_search_t<KDB_PREC_F32, M, 6>(KDB_ARGS);                           \
+    case 768: return launch_search_t<KDB_PREC_F32, M, 12>(KDB_ARGS);                          \
+    case 1024: return launch_search_t<KDB_PREC_F32, M, 16>(KDB_ARGS);                         \
+    default: return launch_search_t<KDB_PREC_F32, M, 0>(KDB_ARGS);                            \
+    }
+        if (v.metric == KDB_METRIC_L2) { KDB_F32(KDB_METRIC_L2) }
+        if (v.metric == KDB_METRIC_COSINE) { KDB_F32(KDB_METRIC_COSINE) }
+#undef KDB_F32
+    }
+    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2, 0>(KDB_ARGS);
+    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE, 0>(KDB_ARGS);
 #undef KDB_ARGS
     kdb_set_error("unsupported precision/metric combination");
     return KDB_ERR_UNSUPPORTED;

@@ -13,6 +13,7 @@ ap.add_argument("--efs", default="50,100,200")
 ap.add_argument("--efc", type=int, default=200)
 ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--metric", type=int, default=1)
+ap.add_argument("--sorted", type=int, default=0, help="1: ids cluster-contiguous (locality experiment)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -25,6 +26,8 @@ def gen(n, seed_off=0):
         if not hasattr(gen, "cent"):
             gen.cent = torch.randn((nc, a.dim), device=dev, generator=g)
         lab = torch.randint(0, nc, (n,), device=dev, generator=g)
+        if a.sorted and n > 100000:
+            lab = torch.sort(lab).values
         x = gen.cent[lab] + 0.3 * torch.randn((n, a.dim), device=dev, generator=g)
     if a.metric == 1:
         x = x / x.norm(dim=1, keepdim=True)
