@@ -64,7 +64,7 @@ struct BuildView {
 };
 
 // ---- phase 1 ------------------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, int BS>
 __global__ void __launch_bounds__(64)
 build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,10 +72,9 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     size_t off = 0;
     s.q = reinterpret_cast<float *>(smem + off);
     off += (size_t)v.ld * 4;
-    s.beam_d = reinterpret_cast<float *>(smem + off);
-    off += (size_t)beam_cap * 4;
-    s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
-    off += (size_t)beam_cap * 4;
+    s.beam_d = nullptr;
+    s.beam_id = nullptr;
+    (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
@@ -103,22 +102,25 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         }
         __threadfence_block();
         wave_lds_fence();
-        Beam b;
+        RegBeam<BS> b;
         QCtr ctr{0, 0};
         uint32_t ep = v.entry;
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;
             uint32_t n_marks = 0;
-            search_layer<KDB_PREC_F32, METRIC>(v, s, b, visited, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, l > 0, n_marks, ctr);
+            search_layer<KDB_PREC_F32, METRIC, 0>(v, s, b, visited, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, l > 0, n_marks, ctr);
             if (insert) {
                 const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
-                for (uint32_t i = (uint32_t)lane; i < b.count; i += 64) {
-                    bv.cand_id[(size_t)task * bv.efc + i] = s.beam_id[i] & KDB_ID_MASK;
-                    bv.cand_key[(size_t)task * bv.efc + i] = s.beam_d[i];
-                }
-                if (lane == 0) bv.cand_cnt[task] = b.count;
+                const uint32_t nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc,
+                                                    bv.cand_key + (size_t)task * bv.efc, false);
+                if (lane == 0) bv.cand_cnt[task] = nc;
             }
-            if (b.count > 0) ep = s.beam_id[0] & KDB_ID_MASK; // nearest (:786-788 / :1849)
+            if (b.count > 0) { // nearest (:786-788 / :1849)
+                float d0;
+                uint32_t f0;
+                b.get(0, d0, f0);
+                ep = f0 & KDB_ID_MASK;
+            }
             if (l > 0) {
                 if (n_marks <= KDB_UP_MARK_CAP) {
                     for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
@@ -570,10 +572,11 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
 
     // ---- launch geometry
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
-    const size_t lds_search = (size_t)idx->ld * 4 + (size_t)beam_cap * 8 + 64 * 8 + KDB_UP_MARK_CAP * 4;
+    const size_t lds_search = (size_t)idx->ld * 4 + 64 * 8 + KDB_UP_MARK_CAP * 4;
     const size_t lds_prune = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
                              (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
-    auto ksearch = build_search_kernel<METRIC>;
+    const int bs = kdb_beam_slots(efc);
+    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2> : bs == 4 ? build_search_kernel<METRIC, 4> : build_search_kernel<METRIC, 6>;
     auto kselect = build_select_kernel<METRIC>;
     auto krev = build_reverse_kernel<METRIC>;
     if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));

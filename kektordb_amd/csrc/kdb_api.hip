@@ -80,7 +80,7 @@ KdbView kdb_make_view(const kdb_index *idx) {
     v.vis_words = (idx->cap >> 5) + 1;
     v.vis_words = (v.vis_words + 3u) & ~3u;
     v.q_absmax = idx->absmax;
-    v.dbg = 0;
+    v.has_deleted = idx->n_deleted > 0 ? 1u : 0u;
     return v;
 }
 
@@ -566,7 +566,6 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         tr_nd = reinterpret_cast<uint32_t *>(idx->d_scratch);
         tr_nh = tr_nd + B;
     }
-    { const char *e = getenv("KDB_DBG"); v.dbg = e ? (uint32_t)atoi(e) : 0u; } // experiments only
     rc = kdb_launch_search(idx, v, d_q, d_qnorm, B, k, effective_ef(ef, flags), d_allow, entry, d_out_ids, d_out_dist,
                            d_out_count, tr_nd, tr_nh, s);
     if (rc) return rc;

@@ -31,7 +31,7 @@ struct KdbView {
     uint32_t metric, precision;
     uint32_t vis_words;      // words per visited bitset = (cap>>5)+1
     float q_absmax;          // int8 quantizer
-    uint32_t dbg;            // experiment flags (KDB_DBG env), 0 in production
+    uint32_t has_deleted;    // 0: no soft-deleted node, the per-neighbour Deleted lookup is skipped
 };
 
 struct kdb_index {

@@ -1,5 +1,13 @@
 // kdb_search_core.cuh -- wave-level HNSW layer search shared by search.hip and build.hip.
 // See search.hip for the design notes; reference: pkg/core/hnsw/hnsw_index.go:2351-2611.
+//
+// The reference's candidate min-heap + result max-heap (hnsw_heap.go) are ONE distance-sorted beam:
+// pop-min = first un-expanded entry, results = the non-traversal-only entries.  Two storages with the
+// same interface:
+//   RegBeam<S>  entry i lives in lane i&63, register slot i>>6 (64*S entries).  Position search is a
+//               ballot + scalar popcount, the shift is a DPP wave_shr, reads are v_readlane: no LDS
+//               round trips on the hop's critical path.  Used for ef <= 366.
+//   LdsBeam     arrays in LDS, any ef that fits LDS.
 #pragma once
 #include "kdb_device.cuh"
 #include <math.h>
@@ -8,17 +16,35 @@ namespace kdbcore {
 
 struct WaveLds {
     float *q;          // query (f32 values, or packed int8)
-    float *beam_d;     // [cap]
-    uint32_t *beam_id; // [cap]  id | flags
+    float *beam_d;     // [cap]   (LdsBeam only)
+    uint32_t *beam_id; // [cap]   id | flags
     uint32_t *nb_id;   // [64]
     float *nb_d;       // [64]
     uint32_t *marks;   // [KDB_UP_MARK_CAP]
 };
 
-struct Beam {
-    uint32_t count, n_res, n_nr, scan_from;
-    float worst;
-};
+// wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
+// told they are uniform
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float unif(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ float readlane_f(float x, uint32_t l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), (int)l));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t x, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l);
+}
+// lane i <- lane i-1 (lane 0 keeps its own value); DPP wave_shr:1
+__device__ __forceinline__ uint32_t shr1_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shr1_f(float x) { return __builtin_bit_cast(float, shr1_u(__builtin_bit_cast(uint32_t, x))); }
+// lane i <- lane i+1 (lane 63 keeps its own value); DPP wave_shl:1
+__device__ __forceinline__ uint32_t shl1_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shl1_f(float x) { return __builtin_bit_cast(float, shl1_u(__builtin_bit_cast(uint32_t, x))); }
 
 __device__ __forceinline__ void wave_lds_fence() {
     // single-wave workgroup: LDS operations of a wave execute in order; only the compiler needs
@@ -56,123 +82,357 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     wave_lds_fence();
 }
 
-__device__ __forceinline__ void beam_insert(const WaveLds &s, Beam &b, float d, uint32_t idf) {
-    const int lane = kdb_lane();
-    const uint32_t id = idf & KDB_ID_MASK;
-    int cnt = 0;
-    for (uint32_t i = (uint32_t)lane; i < b.count; i += 64) {
-        float e = s.beam_d[i];
-        uint32_t eid = s.beam_id[i] & KDB_ID_MASK;
-        cnt += ((e < d) || (e == d && eid < id)) ? 1 : 0;
-    }
-    const uint32_t pos = (uint32_t)kdb_wave_sum_i(cnt);
-    for (int hi = (int)b.count - 1; hi >= (int)pos; hi -= 64) {
-        const int i = hi - lane;
-        const bool act = i >= (int)pos;
-        float e = 0.f;
-        uint32_t x = 0;
-        if (act) {
-            e = s.beam_d[i];
-            x = s.beam_id[i];
-        }
-        wave_lds_fence();
-        if (act) {
-            s.beam_d[i + 1] = e;
-            s.beam_id[i + 1] = x;
-        }
-        wave_lds_fence();
-    }
-    if (lane == 0) {
-        s.beam_d[pos] = d;
-        s.beam_id[pos] = idf;
-    }
-    wave_lds_fence();
-    b.count++;
-    if (pos < b.scan_from) b.scan_from = pos;
-}
+// ------------------------------------------------------------------------------------------------
+// Register-resident beam
+// ------------------------------------------------------------------------------------------------
+template <int S>
+struct RegBeam {
+    static constexpr uint32_t CAP = 64u * S;
+    float d[S];
+    uint32_t id[S]; // id | flags
+    uint32_t count, n_res, n_nr, scan_from, nr_max;
+    float worst;
 
-// index of the last entry with (flag & mask) == want, searching the last 64 entries; -1 if none
-__device__ __forceinline__ int beam_last_with(const WaveLds &s, const Beam &b, uint32_t mask, uint32_t want) {
-    const int i = (int)b.count - 1 - kdb_lane();
-    const bool f = i >= 0 && ((s.beam_id[i] & mask) == want);
-    const unsigned long long m = __ballot(f);
-    if (!m) return -1;
-    return (int)b.count - 1 - __builtin_ctzll(m);
-}
-
-// keep the invariants: n_res <= ef; when n_res == ef the last entry is a result (worst);
-// at most 63 traversal-only entries.
-__device__ __forceinline__ void beam_trim(const WaveLds &s, Beam &b, uint32_t ef) {
-    if (b.n_res > ef) {
-        int j = b.n_nr == 0 ? (int)b.count - 1 : beam_last_with(s, b, KDB_F_NORESULT, 0u);
-        // entries after j are traversal-only and farther than the evicted result: drop them too
-        b.n_nr -= (b.count - 1 - (uint32_t)j);
-        b.count = (uint32_t)j;
-        b.n_res--;
-    }
-    if (b.n_res >= ef && b.n_nr != 0) {
-        int j = beam_last_with(s, b, KDB_F_NORESULT, 0u);
-        if (j >= 0) {
-            b.n_nr -= (b.count - 1 - (uint32_t)j);
-            b.count = (uint32_t)j + 1;
+    __device__ __forceinline__ void bind(const WaveLds &) {}
+    __device__ __forceinline__ void reset(uint32_t ef) {
+        count = n_res = n_nr = scan_from = 0;
+        worst = INFINITY;
+        const int slack = (int)CAP - (int)ef - 2; // traversal-only (deleted / non-allowed entry) entries kept
+        nr_max = slack > 63 ? 63u : (slack < 0 ? 0u : (uint32_t)slack);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            d[s] = INFINITY;
+            id[s] = 0u;
         }
     }
-    while (b.n_nr > 63) { // pathological: >63 deleted nodes nearer than the worst result; drop the farthest
-        int j = -1;
-        for (int base = (int)b.count - 1; base >= 0 && j < 0; base -= 64) {
-            const int i = base - kdb_lane();
-            const bool f = i >= 0 && (s.beam_id[i] & KDB_F_NORESULT);
+    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const { // idx wave-uniform
+        const uint32_t slot = idx >> 6, l = idx & 63u;
+        dd = 0.f;
+        idf = 0u;
+#pragma unroll
+        for (int s = 0; s < S; s++)
+            if (slot == (uint32_t)s) {
+                dd = readlane_f(d[s], l);
+                idf = readlane_u(id[s], l);
+            }
+    }
+    __device__ __forceinline__ void mark_expanded(uint32_t idx) {
+        const uint32_t lane = (uint32_t)kdb_lane();
+#pragma unroll
+        for (int s = 0; s < S; s++)
+            if (64u * s + lane == idx) id[s] |= KDB_F_EXPANDED;
+    }
+    __device__ __forceinline__ int next() {
+        const uint32_t lane = (uint32_t)kdb_lane();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * (s + 1) <= scan_from || 64u * s >= count) continue;
+            const uint32_t i = 64u * s + lane;
+            const bool f = i >= scan_from && i < count && !(id[s] & KDB_F_EXPANDED);
             const unsigned long long m = __ballot(f);
-            if (m) j = base - __builtin_ctzll(m);
+            if (m) return (int)(64u * s + (uint32_t)__builtin_ctzll(m));
         }
-        for (uint32_t lo = (uint32_t)j; lo + 1 < b.count; lo += 64) {
-            const uint32_t i = lo + (uint32_t)kdb_lane();
-            const bool act = i + 1 < b.count;
+        return -1;
+    }
+    // index of the last entry whose (flags & mask) == want; -1 if none
+    __device__ __forceinline__ int last_with(uint32_t mask, uint32_t want) const {
+        const uint32_t lane = (uint32_t)kdb_lane();
+#pragma unroll
+        for (int s = S - 1; s >= 0; s--) {
+            if (64u * s >= count) continue;
+            const uint32_t i = 64u * s + lane;
+            const bool f = i < count && ((id[s] & mask) == want);
+            const unsigned long long m = __ballot(f);
+            if (m) return (int)(64u * s + 63u - (uint32_t)__builtin_clzll(m));
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void insert(float dd, uint32_t idf) {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        const uint32_t idm = idf & KDB_ID_MASK;
+        uint32_t pos = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * s >= count) continue;
+            const uint32_t i = 64u * s + lane;
+            const float e = d[s];
+            const uint32_t eid = id[s] & KDB_ID_MASK;
+            const bool less = i < count && ((e < dd) || (e == dd && eid < idm));
+            pos += (uint32_t)__builtin_popcountll(__ballot(less));
+        }
+#pragma unroll
+        for (int s = S - 1; s >= 0; s--) {
+            if (64u * (s + 1) <= pos || 64u * s > count) continue; // untouched slots
+            const uint32_t i = 64u * s + lane;
+            float pd = shr1_f(d[s]);
+            uint32_t pi = shr1_u(id[s]);
+            if (s > 0) {
+                const float cd = readlane_f(d[s > 0 ? s - 1 : 0], 63);
+                const uint32_t ci = readlane_u(id[s > 0 ? s - 1 : 0], 63);
+                if (lane == 0) {
+                    pd = cd;
+                    pi = ci;
+                }
+            }
+            if (i > pos) {
+                d[s] = pd;
+                id[s] = pi;
+            } else if (i == pos) {
+                d[s] = dd;
+                id[s] = idf;
+            }
+        }
+        count++;
+        if (pos < scan_from) scan_from = pos;
+    }
+    // remove entry j (shift the tail left by one)
+    __device__ __forceinline__ void remove(uint32_t j) {
+        const uint32_t lane = (uint32_t)kdb_lane();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * (s + 1) <= j || 64u * s >= count) continue;
+            const uint32_t i = 64u * s + lane;
+            float nd = shl1_f(d[s]);
+            uint32_t ni = shl1_u(id[s]);
+            if (s + 1 < S) {
+                const float cd = readlane_f(d[s + 1 < S ? s + 1 : s], 0);
+                const uint32_t ci = readlane_u(id[s + 1 < S ? s + 1 : s], 0);
+                if (lane == 63) {
+                    nd = cd;
+                    ni = ci;
+                }
+            }
+            if (i >= j) {
+                d[s] = nd;
+                id[s] = ni;
+            }
+        }
+        count--;
+        if (scan_from > j) scan_from--;
+    }
+    // invariants: n_res <= ef; when n_res == ef the last entry is a result (the worst);
+    // at most nr_max traversal-only entries
+    __device__ __forceinline__ void trim(uint32_t ef) {
+        if (n_res > ef) {
+            const int j = n_nr == 0 ? (int)count - 1 : last_with(KDB_F_NORESULT, 0u);
+            n_nr -= (count - 1 - (uint32_t)j); // farther traversal-only entries go with it
+            count = (uint32_t)j;
+            n_res--;
+        }
+        if (n_res >= ef && n_nr != 0) {
+            const int j = last_with(KDB_F_NORESULT, 0u);
+            if (j >= 0) {
+                n_nr -= (count - 1 - (uint32_t)j);
+                count = (uint32_t)j + 1;
+            }
+        }
+        while (n_nr > nr_max) { // pathological: many deleted nodes nearer than the worst result
+            const int j = last_with(KDB_F_NORESULT, KDB_F_NORESULT);
+            remove((uint32_t)j);
+            n_nr--;
+        }
+        if (n_res >= ef && count > 0) {
+            float dd;
+            uint32_t idf;
+            get(count - 1, dd, idf);
+            worst = dd;
+        } else {
+            worst = INFINITY;
+        }
+    }
+    __device__ __forceinline__ int first_result() const { // index of the nearest result entry, -1 if none
+        const uint32_t lane = (uint32_t)kdb_lane();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * s >= count) continue;
+            const uint32_t i = 64u * s + lane;
+            const bool f = i < count && !(id[s] & KDB_F_NORESULT);
+            const unsigned long long m = __ballot(f);
+            if (m) return (int)(64u * s + (uint32_t)__builtin_ctzll(m));
+        }
+        return -1;
+    }
+    // results (non traversal-only entries, ascending), first k -> out arrays; returns the number written
+    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate) const {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        uint32_t nout = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * s >= count || nout >= k) continue;
+            const uint32_t i = 64u * s + lane;
+            const bool f = i < count && !(id[s] & KDB_F_NORESULT);
+            const unsigned long long m = __ballot(f);
+            const uint32_t p = nout + kdb_mbcnt(m);
+            if (f && p < k) {
+                out_ids[p] = id[s] & KDB_ID_MASK;
+                out_key[p] = negate ? -d[s] : d[s];
+            }
+            nout += (uint32_t)__builtin_popcountll(m);
+        }
+        return nout > k ? k : nout;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident beam (any ef)
+// ------------------------------------------------------------------------------------------------
+struct LdsBeam {
+    float *bd;
+    uint32_t *bi;
+    uint32_t count, n_res, n_nr, scan_from, nr_max;
+    float worst;
+
+    __device__ __forceinline__ void bind(const WaveLds &s) {
+        bd = s.beam_d;
+        bi = s.beam_id;
+    }
+    __device__ __forceinline__ void reset(uint32_t) {
+        count = n_res = n_nr = scan_from = 0;
+        worst = INFINITY;
+        nr_max = 63;
+    }
+    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const {
+        dd = unif(bd[idx]);
+        idf = uni(bi[idx]);
+    }
+    __device__ __forceinline__ void mark_expanded(uint32_t idx) {
+        if (kdb_lane() == 0) bi[idx] |= KDB_F_EXPANDED;
+        wave_lds_fence();
+    }
+    __device__ __forceinline__ int next() {
+        for (uint32_t base = scan_from; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            const bool f = i < count && !(bi[i] & KDB_F_EXPANDED);
+            const unsigned long long m = __ballot(f);
+            if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
+        }
+        return -1;
+    }
+    __device__ __forceinline__ int last_with(uint32_t mask, uint32_t want) const {
+        for (int base = (int)count - 1; base >= 0; base -= 64) {
+            const int i = base - kdb_lane();
+            const bool f = i >= 0 && ((bi[i] & mask) == want);
+            const unsigned long long m = __ballot(f);
+            if (m) return base - __builtin_ctzll(m);
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void insert(float dd, uint32_t idf) {
+        const int lane = kdb_lane();
+        const uint32_t idm = idf & KDB_ID_MASK;
+        uint32_t pos = 0;
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            bool less = false;
+            if (i < count) {
+                const float e = bd[i];
+                const uint32_t eid = bi[i] & KDB_ID_MASK;
+                less = (e < dd) || (e == dd && eid < idm);
+            }
+            pos += (uint32_t)__builtin_popcountll(__ballot(less));
+        }
+        for (int hi = (int)count - 1; hi >= (int)pos; hi -= 64) {
+            const int i = hi - lane;
+            const bool act = i >= (int)pos;
             float e = 0.f;
             uint32_t x = 0;
             if (act) {
-                e = s.beam_d[i + 1];
-                x = s.beam_id[i + 1];
+                e = bd[i];
+                x = bi[i];
             }
             wave_lds_fence();
             if (act) {
-                s.beam_d[i] = e;
-                s.beam_id[i] = x;
+                bd[i + 1] = e;
+                bi[i + 1] = x;
             }
             wave_lds_fence();
         }
-        b.count--;
-        b.n_nr--;
-        if (b.scan_from > (uint32_t)j) b.scan_from--;
+        if (lane == 0) {
+            bd[pos] = dd;
+            bi[pos] = idf;
+        }
+        wave_lds_fence();
+        count++;
+        if (pos < scan_from) scan_from = pos;
     }
-    b.worst = (b.n_res >= ef && b.count > 0) ? s.beam_d[b.count - 1] : INFINITY;
-}
-
-__device__ __forceinline__ int beam_next(const WaveLds &s, Beam &b) {
-    for (uint32_t base = b.scan_from; base < b.count; base += 64) {
-        const uint32_t i = base + (uint32_t)kdb_lane();
-        const bool f = i < b.count && !(s.beam_id[i] & KDB_F_EXPANDED);
-        const unsigned long long m = __ballot(f);
-        if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
+    __device__ __forceinline__ void remove(uint32_t j) {
+        for (uint32_t lo = j; lo + 1 < count; lo += 64) {
+            const uint32_t i = lo + (uint32_t)kdb_lane();
+            const bool act = i + 1 < count;
+            float e = 0.f;
+            uint32_t x = 0;
+            if (act) {
+                e = bd[i + 1];
+                x = bi[i + 1];
+            }
+            wave_lds_fence();
+            if (act) {
+                bd[i] = e;
+                bi[i] = x;
+            }
+            wave_lds_fence();
+        }
+        count--;
+        if (scan_from > j) scan_from--;
     }
-    return -1;
-}
+    __device__ __forceinline__ void trim(uint32_t ef) {
+        if (n_res > ef) {
+            const int j = n_nr == 0 ? (int)count - 1 : last_with(KDB_F_NORESULT, 0u);
+            n_nr -= (count - 1 - (uint32_t)j);
+            count = (uint32_t)j;
+            n_res--;
+        }
+        if (n_res >= ef && n_nr != 0) {
+            const int j = last_with(KDB_F_NORESULT, 0u);
+            if (j >= 0) {
+                n_nr -= (count - 1 - (uint32_t)j);
+                count = (uint32_t)j + 1;
+            }
+        }
+        while (n_nr > nr_max) {
+            const int j = last_with(KDB_F_NORESULT, KDB_F_NORESULT);
+            remove((uint32_t)j);
+            n_nr--;
+        }
+        worst = (n_res >= ef && count > 0) ? unif(bd[count - 1]) : INFINITY;
+    }
+    __device__ __forceinline__ int first_result() const {
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            const bool f = i < count && !(bi[i] & KDB_F_NORESULT);
+            const unsigned long long m = __ballot(f);
+            if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
+        }
+        return -1;
+    }
+    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate) const {
+        uint32_t nout = 0;
+        for (uint32_t base = 0; base < count && nout < k; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            const bool f = i < count && !(bi[i] & KDB_F_NORESULT);
+            const unsigned long long m = __ballot(f);
+            const uint32_t p = nout + kdb_mbcnt(m);
+            if (f && p < k) {
+                out_ids[p] = bi[i] & KDB_ID_MASK;
+                out_key[p] = negate ? -bd[i] : bd[i];
+            }
+            nout += (uint32_t)__builtin_popcountll(m);
+        }
+        return nout > k ? k : nout;
+    }
+};
 
 struct QCtr {
     uint32_t n_dist, n_hops;
 };
 
-// searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the beam in LDS.
-template <int PREC, int METRIC, int NCH = 0>
-__device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32_t *visited,
+// searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
+template <int PREC, int METRIC, int NCH, class BeamT>
+__device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, uint32_t *visited,
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm,
                              bool record_marks, uint32_t &n_marks, QCtr &ctr) {
     const int lane = kdb_lane();
-    b.count = 0;
-    b.n_res = 0;
-    b.n_nr = 0;
-    b.scan_from = 0;
-    b.worst = INFINITY;
+    b.reset(ef);
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     if (lane == 0) s.nb_id[0] = ep;
     wave_lds_fence();
@@ -186,37 +446,30 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         }
         bool nr = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
         if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) nr = true;
-        beam_insert(s, b, s.nb_d[0], ep | (nr ? KDB_F_NORESULT : 0u));
+        b.insert(unif(s.nb_d[0]), ep | (nr ? KDB_F_NORESULT : 0u));
         if (nr) b.n_nr++; else b.n_res++;
-        beam_trim(s, b, ef);
+        b.trim(ef);
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
-    // level-0 adjacency prefetch: while a hop's rows are in flight, the neighbour list of the candidate
-    // that will be expanded next (unless this hop inserts a nearer one) is already being fetched
-    uint32_t pf_id = 0, pf_nb = 0;
     for (;;) {
-        const int idx = beam_next(s, b);
+        const int idx = b.next();
         if (idx < 0) break;
-        const uint32_t cur = s.beam_id[idx] & KDB_ID_MASK;
-        const float cur_d = s.beam_d[idx];
+        float cur_d;
+        uint32_t cur_f;
+        b.get((uint32_t)idx, cur_d, cur_f);
+        const uint32_t cur = cur_f & KDB_ID_MASK;
         if (b.n_res >= ef && cur_d > b.worst) break; // :2501-2506 (never true after trimming; kept for clarity)
-        if (lane == 0) s.beam_id[idx] |= KDB_F_EXPANDED;
+        b.mark_expanded((uint32_t)idx);
         b.scan_from = (uint32_t)idx + 1;
-        wave_lds_fence();
         if (level > 0 && (int)v.levels[cur] < level) continue; // :2524-2527 node lacks this level
         ctr.n_hops++;
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
                                          : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
-        uint32_t nb;
-        if (level == 0 && pf_id == cur) nb = pf_nb;
-        else nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
         bool fresh = nb != 0u && nb <= v.count;
         if (fresh) { // visited test-and-set (:2539-2542)
             const uint32_t bit = 1u << (nb & 31);
-            uint32_t old;
-            if (v.dbg & 2u) { old = visited[nb >> 5]; visited[nb >> 5] = old | bit; }
-            else if (v.dbg & 8u) old = atomicOr(&visited[(nb >> 5) & 1023u], bit); // timing experiment: 4 KB window
-            else old = atomicOr(&visited[nb >> 5], bit);
+            const uint32_t old = atomicOr(&visited[nb >> 5], bit);
             fresh = !(old & bit);
         }
         if (record_marks) {
@@ -230,19 +483,13 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
         const unsigned long long m = __ballot(fresh);
         const uint32_t n = (uint32_t)__builtin_popcountll(m);
-        if (level == 0) {
-            const int nidx = beam_next(s, b);
-            if (nidx >= 0) {
-                pf_id = s.beam_id[nidx] & KDB_ID_MASK;
-                pf_nb = (uint32_t)lane < deg ? v.adj0[(size_t)pf_id * v.deg0 + lane] : 0u;
-            }
-        }
         if (n == 0) continue;
         if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
         wave_lds_fence();
-        // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather
+        // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather;
+        // skipped when the index holds no deleted node
         uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
-        const uint32_t delw = ((uint32_t)lane < n && !(v.dbg & 16u)) ? v.deleted[my_id >> 5] : 0u;
+        const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
         compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
@@ -250,18 +497,26 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, Beam &b, uint32
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || my_d < b.worst));
         while (pass) { // sequential, in stored order (:2577-2590)
-            const int j = __builtin_ctzll(pass);
+            const uint32_t j = (uint32_t)__builtin_ctzll(pass);
             pass &= pass - 1;
-            const float d = __shfl(my_d, j, 64);
+            const float d = readlane_f(my_d, j);
             if (!(b.n_res < ef || d < b.worst)) continue;
-            const uint32_t id = __shfl(my_id, j, 64);
-            const bool nr = __shfl((int)my_nr, j, 64) != 0;
-            beam_insert(s, b, d, id | (nr ? KDB_F_NORESULT : 0u));
+            const uint32_t id = readlane_u(my_id, j);
+            const bool nr = readlane_u((uint32_t)my_nr, j) != 0;
+            b.insert(d, id | (nr ? KDB_F_NORESULT : 0u));
             if (nr) b.n_nr++; else b.n_res++;
-            beam_trim(s, b, ef);
+            b.trim(ef);
         }
     }
 }
 
+// beam slots needed for ef (>= 16 traversal-only entries of slack); 0 = use the LDS beam
+__host__ __device__ inline int kdb_beam_slots(uint32_t ef) {
+    const uint32_t need = ef + 2 + 16;
+    if (need <= 128) return 2;
+    if (need <= 256) return 4;
+    if (need <= 384) return 6;
+    return 0;
+}
 
 } // namespace kdbcore

@@ -18,6 +18,9 @@ using namespace kdbcore;
 
 namespace {
 
+template <int BS> struct BeamSel { using type = RegBeam<BS>; };
+template <> struct BeamSel<0> { using type = LdsBeam; };
+
 template <int PREC>
 __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
     return PREC == KDB_PREC_I8 ? ((size_t)ld + 15) / 16 * 16 : (size_t)ld * 4;
@@ -26,7 +29,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #ifndef KDB_SEARCH_MINW
 #define KDB_SEARCH_MINW 4
 #endif
-template <int PREC, int METRIC, int NCH>
+template <int PREC, int METRIC, int NCH, int BS>
 __global__ void __launch_bounds__(64, KDB_SEARCH_MINW)
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
@@ -39,9 +42,9 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.q = reinterpret_cast<float *>(smem + off);
     off += q_lds_bytes<PREC>(v.ld);
     s.beam_d = reinterpret_cast<float *>(smem + off);
-    off += (size_t)beam_cap * 4;
+    if (BS == 0) off += (size_t)beam_cap * 4;
     s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
-    off += (size_t)beam_cap * 4;
+    if (BS == 0) off += (size_t)beam_cap * 4;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
@@ -51,6 +54,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     const int lane = kdb_lane();
     uint32_t *visited = visited_pool + (size_t)blockIdx.x * v.vis_words;
     unsigned long long tot_dist = 0, tot_hops = 0;
+    typename BeamSel<BS>::type b;
+    b.bind(s);
 
     for (;;) {
         uint32_t qi = 0;
@@ -59,7 +64,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         if (qi >= B) break;
 
         // clear the visited bitset (reference: BitSet.Clear per layer call, bitset.go:44-48)
-        if (!(v.dbg & 1u)) {
+        {
             uint4 z = make_uint4(0, 0, 0, 0);
             uint4 *v4 = reinterpret_cast<uint4 *>(visited);
             const uint32_t n4 = v.vis_words >> 2;
@@ -84,7 +89,6 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         __threadfence_block();
         wave_lds_fence();
 
-        Beam b;
         QCtr ctr{0, 0};
         uint32_t ep = entry;
         bool failed = false;
@@ -92,16 +96,14 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         for (int l = v.max_level; l > 0 && !failed; l--) {
             uint32_t n_marks = 0;
             search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, l, 1u, qnorm, true, n_marks, ctr);
-            // first result entry
-            int best = -1;
-            for (uint32_t base = 0; base < b.count && best < 0; base += 64) {
-                const uint32_t i = base + (uint32_t)lane;
-                const bool f = i < b.count && !(s.beam_id[i] & KDB_F_NORESULT);
-                const unsigned long long m = __ballot(f);
-                if (m) best = (int)(base + (uint32_t)__builtin_ctzll(m));
-            }
+            const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
-            else ep = s.beam_id[best] & KDB_ID_MASK;
+            else {
+                float bd_;
+                uint32_t bf_;
+                b.get((uint32_t)best, bd_, bf_);
+                ep = bf_ & KDB_ID_MASK;
+            }
             // un-mark what this layer marked (the reference clears the whole bitset per call)
             if (n_marks <= KDB_UP_MARK_CAP) {
                 for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
@@ -120,19 +122,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             uint32_t dummy = 0;
             search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, 0, ef, qnorm, false, dummy, ctr);
             // results = non traversal-only entries, ascending (:2596-2610), first k
-            for (uint32_t base = 0; base < b.count && nout < k; base += 64) {
-                const uint32_t i = base + (uint32_t)lane;
-                const bool f = i < b.count && !(s.beam_id[i] & KDB_F_NORESULT);
-                const unsigned long long m = __ballot(f);
-                const uint32_t p = nout + kdb_mbcnt(m);
-                if (f && p < k) {
-                    out_ids[(size_t)qi * k + p] = s.beam_id[i] & KDB_ID_MASK;
-                    float key = s.beam_d[i];
-                    out_dist[(size_t)qi * k + p] = (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) ? -key : key;
-                }
-                nout += (uint32_t)__builtin_popcountll(m);
-            }
-            if (nout > k) nout = k;
+            nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
+                                   PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
         }
         for (uint32_t p = nout + (uint32_t)lane; p < k; p += 64) {
             out_ids[(size_t)qi * k + p] = 0u;
@@ -328,20 +319,20 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
     return KDB_OK;
 }
 
-template <int PREC, int METRIC, int NCH>
-static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+template <int PREC, int METRIC, int NCH, int BS>
+static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                            uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                            float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
     const uint32_t beam_cap = ((eff + 64 + 1) + 63) / 64 * 64;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds = qb + (size_t)beam_cap * 8 + 64 * 8 + KDB_UP_MARK_CAP * 4;
+    const size_t lds = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8 + KDB_UP_MARK_CAP * 4;
     if (lds > 160 * 1024) {
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
         return KDB_ERR_UNSUPPORTED;
     }
-    auto kern = hnsw_search_kernel<PREC, METRIC, NCH>;
+    auto kern = hnsw_search_kernel<PREC, METRIC, NCH, BS>;
     if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipDeviceProp_t prop;
     KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
@@ -363,6 +354,22 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
     return KDB_OK;
 }
 
+template <int PREC, int METRIC, int NCH>
+static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                           uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                           float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
+                           hipStream_t s) {
+    const uint32_t eff = ef < k ? k : ef;
+#define KDB_A idx, v, d_q, d_qnorm, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+    switch (kdb_beam_slots(eff)) { // beam in registers (2/4/6 slots of 64 entries) or in LDS
+    case 2: return launch_search_bs<PREC, METRIC, NCH, 2>(KDB_A);
+    case 4: return launch_search_bs<PREC, METRIC, NCH, 4>(KDB_A);
+    case 6: return launch_search_bs<PREC, METRIC, NCH, 6>(KDB_A);
+    default: return launch_search_bs<PREC, METRIC, NCH, 0>(KDB_A);
+    }
+#undef KDB_A
+}
+
 int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                       uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
@@ -374,7 +381,6 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
     case 128: return launch_search_t<KDB_PREC_F32, M, 2>(KDB_ARGS);                           \
     case 384: return launch_search_t<KDB_PREC_F32, M, 6>(KDB_ARGS);                           \
     case 768: return launch_search_t<KDB_PREC_F32, M, 12>(KDB_ARGS);                          \
-    case 1024: return launch_search_t<KDB_PREC_F32, M, 16>(KDB_ARGS);                         \
     default: return launch_search_t<KDB_PREC_F32, M, 0>(KDB_ARGS);                            \
     }
         if (v.metric == KDB_METRIC_L2) { KDB_F32(KDB_METRIC_L2) }

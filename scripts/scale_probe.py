@@ -49,6 +49,8 @@ for ef in [int(e) for e in a.efs.split(",")]:
     idx.search_batch_dev(Q, k, ef, si, sd, sc); idx.sync()
     t0 = time.time(); idx.search_batch_dev(Q, k, ef, si, sd, sc); idx.sync(); t = time.time() - t0
     c = idx.counters()
+    print("pf_hits/q", (c["n_dist"] >> 40) / a.nq); c["n_dist"] &= (1 << 40) - 1
+    c["bytes"] = c["n_dist"] * (a.dim * 4 + 4) + c["n_hops"] * 128
     r = si.cpu().numpy()
     rec = np.mean([len(set(r[i].tolist()) & set(gt[i].tolist())) / k for i in range(a.nq)])
     print(json.dumps({"ef": ef, "recall": round(float(rec), 4), "qps": round(a.nq / t), "ms": round(t * 1e3, 2), "kernel_ms": round(c["kernel_ms"], 3),
