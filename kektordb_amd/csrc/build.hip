@@ -81,7 +81,10 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     off += 64 * 4;
     s.marks = reinterpret_cast<uint32_t *>(smem + off);
     const int lane = kdb_lane();
-    uint32_t *visited = visited_pool + (size_t)blockIdx.x * v.vis_words;
+    VisBitset vis;
+    vis.bits = visited_pool + (size_t)blockIdx.x * v.vis_words;
+    vis.words = v.vis_words;
+    vis.marks = s.marks;
     for (;;) {
         uint32_t bi = 0;
         if (lane == 0) bi = atomicAdd(work, 1u);
@@ -89,12 +92,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         if (bi >= bv.nb) break;
         const uint32_t node = bv.first + bi;
         const int L = (int)v.levels[node];
-        {
-            uint4 z = make_uint4(0, 0, 0, 0);
-            uint4 *v4 = reinterpret_cast<uint4 *>(visited);
-            for (uint32_t i = (uint32_t)lane; i < (v.vis_words >> 2); i += 64) v4[i] = z;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        vis.begin_query();
         {
             const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)node * v.ld);
             float4 *dst = reinterpret_cast<float4 *>(s.q);
@@ -107,8 +105,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         uint32_t ep = v.entry;
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;
-            uint32_t n_marks = 0;
-            search_layer<KDB_PREC_F32, METRIC, 0>(v, s, b, visited, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, l > 0, n_marks, ctr);
+            search_layer<KDB_PREC_F32, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, ctr);
             if (insert) {
                 const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
                 const uint32_t nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc,
@@ -120,19 +117,6 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
                 uint32_t f0;
                 b.get(0, d0, f0);
                 ep = f0 & KDB_ID_MASK;
-            }
-            if (l > 0) {
-                if (n_marks <= KDB_UP_MARK_CAP) {
-                    for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
-                        const uint32_t id = s.marks[i];
-                        atomicAnd(&visited[id >> 5], ~(1u << (id & 31)));
-                    }
-                } else {
-                    for (uint32_t i = (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __threadfence_block();
-                wave_lds_fence();
             }
         }
     }

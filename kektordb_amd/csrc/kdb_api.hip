@@ -127,6 +127,19 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
     return idx->d_ctr + (size_t)slot * 2;
 }
 
+int kdb_ensure_retry(kdb_index *idx, uint32_t n) {
+    if (idx->retry_cap >= n) return KDB_OK;
+    if (idx->d_retry) {
+        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipFree(idx->d_retry));
+        idx->d_retry = nullptr;
+        idx->retry_cap = 0;
+    }
+    KDB_HIP(hipMalloc(&idx->d_retry, ((size_t)n + n / 4 + 64) * 4));
+    idx->retry_cap = n + n / 4 + 64;
+    return KDB_OK;
+}
+
 static int ensure_qbuf(kdb_index *idx, size_t bytes) {
     if (idx->qbuf_bytes >= bytes) return KDB_OK;
     if (idx->d_qbuf) {
@@ -244,7 +257,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
                     idx->d_deleted, idx->d_visited, idx->d_scratch, idx->d_work,  idx->d_ctr,    idx->d_qbuf,
-                    idx->d_iobuf, idx->d_build};
+                    idx->d_iobuf, idx->d_build, idx->d_retry};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (uint32_t i = 0; i < kdb_index::RING; i++) {

@@ -422,28 +422,140 @@ struct LdsBeam {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Visited set (the reference's BitSet, bitset.go).  Two exact implementations:
+//   VisBitset  one bit per node in a per-wave bitset in HBM; atomicOr test-and-set.  Any size.
+//   VisHash    open-addressing hash set of node ids in LDS (ds_cmpst), sized from ef: the set only ever
+//              holds the n_dist ids a query evaluates (~9*ef), so it fits in a few KB, needs no HBM
+//              traffic and no clearing pass.  On overflow the query is retried with VisBitset.
+// ------------------------------------------------------------------------------------------------
+struct VisBitset {
+    uint32_t *bits;
+    uint32_t words;
+    uint32_t *marks; // LDS list of ids marked on an upper layer (un-marked afterwards)
+    uint32_t n_marks;
+    bool record;
+    static constexpr bool kHash = false;
+    __device__ __forceinline__ bool overflowed() const { return false; }
+    __device__ __forceinline__ void clear_all() {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *v4 = reinterpret_cast<uint4 *>(bits);
+        const uint32_t n4 = words >> 2;
+        for (uint32_t i = lane; i < n4; i += 64) v4[i] = z;
+        for (uint32_t i = (n4 << 2) + lane; i < words; i += 64) bits[i] = 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores land before the first atomicOr
+    }
+    __device__ __forceinline__ void begin_query() { clear_all(); }
+    __device__ __forceinline__ void begin_layer(bool upper) {
+        record = upper;
+        n_marks = 0;
+    }
+    __device__ __forceinline__ void end_layer() { // un-mark what an upper layer marked
+        if (!record) return;
+        const uint32_t lane = (uint32_t)kdb_lane();
+        if (n_marks <= KDB_UP_MARK_CAP) {
+            for (uint32_t i = lane; i < n_marks; i += 64) {
+                const uint32_t id = marks[i];
+                atomicAnd(&bits[id >> 5], ~(1u << (id & 31)));
+            }
+        } else {
+            clear_all();
+        }
+        __threadfence_block();
+        wave_lds_fence();
+    }
+    // per lane: mark `id`; true if it was not marked before.  All lanes must call (ballots inside).
+    __device__ __forceinline__ bool test_and_set(uint32_t id, bool active) {
+        bool fresh = false;
+        if (active) {
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = atomicOr(&bits[id >> 5], bit);
+            fresh = !(old & bit);
+        }
+        if (record) {
+            const unsigned long long mm = __ballot(fresh);
+            if (fresh) {
+                const uint32_t p = n_marks + kdb_mbcnt(mm);
+                if (p < KDB_UP_MARK_CAP) marks[p] = id;
+            }
+            n_marks += (uint32_t)__builtin_popcountll(mm);
+        }
+        return fresh;
+    }
+};
+
+struct VisHash { // hybrid: LDS hash set that migrates into the wave's HBM bitset if it fills up
+    uint32_t *tab;   // LDS, `size` words, 0 = empty, else node id
+    uint32_t size;   // power of two
+    uint32_t shift;  // 32 - log2(size)
+    uint32_t n, limit;
+    bool in_bits;    // wave-uniform: this layer call has spilled to the bitset
+    VisBitset bs;
+    static constexpr bool kHash = true;
+    __device__ __forceinline__ bool overflowed() const { return false; }
+    __device__ __forceinline__ void clear_tab() {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = lane; i < (size >> 2); i += 64) t4[i] = z;
+        n = 0;
+        wave_lds_fence();
+    }
+    __device__ __forceinline__ void begin_query() {}
+    __device__ __forceinline__ void begin_layer(bool) { // BitSet.Clear per layer call (bitset.go:44-48)
+        in_bits = false;
+        bs.record = false;
+        bs.n_marks = 0;
+        clear_tab();
+    }
+    __device__ __forceinline__ void end_layer() {}
+    __device__ __forceinline__ void migrate() { // rare: the set outgrew LDS -> continue on the HBM bitset
+        const uint32_t lane = (uint32_t)kdb_lane();
+        bs.clear_all();
+        for (uint32_t i = lane; i < size; i += 64) {
+            const uint32_t id = tab[i];
+            if (id) atomicOr(&bs.bits[id >> 5], 1u << (id & 31));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        in_bits = true;
+    }
+    __device__ __forceinline__ bool test_and_set(uint32_t id, bool active) {
+        if (in_bits) return bs.test_and_set(id, active);
+        bool fresh = false;
+        if (active) {
+            uint32_t h = (id * 2654435761u) >> shift;
+            for (uint32_t probe = 0; probe < size; probe++) {
+                const uint32_t old = atomicCAS(&tab[h], 0u, id); // ds_cmpst_rtn_b32
+                if (old == 0u) { fresh = true; break; }
+                if (old == id) break;
+                h = (h + 1u) & (size - 1u);
+            }
+        }
+        n += (uint32_t)__builtin_popcountll(__ballot(fresh));
+        if (n > limit) migrate();
+        return fresh;
+    }
+};
+
 struct QCtr {
     uint32_t n_dist, n_hops;
 };
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
-template <int PREC, int METRIC, int NCH, class BeamT>
-__device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, uint32_t *visited,
-                             const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm,
-                             bool record_marks, uint32_t &n_marks, QCtr &ctr) {
+template <int PREC, int METRIC, int NCH, class BeamT, class VisT>
+__device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT &vis,
+                             const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr) {
     const int lane = kdb_lane();
     b.reset(ef);
+    vis.begin_layer(level > 0);
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     if (lane == 0) s.nb_id[0] = ep;
     wave_lds_fence();
     compute_dists<PREC, METRIC, NCH>(v, s, 1, qnorm);
     ctr.n_dist++;
     {
-        if (lane == 0) atomicOr(&visited[ep >> 5], 1u << (ep & 31));
-        if (record_marks) {
-            if (lane == 0 && n_marks < KDB_UP_MARK_CAP) s.marks[n_marks] = ep;
-            n_marks++;
-        }
+        (void)vis.test_and_set(ep, lane == 0);
         bool nr = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
         if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) nr = true;
         b.insert(unif(s.nb_d[0]), ep | (nr ? KDB_F_NORESULT : 0u));
@@ -466,20 +578,8 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, uint3
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
                                          : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
         uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
-        bool fresh = nb != 0u && nb <= v.count;
-        if (fresh) { // visited test-and-set (:2539-2542)
-            const uint32_t bit = 1u << (nb & 31);
-            const uint32_t old = atomicOr(&visited[nb >> 5], bit);
-            fresh = !(old & bit);
-        }
-        if (record_marks) {
-            const unsigned long long mm = __ballot(fresh);
-            if (fresh) {
-                const uint32_t p = n_marks + kdb_mbcnt(mm);
-                if (p < KDB_UP_MARK_CAP) s.marks[p] = nb;
-            }
-            n_marks += (uint32_t)__builtin_popcountll(mm);
-        }
+        // visited test-and-set (:2539-2542)
+        bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
         const unsigned long long m = __ballot(fresh);
         const uint32_t n = (uint32_t)__builtin_popcountll(m);
@@ -508,6 +608,14 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, uint3
             b.trim(ef);
         }
     }
+    vis.end_layer();
+}
+
+// LDS hash-set size (words) for ef; 0 = use the HBM bitset
+__host__ __device__ inline uint32_t kdb_vis_hash_size(uint32_t ef) {
+    if (ef <= 100) return 2048; // the set holds the ~9*ef ids a query evaluates
+    if (ef <= 260) return 4096;
+    return 0;
 }
 
 // beam slots needed for ef (>= 16 traversal-only entries of slack); 0 = use the LDS beam

@@ -13,6 +13,8 @@
 //     upper layers un-mark what they marked instead of clearing;
 //   * queries are pulled from an atomic work counter by persistent waves.
 #include "kdb_search_core.cuh"
+#include <stdio.h>
+#include <stdlib.h>
 
 using namespace kdbcore;
 
@@ -20,6 +22,8 @@ namespace {
 
 template <int BS> struct BeamSel { using type = RegBeam<BS>; };
 template <> struct BeamSel<0> { using type = LdsBeam; };
+template <int VIS> struct VisSel { using type = VisBitset; };
+template <> struct VisSel<1> { using type = VisHash; };
 
 template <int PREC>
 __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
@@ -29,13 +33,15 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #ifndef KDB_SEARCH_MINW
 #define KDB_SEARCH_MINW 4
 #endif
-template <int PREC, int METRIC, int NCH, int BS>
+// VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
+// VIS = 0: visited bitset in HBM.
+template <int PREC, int METRIC, int NCH, int BS, int VIS>
 __global__ void __launch_bounds__(64, KDB_SEARCH_MINW)
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
-                   uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work, unsigned long long *gctr,
-                   uint32_t *out_ids, float *out_dist, uint32_t *out_count, uint32_t *tr_ndist,
-                   uint32_t *tr_nhops) {
+                   uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
+                   unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
+                   uint32_t *tr_ndist, uint32_t *tr_nhops) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds s;
     size_t off = 0;
@@ -49,29 +55,33 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
-    s.marks = reinterpret_cast<uint32_t *>(smem + off);
+    s.marks = reinterpret_cast<uint32_t *>(smem + off); // VIS=0: un-mark list; VIS=1: the hash table
 
     const int lane = kdb_lane();
-    uint32_t *visited = visited_pool + (size_t)blockIdx.x * v.vis_words;
     unsigned long long tot_dist = 0, tot_hops = 0;
     typename BeamSel<BS>::type b;
     b.bind(s);
-
+    typename VisSel<VIS>::type vis;
+    if constexpr (VIS == 1) {
+        vis.tab = s.marks;
+        vis.size = vis_size;
+        vis.shift = 32u - (uint32_t)__builtin_ctz(vis_size);
+        vis.limit = vis_size - vis_size / 8 - 64u; // probing stays short; room for one more hop
+        vis.bs.bits = visited_pool + (size_t)blockIdx.x * v.vis_words;
+        vis.bs.words = v.vis_words;
+        vis.bs.marks = nullptr;
+    } else {
+        vis.bits = visited_pool + (size_t)blockIdx.x * v.vis_words;
+        vis.words = v.vis_words;
+        vis.marks = s.marks;
+    }
     for (;;) {
         uint32_t qi = 0;
         if (lane == 0) qi = atomicAdd(work, 1u);
         qi = __shfl(qi, 0, 64);
         if (qi >= B) break;
 
-        // clear the visited bitset (reference: BitSet.Clear per layer call, bitset.go:44-48)
-        {
-            uint4 z = make_uint4(0, 0, 0, 0);
-            uint4 *v4 = reinterpret_cast<uint4 *>(visited);
-            const uint32_t n4 = v.vis_words >> 2;
-            for (uint32_t i = (uint32_t)lane; i < n4; i += 64) v4[i] = z;
-            for (uint32_t i = (n4 << 2) + (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores land before the first atomicOr
-        }
+        vis.begin_query();
         // query -> LDS
         float qnorm = 1.f;
         if (PREC == KDB_PREC_I8) {
@@ -94,8 +104,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         bool failed = false;
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
-            uint32_t n_marks = 0;
-            search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, l, 1u, qnorm, true, n_marks, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, vis, allow, ep, l, 1u, qnorm, ctr);
             const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
@@ -104,23 +113,10 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
                 b.get((uint32_t)best, bd_, bf_);
                 ep = bf_ & KDB_ID_MASK;
             }
-            // un-mark what this layer marked (the reference clears the whole bitset per call)
-            if (n_marks <= KDB_UP_MARK_CAP) {
-                for (uint32_t i = (uint32_t)lane; i < n_marks; i += 64) {
-                    const uint32_t id = s.marks[i];
-                    atomicAnd(&visited[id >> 5], ~(1u << (id & 31)));
-                }
-            } else {
-                for (uint32_t i = (uint32_t)lane; i < v.vis_words; i += 64) visited[i] = 0u;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __threadfence_block();
-            wave_lds_fence();
         }
         uint32_t nout = 0;
         if (!failed) {
-            uint32_t dummy = 0;
-            search_layer<PREC, METRIC, NCH>(v, s, b, visited, allow, ep, 0, ef, qnorm, false, dummy, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, vis, allow, ep, 0, ef, qnorm, ctr);
             // results = non traversal-only entries, ascending (:2596-2610), first k
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
                                    PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
@@ -321,37 +317,45 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 
 template <int PREC, int METRIC, int NCH, int BS>
 static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
-                           uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
-                           float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
-                           hipStream_t s) {
+                            uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                            float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
+                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
     const uint32_t beam_cap = ((eff + 64 + 1) + 63) / 64 * 64;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8 + KDB_UP_MARK_CAP * 4;
+    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8;
+    // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
+    // the HBM bitset alone for large ef
+    const uint32_t hsize = (BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
+    const size_t lds = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
     if (lds > 160 * 1024) {
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
         return KDB_ERR_UNSUPPORTED;
     }
-    auto kern = hnsw_search_kernel<PREC, METRIC, NCH, BS>;
-    if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipDeviceProp_t prop;
     KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
-    int per_cu = occupancy_blocks(kern, 64, lds);
-    uint32_t grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-    if (grid > B) grid = B;
-    if (grid == 0) return KDB_OK;
-    int rc = kdb_ensure_visited(idx, grid);
-    if (rc) return rc;
-    KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
-    unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
-    KDB_HIP(hipMemsetAsync(d_ctr, 0, 16, s));
-    KDB_HIP(hipEventRecord(idx->ev0, s));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, B, k, eff, d_allow, entry, beam_cap,
-                       idx->d_visited, idx->d_work, d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist,
-                       d_tr_nhops);
-    KDB_HIP(hipGetLastError());
-    KDB_HIP(hipEventRecord(idx->ev1, s));
-    return KDB_OK;
+    const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
+    auto launch = [&](auto kern, uint32_t vis_size) -> int {
+        if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, 64, lds);
+        if (grid > B) grid = B;
+        if (grid == 0) return KDB_OK;
+        int rc = kdb_ensure_visited(idx, grid);
+        if (rc) return rc;
+        unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
+        KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
+        KDB_HIP(hipMemsetAsync(d_ctr, 0, 16, s));
+        KDB_HIP(hipEventRecord(idx->ev0, s));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, B, k, eff, d_allow, entry, beam_cap, vis_size,
+                           idx->d_visited, idx->d_work, d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
+        KDB_HIP(hipGetLastError());
+        KDB_HIP(hipEventRecord(idx->ev1, s));
+        return KDB_OK;
+    };
+    if constexpr (BS == 2 || BS == 4) {
+        if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
+    }
+    return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 0>, 0u);
 }
 
 template <int PREC, int METRIC, int NCH>
@@ -398,7 +402,8 @@ template <int PREC, int METRIC>
 static int launch_distance_t(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, const uint32_t *d_ids,
                              uint32_t C, float *d_out, hipStream_t s) {
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds = qb + 64 * 8;
+    size_t lds = qb + 64 * 8;
+    if (const char *e = getenv("KDB_TILE_LDS")) lds = (size_t)atoi(e); // occupancy experiment
     const uint32_t chunks = (C + 31) / 32;
     hipLaunchKernelGGL((distance_tile_kernel<PREC, METRIC>), dim3(B * chunks), dim3(64), lds, s, v, d_q, d_qnorm, B, d_ids, C, d_out);
     KDB_HIP(hipGetLastError());

@@ -12,8 +12,14 @@ X = torch.randn((a.n, a.dim), device=dev); X /= X.norm(dim=1, keepdim=True)
 idx = K.HipIndex(a.dim, K.COSINE, K.F32, 16, 200, capacity=a.n)
 idx.upload_rows(X, 1); idx.set_count(a.n)
 Q = torch.randn((a.B, a.dim), device=dev)
-for C in (32, 64, a.C):
-    ids = torch.randint(1, a.n + 1, (a.B, C), device=dev, dtype=torch.int32)
+perm = (torch.randperm(a.n, device=dev) + 1).to(torch.int32)
+for C in (32, 64, a.C, -122):
+    if C < 0:   # every row of the corpus exactly once (no cache reuse): B x C = 8192 x 122 < n
+        C = -C
+        ids = perm[: a.B * C].reshape(a.B, C).contiguous()
+        print("unique rows:", end=" ")
+    else:
+        ids = torch.randint(1, a.n + 1, (a.B, C), device=dev, dtype=torch.int32)
     out = torch.zeros((a.B, C), device=dev)
     for _ in range(3):
         idx.distance_batch_dev(Q, ids, out, prepared=True)
