@@ -49,6 +49,18 @@ def gen_corpus(n, dim, law, seed, dev, centers=None):
     return x.contiguous()
 
 
+def traffic_from_profile(n, dim, ef, B):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
+    cannot be run from inside the timed process); only reported when the profiled workload is this one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        if t["workload"] == f"{n}x{dim} clustered ef={ef} batch {B}":
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def recall_at_k(ids, gt, k):
     hit = 0
     for a, b in zip(ids, gt):
@@ -69,7 +81,7 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef with recall@k >= --recall")
     ap.add_argument("--recall", type=float, default=0.95)
     ap.add_argument("--efc", type=int, default=200)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all hardware threads")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
@@ -206,7 +218,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic_from_profile(n, dim, ef, B),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "n_dist_per_query": round(float(np.mean(ndist)) / B, 1),
@@ -270,13 +282,16 @@ def cpu_baseline(idx, Q, k, ef, n, dim, a):
     rate, threads = best
     log(f"[bench] cpu baseline: graph+rows on host in {time.time() - t_host:.1f}s, quota {quota} cpus, {threads} threads")
     sample = int(min(len(q), max(256, rate * a.cpu_seconds)))
+    reps = int(max(1, min(64, round(rate * a.cpu_seconds / sample))))  # repeat the sample to ~cpu_seconds of work
     t0 = time.perf_counter()
-    ids, dist, cnt, (nd, nh) = orc.search_many_threads(q[:sample], k, ef, threads)
+    for _ in range(reps):
+        ids, dist, cnt, (nd, nh) = orc.search_many_threads(q[:sample], k, ef, threads)
     tm = time.perf_counter() - t0
+    sample_total = sample * reps
     return {
-        "value": round(sample / tm, 1), "unit": "queries/s", "cores": threads, "cpu_quota": quota, "host_cpus": ncpu,
+        "value": round(sample_total / tm, 1), "unit": "queries/s", "cores": threads, "cpu_quota": quota, "host_cpus": ncpu,
         "kind": "port",
-        "sample": f"{sample} of the {len(q)} timed queries, same graph/rows/ef={ef}, C restatement of the reference "
+        "sample": f"{sample} of the {len(q)} timed queries x {reps} passes, same graph/rows/ef={ef}, C restatement of the reference "
                   f"algorithm (oracle/kdb_oracle.c, AVX2 -tags-rust arithmetic), one query per thread on {threads} threads, "
                   f"{tm:.1f}s",
         "single_thread_qps": round(qps1, 1),

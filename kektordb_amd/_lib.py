@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("KDB_LIB") or os.path.join(_HERE, "lib", "libkektor_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libkektor_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol declared in include/kektor_hip.h (tests check the .so exports all of them)

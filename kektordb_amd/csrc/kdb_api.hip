@@ -12,7 +12,6 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
-#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 

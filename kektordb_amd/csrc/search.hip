@@ -190,59 +190,100 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     }
 }
 
-// Query preparation (searchInternal Phase 0, hnsw_index.go:404-434): one thread per query so the
-// normalisation reproduces normalize() (:3034-3045) exactly: sequential f32 sum of squares,
-// f64 sqrt, f32 reciprocal, f32 multiply.  Output rows are padded to `ld` with zeros.
-__global__ void prep_queries_kernel(KdbView v, const float *__restrict__ in, uint32_t B, void *out, float *qnorm_out,
-                                    int normalize) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float *q = in + (size_t)b * v.dim;
+// Query preparation (searchInternal Phase 0, hnsw_index.go:404-434).  The normalisation must reproduce
+// normalize() (:3034-3045) exactly -- sequential f32 sum of squares, f64 sqrt, f32 reciprocal, f32
+// multiply -- so one lane walks each query in order; a 64-thread block owns PQ = 16 queries and moves
+// them through LDS in [16 queries x 64 dims] tiles so that global reads and writes are coalesced.
+// Output rows are padded to `ld` with zeros.
+constexpr uint32_t PQ = 16;
+__global__ void __launch_bounds__(64)
+prep_queries_kernel(KdbView v, const float *__restrict__ in, uint32_t B, void *out, float *qnorm_out,
+                    int normalize) {
+    __shared__ float tile[PQ][65];
+    const uint32_t t = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * PQ;
+    const uint32_t b = b0 + t;
+    const uint32_t nq = B - b0 < PQ ? B - b0 : PQ;
     float inv = 1.f;
     bool scale = false;
     if (normalize && v.metric == KDB_METRIC_COSINE) {
         float nsq = 0.f;
-        for (uint32_t i = 0; i < v.dim; i++) {
-            float x = q[i];
-            float sq = x * x;
-            nsq = nsq + sq;
+        for (uint32_t c0 = 0; c0 < v.dim; c0 += 64) {
+            float x[PQ];
+#pragma unroll
+            for (uint32_t r = 0; r < PQ; r++) // row r of the tile: 64 consecutive dims of query b0+r
+                x[r] = (r < nq && c0 + t < v.dim) ? in[(size_t)(b0 + r) * v.dim + c0 + t] : 0.f;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < PQ; r++) tile[r][t] = x[r];
+            __syncthreads();
+            const uint32_t w = v.dim - c0 < 64u ? v.dim - c0 : 64u;
+            if (t < nq)
+                for (uint32_t i = 0; i < w; i++) {
+                    const float y = tile[t][i];
+                    const float sq = y * y;
+                    nsq = nsq + sq;
+                }
         }
-        if (nsq > 0.f) {
+        if (t < nq && nsq > 0.f) {
             inv = 1.0f / (float)sqrt((double)nsq);
             scale = true;
         }
     }
-    if (v.precision == KDB_PREC_F32) {
-        float *o = reinterpret_cast<float *>(out) + (size_t)b * v.ld;
-        for (uint32_t i = 0; i < v.dim; i++) o[i] = scale ? q[i] * inv : q[i];
-        for (uint32_t i = v.dim; i < v.ld; i++) o[i] = 0.f;
-    } else if (v.precision == KDB_PREC_F16) {
-        float *o = reinterpret_cast<float *>(out) + (size_t)b * v.ld;
-        for (uint32_t i = 0; i < v.dim; i++) {
-            float x = scale ? q[i] * inv : q[i];
-            _Float16 h = (_Float16)x; // RNE, as float16.Fromfloat32 (hnsw_index.go:425)
-            o[i] = (float)h;
+    // every lane needs the scale factor of the query whose row it writes: share through LDS
+    __shared__ float s_inv[PQ];
+    __shared__ int s_scale[PQ];
+    if (t < PQ) {
+        s_inv[t] = inv;
+        s_scale[t] = scale ? 1 : 0;
+    }
+    __syncthreads();
+    const uint32_t i8row = (v.ld + 15) / 16 * 16;
+    if (v.precision != KDB_PREC_I8) { // elementwise: scale (and f16 round trip) with coalesced reads/writes
+        for (uint32_t c0 = 0; c0 < v.ld; c0 += 64) {
+#pragma unroll
+            for (uint32_t r = 0; r < PQ; r++) {
+                if (r >= nq || c0 + t >= v.ld) continue;
+                float x = c0 + t < v.dim ? in[(size_t)(b0 + r) * v.dim + c0 + t] : 0.f;
+                if (s_scale[r]) x = x * s_inv[r];
+                if (v.precision == KDB_PREC_F16) {
+                    const _Float16 h = (_Float16)x; // RNE, as float16.Fromfloat32 (hnsw_index.go:425)
+                    x = (float)h;
+                }
+                reinterpret_cast<float *>(out)[(size_t)(b0 + r) * v.ld + c0 + t] = x;
+            }
         }
-        for (uint32_t i = v.dim; i < v.ld; i++) o[i] = 0.f;
-    } else {
-        // Quantizer.Quantize (quantizer.go:150-176) then the query norm (:2411-2418)
-        int8_t *o = reinterpret_cast<int8_t *>(out) + (size_t)b * ((v.ld + 15) / 16 * 16);
-        long long nsum = 0;
-        for (uint32_t i = 0; i < v.dim; i++) {
-            float x = scale ? q[i] * inv : q[i];
+        return;
+    }
+    // int8: Quantizer.Quantize (quantizer.go:150-176) is elementwise too; the query norm (:2411-2418) is an
+    // exact integer sum, accumulated per query by one lane
+    long long nsum = 0;
+    for (uint32_t c0 = 0; c0 < i8row; c0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < PQ; r++) {
             int8_t qv = 0;
-            if (v.q_absmax != 0.f) {
-                float r = x / v.q_absmax;
-                float sc = r * 127.0f;
+            if (r < nq && c0 + t < v.dim && v.q_absmax != 0.f) {
+                float x = in[(size_t)(b0 + r) * v.dim + c0 + t];
+                if (s_scale[r]) x = x * s_inv[r];
+                const float r_ = x / v.q_absmax;
+                float sc = r_ * 127.0f;
                 if (sc > 127.0f) sc = 127.0f;
                 else if (sc < -127.0f) sc = -127.0f;
                 qv = (int8_t)round((double)sc);
             }
-            o[i] = qv;
-            nsum += (long long)qv * (long long)qv;
+            if (r < nq && c0 + t < i8row) reinterpret_cast<int8_t *>(out)[(size_t)(b0 + r) * i8row + c0 + t] = qv;
+            tile[r][t] = (float)qv;
         }
-        for (uint32_t i = v.dim; i < (v.ld + 15) / 16 * 16; i++) o[i] = 0;
-        float qn = (float)sqrt((double)nsum);
+        __syncthreads();
+        if (t < nq)
+            for (uint32_t i = 0; i < 64; i++) {
+                const long long q_ = (long long)tile[t][i];
+                nsum += q_ * q_;
+            }
+    }
+    if (t < nq) {
+        const float qn = (float)sqrt((double)nsum);
         qnorm_out[b] = qn == 0.f ? 1.f : qn;
     }
 }
@@ -292,7 +333,7 @@ int occupancy_blocks(K kern, int threads, size_t lds) {
 int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, void *d_out, float *d_qnorm,
                             int normalize, hipStream_t s) {
     if (B == 0) return KDB_OK;
-    hipLaunchKernelGGL(prep_queries_kernel, dim3((B + 63) / 64), dim3(64), 0, s, v, d_in, B, d_out, d_qnorm, normalize);
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((B + PQ - 1) / PQ), dim3(64), 0, s, v, d_in, B, d_out, d_qnorm, normalize);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }
@@ -402,8 +443,7 @@ template <int PREC, int METRIC>
 static int launch_distance_t(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, const uint32_t *d_ids,
                              uint32_t C, float *d_out, hipStream_t s) {
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    size_t lds = qb + 64 * 8;
-    if (const char *e = getenv("KDB_TILE_LDS")) lds = (size_t)atoi(e); // occupancy experiment
+    const size_t lds = qb + 64 * 8;
     const uint32_t chunks = (C + 31) / 32;
     hipLaunchKernelGGL((distance_tile_kernel<PREC, METRIC>), dim3(B * chunks), dim3(64), lds, s, v, d_q, d_qnorm, B, d_ids, C, d_out);
     KDB_HIP(hipGetLastError());
