@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="rows per GPU shard")
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="rows per GPU shard")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8192, help="queries per step")
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all hardware threads")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL) or gloo (test rigs: several ranks on one GPU)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,12 +92,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         log(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    ngpu = torch.cuda.device_count()
+    local_rank = local_rank % max(ngpu, 1) if a.backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(a.backend)
 
     import kektordb_amd as K
     from kektordb_amd.shard import ShardedSearch
@@ -171,7 +177,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     recall = recall_at_k(out_ids.cpu().numpy().view(np.uint32), gt, k)

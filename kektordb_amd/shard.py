@@ -96,10 +96,19 @@ class ShardedSearch:
                 idx.search_batch_dev(d_queries, k, ef, *tgt, d_allow, stream=raw)
             if self.world == 1:
                 return
-            # the one exchange step: all-gather of per-shard top-k over xGMI
-            dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
-            dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
-            dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
+            # the one exchange step: all-gather of per-shard top-k (RCCL over xGMI)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
+                dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
+                dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
+            else:
+                # test rigs without RCCL (several ranks sharing one GPU under gloo): same exchange staged
+                # through host memory; everything else on this path is identical
+                for g_t, l_t in ((g_ids, l_ids), (g_dist, l_dist), (g_cnt, l_cnt)):
+                    h = l_t.cpu()
+                    parts = [torch.zeros_like(h) for _ in range(self.world)]
+                    dist.all_gather(parts, h, group=self.group)
+                    g_t.copy_(torch.stack(parts).to(dev))
             if self._dev_bases is None:
                 self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
             idx.merge_topk_dev(self.world, B, k, g_ids, g_dist, g_cnt, self._dev_bases, out_ids, out_dist, out_cnt,
