@@ -74,6 +74,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     off += (size_t)v.ld * 4;
     s.beam_d = nullptr;
     s.beam_id = nullptr;
+    s.beam_cap = 0;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;

@@ -21,6 +21,7 @@ struct WaveLds {
     uint32_t *nb_id;   // [64]
     float *nb_d;       // [64]
     uint32_t *marks;   // [KDB_UP_MARK_CAP]
+    uint32_t beam_cap; // entries in beam_d / beam_id
 };
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
@@ -279,17 +280,19 @@ struct RegBeam {
 struct LdsBeam {
     float *bd;
     uint32_t *bi;
+    uint32_t cap;
     uint32_t count, n_res, n_nr, scan_from, nr_max;
     float worst;
 
     __device__ __forceinline__ void bind(const WaveLds &s) {
         bd = s.beam_d;
         bi = s.beam_id;
+        cap = s.beam_cap;
     }
-    __device__ __forceinline__ void reset(uint32_t) {
+    __device__ __forceinline__ void reset(uint32_t ef) {
         count = n_res = n_nr = scan_from = 0;
         worst = INFINITY;
-        nr_max = 63;
+        nr_max = cap > ef + 2 ? cap - ef - 2 : 0; // traversal-only entries kept (the launcher sizes cap ~ 2*ef)
     }
     __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const {
         dd = unif(bd[idx]);

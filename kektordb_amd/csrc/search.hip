@@ -56,6 +56,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
     s.marks = reinterpret_cast<uint32_t *>(smem + off); // VIS=0: un-mark list; VIS=1: the hash table
+    s.beam_cap = beam_cap;
 
     const int lane = kdb_lane();
     unsigned long long tot_dist = 0, tot_hops = 0;
@@ -362,7 +363,8 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
                             float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                             hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
-    const uint32_t beam_cap = ((eff + 64 + 1) + 63) / 64 * 64;
+    // LDS beam (BS == 0): room for ef results plus as many traversal-only (deleted) entries
+    const uint32_t beam_cap = ((2 * eff + 66) + 63) / 64 * 64;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
     const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8;
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,

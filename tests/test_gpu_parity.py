@@ -356,3 +356,25 @@ def test_sharded_search_two_ranks_one_gpu(tmp_path):
     rec = np.mean([len(set(r["ids"][b]) & set(exact[b])) / k for b in range(96)])
     assert rec > 0.9, rec
     assert r["ids"].max() > 3000 and r["ids"].min() >= 1   # results come from both id ranges
+
+
+@pytest.mark.parametrize("ef", [120, 250, 300, 400, 700])
+def test_search_beam_and_visited_variants(oracle, hip, ef):
+    """every beam storage (register slots 2/4/6, LDS beam) and visited-set path (LDS hash 2048/4096, migration
+    to the HBM bitset, bitset only) returns exactly the oracle's results and counters"""
+    O = oracle
+    n, dim = 6000, 32
+    X = make_corpus(n, dim, "uniform", seed=61)
+    deleted = list(range(9, n, 11))
+    orc, idx = build_pair(O, hip, X, 0, efc=60, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(12, dim, "uniform", seed=62)
+    k = 20
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, trace=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = orc.search(Q[b], k, ef=ef, counters=True)
+        c = int(cnt[b])
+        assert c == len(oi)
+        assert np.array_equal(ids[b, :c], oi), (ef, b)
+        assert np.array_equal(dist[b, :c].astype(np.float64), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
