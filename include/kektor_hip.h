@@ -16,6 +16,7 @@
  *                           batched: B queries x C gathered candidate rows per call
  *   kdb_index_upload_rows   Node.vec slices into mmap.VectorArena (pkg/core/hnsw/hnsw_index.go:602-633,
  *                           pkg/storage/mmap/arena.go:378-447): same dense row-major row layout
+ *   kdb_index_upload_arena  the arena files themselves (pkg/storage/mmap/arena.go:14-23,90-95,335-342,403-404)
  *   kdb_index_upload_graph  Node.Connections (pkg/core/hnsw/hnsw_node.go:13-68) as exported by
  *                           SnapshotData (hnsw_index.go:3064): per-level adjacency, entry point, maxLevel
  *   kdb_index_mark_deleted  Node.Deleted soft delete (hnsw_index.go:2303)
@@ -133,6 +134,15 @@ KDB_API int kdb_index_upload_norms(kdb_index *idx, uint32_t first_id, uint32_t n
 KDB_API int kdb_index_set_quantizer(kdb_index *idx, float abs_max);
 KDB_API int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g);
 KDB_API int kdb_index_mark_deleted(kdb_index *idx, const uint32_t *ids, uint32_t n);
+/* Populate rows 1..count straight from a KektorDB data directory: the arena_%04d.bin files of
+ * pkg/storage/mmap/arena.go (64 MiB chunks, 64-byte header {LE u32 magic 0x4B414F4E, version 1, dim,
+ * u8 precision}, rows dense at 64 + (slot % vecsPerChunk)*vectorSize).  slot_table[id] = physical slot
+ * of internal id (ArenaState.SlotTable, arena.go:252-270; 0xFFFFFFFF = unallocated -> zero row), or
+ * NULL for the identity id -> id-1.  kdb_arena_read_rows is the host-only half (no GPU needed): it
+ * gathers rows first_id..first_id+n-1 into a dense buffer.                                          */
+KDB_API int kdb_index_upload_arena(kdb_index *idx, const char *dir, const uint32_t *slot_table, uint32_t count);
+KDB_API int kdb_arena_read_rows(const char *dir, uint32_t dim, uint32_t precision, const uint32_t *slot_table,
+                        uint32_t first_id, uint32_t n, void *out_rows);
 /* Rows without a graph (flat scan only): declare ids 1..count present.                            */
 KDB_API int kdb_index_set_count(kdb_index *idx, uint32_t count);
 

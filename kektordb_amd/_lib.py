@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # every symbol declared in include/kektor_hip.h (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "kdb_abi_version", "kdb_hip_device_count", "kdb_last_error", "kdb_index_create", "kdb_index_destroy",
-    "kdb_index_upload_rows", "kdb_index_upload_rows_dev", "kdb_index_upload_norms", "kdb_index_set_quantizer",
+    "kdb_index_upload_rows", "kdb_index_upload_rows_dev", "kdb_index_upload_arena", "kdb_arena_read_rows", "kdb_index_upload_norms", "kdb_index_set_quantizer",
     "kdb_index_upload_graph", "kdb_index_mark_deleted", "kdb_index_set_count", "kdb_index_graph_info",
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
@@ -86,6 +86,8 @@ def load():
     L.kdb_index_destroy.restype = None
     L.kdb_index_upload_rows.argtypes = [vp, u32, u32, vp]
     L.kdb_index_upload_rows_dev.argtypes = [vp, u32, u32, vp]
+    L.kdb_index_upload_arena.argtypes = [vp, C.c_char_p, vp, u32]
+    L.kdb_arena_read_rows.argtypes = [C.c_char_p, u32, u32, vp, u32, u32, vp]
     L.kdb_index_upload_norms.argtypes = [vp, u32, u32, vp]
     L.kdb_index_set_quantizer.argtypes = [vp, C.c_float]
     L.kdb_index_upload_graph.argtypes = [vp, C.POINTER(GraphView)]

@@ -92,6 +92,11 @@ class HipIndex:
         assert a.ndim == 2 and a.shape[1] == self.dim
         check(self.L.kdb_index_upload_rows(self.h, first_id, a.shape[0], _ptr(a)), "upload_rows")
 
+    def upload_arena(self, arena_dir: str, count: int, slot_table=None):
+        """rows 1..count from the reference's arena files (pkg/storage/mmap/arena.go layout)."""
+        st = None if slot_table is None else np.ascontiguousarray(slot_table, dtype=np.uint32)
+        check(self.L.kdb_index_upload_arena(self.h, arena_dir.encode(), _ptr(st), int(count)), "upload_arena")
+
     def upload_norms(self, norms, first_id: int = 1):
         a = np.ascontiguousarray(norms, dtype=np.float32)
         check(self.L.kdb_index_upload_norms(self.h, first_id, a.shape[0], _ptr(a)), "upload_norms")
@@ -286,6 +291,15 @@ def merge_topk(metric: int, ids, dist, count, k: int, id_base=None, precision: i
     check(L.kdb_merge_topk(metric, precision, G, B, k, _ptr(ids), _ptr(dist), _ptr(count), _ptr(base), _ptr(o_ids),
                            _ptr(o_dist), _ptr(o_cnt)), "kdb_merge_topk")
     return o_ids, o_dist, o_cnt
+
+
+def arena_read_rows(arena_dir: str, dim: int, precision: int, first_id: int, n: int, slot_table=None) -> np.ndarray:
+    """host-only reader of the reference's arena files (kdb_arena_read_rows)."""
+    L = _lib.load()
+    out = np.zeros((n, dim), dtype=_ELEM[precision])
+    st = None if slot_table is None else np.ascontiguousarray(slot_table, dtype=np.uint32)
+    check(L.kdb_arena_read_rows(arena_dir.encode(), dim, precision, _ptr(st), first_id, n, _ptr(out)), "arena_read_rows")
+    return out
 
 
 def dense_bitset(ids: Sequence[int], count: int) -> np.ndarray:
