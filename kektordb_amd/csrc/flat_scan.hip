@@ -24,7 +24,8 @@ constexpr int FS_TR = 128;          // rows per tile
 constexpr int FS_TQ = 128;          // queries per tile
 constexpr int FS_BK = 32;           // K slab (floats) per stage = 128 B per row
 constexpr int FS_LDS_STRIDE = 40;   // floats per LDS row (160 B)
-constexpr int FS_QCAP = 2048;       // survivor queue entries
+constexpr int FS_QPER = 16;         // survivor slots per query per round (per-query mini queues in LDS)
+constexpr int FS_LDS_KL = 16;       // running top-k lists live in LDS up to this length, else in HBM scratch
 constexpr uint32_t FS_MAX_MERGE = 8192;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,12 +51,13 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lds_a = reinterpret_cast<float *>(smem);                       // [128][40]
     float *lds_b = lds_a + FS_TR * FS_LDS_STRIDE;                         // [128][40]
-    float *tau = lds_b + FS_TQ * FS_LDS_STRIDE;                           // [128]
-    uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FS_TQ);         // [128] id of the current worst
-    float *q_key = reinterpret_cast<float *>(tau_id + FS_TQ);             // [QCAP]
-    uint32_t *q_row = reinterpret_cast<uint32_t *>(q_key + FS_QCAP);      // [QCAP]
-    uint32_t *q_q = q_row + FS_QCAP;                                      // [QCAP]
-    uint32_t *q_cnt = q_q + FS_QCAP;                                      // [4]
+    float *tau = lds_b + FS_TQ * FS_LDS_STRIDE;                           // [128] current k-th best per query
+    uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FS_TQ);         // [128] its id
+    uint32_t *q_cnt = tau_id + FS_TQ;                                     // [128] survivors queued this round
+    float *q_key = reinterpret_cast<float *>(q_cnt + FS_TQ);              // [128][FS_QPER]
+    uint32_t *q_row = reinterpret_cast<uint32_t *>(q_key + FS_TQ * FS_QPER); // [128][FS_QPER]
+    float *l_key = reinterpret_cast<float *>(q_row + FS_TQ * FS_QPER);    // [128][kl] when kl <= FS_LDS_KL
+    uint32_t *l_id = reinterpret_cast<uint32_t *>(l_key + FS_TQ * FS_LDS_KL);
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -76,16 +78,17 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
 
     // owner state: thread t < 128 owns query q0+t
     const size_t list_base = ((size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid) * p.kl;
-    float *my_key = p.part_key + list_base;
-    uint32_t *my_id = p.part_id + list_base;
+    const bool lds_lists = p.kl <= (uint32_t)FS_LDS_KL;
+    float *my_key = lds_lists ? l_key + (size_t)tid * p.kl : p.part_key + list_base;
+    uint32_t *my_id = lds_lists ? l_id + (size_t)tid * p.kl : p.part_id + list_base;
     uint32_t my_cnt = 0, my_maxpos = 0;
     float my_max = INFINITY;
     uint32_t my_maxid = 0xffffffffu;
     if (tid < FS_TQ) {
         tau[tid] = INFINITY;
         tau_id[tid] = 0xffffffffu;
+        q_cnt[tid] = 0;
     }
-    if (tid == 0) q_cnt[0] = 0;
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint32_t nslab = v.ld / FS_BK + ((v.ld % FS_BK) ? 1u : 0u); // ld is a multiple of 16; last slab may be half
@@ -194,26 +197,24 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                             pend[a] &= ~bit; // cannot enter the list any more (tau only tightens)
                             continue;
                         }
-                        const uint32_t slot = atomicAdd(&q_cnt[0], 1u);
-                        if (slot < (uint32_t)FS_QCAP) {
-                            q_key[slot] = key;
-                            q_row[slot] = rid;
-                            q_q[slot] = (uint32_t)qq;
+                        const uint32_t slot = atomicAdd(&q_cnt[qq], 1u);
+                        if (slot < (uint32_t)FS_QPER) {
+                            q_key[qq * FS_QPER + (int)slot] = key;
+                            q_row[qq * FS_QPER + (int)slot] = rid;
                             pend[a] &= ~bit;
                         } else {
-                            left = true; // queue full: retry next round
+                            left = true; // this query's mini queue is full: retry next round
                         }
                     }
                 }
             }
             __syncthreads();
-            uint32_t nq = q_cnt[0];
-            if (nq > (uint32_t)FS_QCAP) nq = FS_QCAP;
-            if (tid < FS_TQ && nq) { // drain: the owner thread of each query takes its entries
+            if (tid < FS_TQ) { // drain: every owner lane takes ITS OWN queue, all lanes in parallel
+                uint32_t nq = q_cnt[tid];
+                if (nq > (uint32_t)FS_QPER) nq = FS_QPER;
                 for (uint32_t e = 0; e < nq; e++) {
-                    if (q_q[e] != (uint32_t)tid) continue;
-                    const float key = q_key[e];
-                    const uint32_t rid = q_row[e];
+                    const float key = q_key[tid * FS_QPER + (int)e];
+                    const uint32_t rid = q_row[tid * FS_QPER + (int)e];
                     if (my_cnt < p.kl) {
                         my_key[my_cnt] = key;
                         my_id[my_cnt] = rid;
@@ -241,13 +242,19 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     tau[tid] = my_max;
                     tau_id[tid] = my_maxid;
                 }
+                q_cnt[tid] = 0;
             }
-            __syncthreads();
-            if (tid == 0) q_cnt[0] = 0;
             if (!__syncthreads_or(left ? 1 : 0)) break;
         }
     }
-    if (tid < FS_TQ) p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid] = my_cnt;
+    if (tid < FS_TQ) {
+        if (lds_lists)
+            for (uint32_t i = 0; i < my_cnt; i++) {
+                p.part_key[list_base + i] = my_key[i];
+                p.part_id[list_base + i] = my_id[i];
+            }
+        p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid] = my_cnt;
+    }
 }
 
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id) {
@@ -503,7 +510,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
 
-    const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 8 + (size_t)FS_QCAP * 12 + 16;
+    const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
+                       (size_t)FS_TQ * FS_LDS_KL * 8;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
     (void)kdb_stats_begin(idx, 2, B, 0);
