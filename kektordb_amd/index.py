@@ -44,6 +44,14 @@ def _tptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _ready(stream):
+    """Device tensors handed to the library must be complete.  With an explicit HIP stream the caller orders
+    the work; without one the library runs on its own non-blocking stream, so wait for torch's current stream."""
+    if not stream:
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 class HipIndex:
     def __init__(self, dim: int, metric: int = COSINE, precision: int = F32, m: int = 16,
                  ef_construction: int = 200, capacity: int = 1 << 20, device_id: int = 0):
@@ -86,6 +94,7 @@ class HipIndex:
         self._live()
         if hasattr(rows, "data_ptr"):
             assert rows.is_contiguous() and rows.shape[1] == self.dim
+            _ready(None)
             check(self.L.kdb_index_upload_rows_dev(self.h, first_id, rows.shape[0], _tptr(rows)), "upload_rows_dev")
             return
         a = np.ascontiguousarray(rows, dtype=_ELEM[self.precision])
@@ -195,6 +204,7 @@ class HipIndex:
                          stream=None, prepared=False):
         """torch device tensors in, asynchronous on `stream` (a raw hipStream_t int or None)."""
         self._live()
+        _ready(stream)
         B = d_queries.shape[0]
         check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared),
                                           _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
@@ -214,6 +224,7 @@ class HipIndex:
 
     def flat_scan_batch_dev(self, d_queries, k, d_out_ids, d_out_dist, d_out_count, d_allow=None, stream=None):
         self._live()
+        _ready(stream)
         B = d_queries.shape[0]
         check(self.L.kdb_flat_scan_batch_dev(self.h, _tptr(d_queries), B, k, _tptr(d_allow), self._flags(),
                                              _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
@@ -231,6 +242,7 @@ class HipIndex:
         return out
 
     def distance_batch_dev(self, d_queries, d_ids, d_out, stream=None, prepared=False):
+        _ready(stream)
         B, Cn = d_ids.shape
         check(self.L.kdb_distance_batch_dev(self.h, _tptr(d_queries), B, _tptr(d_ids), Cn, self._flags(prepared),
                                             _tptr(d_out), C.c_void_p(stream) if stream else None),

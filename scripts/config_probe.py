@@ -1,0 +1,77 @@
+"""Full-size probes of BASELINE configs 3 and 5 on one MI355X (numbers quoted in DESIGN.md)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import kektordb_amd as K
+from kektordb_amd.index import dense_bitset
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=3)
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--nq", type=int, default=1024)
+ap.add_argument("--hnsw", type=int, default=1)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(3)
+
+def gen_rows(n, dim, normalize, chunk=1_000_000, centers=None):
+    out = torch.empty((n, dim), device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        if centers is None:
+            out[s:e] = torch.randn((e - s, dim), device=dev, generator=g)
+        else:
+            lab = torch.randint(0, centers.shape[0], (e - s,), device=dev, generator=g)
+            out[s:e] = centers[lab] + 0.3 * torch.randn((e - s, dim), device=dev, generator=g)
+        if normalize:
+            out[s:e] /= out[s:e].norm(dim=1, keepdim=True)
+    return out
+
+def timed(f):
+    torch.cuda.synchronize(); t = time.time(); r = f(); torch.cuda.synchronize(); return r, time.time() - t
+
+if a.config == 3:   # 10M x 768 L2 k=100: flat scan vs HNSW (iid N(0,1), not normalised)
+    n, dim, k, B = a.n, 768, 100, a.nq
+    X, tg = timed(lambda: gen_rows(n, dim, False))
+    Q = torch.randn((B, dim), device=dev, generator=g)
+    idx = K.HipIndex(dim, K.L2, K.F32, 16, 200, capacity=n)
+    _, tu = timed(lambda: idx.upload_rows(X, 1)); idx.set_count(n); del X
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev); od = torch.zeros((B, k), device=dev); oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    idx.flat_scan_batch_dev(Q, k, oi, od, oc); idx.sync()
+    _, tf = timed(lambda: (idx.flat_scan_batch_dev(Q, k, oi, od, oc), idx.sync()))
+    c = idx.counters()
+    print(json.dumps({"config": 3, "rows": n, "gen_s": round(tg, 1), "upload_s": round(tu, 1), "flat_scan_ms": round(tf * 1e3, 1), "flat_kernel_ms": round(c["kernel_ms"], 1),
+                      "flat_qps": round(B / tf), "flat_tflops": round(2 * B * n * dim / c["kernel_ms"] / 1e9, 1), "sorted": bool((od[:, 1:] >= od[:, :-1]).all().item())}))
+    if a.hnsw:
+        _, tb = timed(lambda: idx.build(n, batch=16384, ef_construction=200, seed=1))
+        gt = oi.cpu().numpy()
+        for ef in (100, 400, 1600):
+            si = torch.zeros_like(oi); sd = torch.zeros_like(od); sc = torch.zeros_like(oc)
+            idx.search_batch_dev(Q, k, ef, si, sd, sc); idx.sync()
+            _, ts = timed(lambda: (idx.search_batch_dev(Q, k, ef, si, sd, sc), idx.sync()))
+            r = si.cpu().numpy()
+            rec = np.mean([len(set(r[i].tolist()) & set(gt[i].tolist())) / k for i in range(B)])
+            print(json.dumps({"config": 3, "hnsw_build_s": round(tb, 1), "ef": ef, "recall_at_100": round(float(rec), 4), "qps": round(B / ts), "kernel_ms": round(idx.counters()["kernel_ms"], 2)}))
+else:               # 10M x 1536 cosine, clustered, category filter at 1% selectivity -> exact scan over allowed rows
+    n, dim, k, B = a.n, 1536, 10, a.nq
+    cent = torch.randn((4096, dim), device=dev, generator=g)
+    X, tg = timed(lambda: gen_rows(n, dim, True, centers=cent))
+    Q = gen_rows(B, dim, True, centers=cent)
+    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 200, capacity=n)
+    _, tu = timed(lambda: idx.upload_rows(X, 1)); idx.set_count(n)
+    cat = torch.randint(0, 100, (n,), device=dev, generator=g)      # uniform category id in [0,100)
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev); od = torch.zeros((B, k), device=dev); oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    res = []
+    for c_ in range(3):                                              # a few categories; all queries share the filter
+        ids = (torch.nonzero(cat == c_).flatten() + 1).cpu().numpy()
+        ab = torch.from_numpy(dense_bitset(ids, n).view(np.int64)).to(dev)
+        idx.flat_scan_batch_dev(Q, k, oi, od, oc, d_allow=ab); idx.sync()
+        _, tf = timed(lambda: (idx.flat_scan_batch_dev(Q, k, oi, od, oc, d_allow=ab), idx.sync()))
+        got = oi.cpu().numpy()
+        ok = bool(np.isin(got[got > 0], ids).all())
+        # exact check of a few queries against torch over the allowed rows (measurement tool only)
+        sub = X[torch.from_numpy(ids.astype(np.int64) - 1).to(dev)]
+        ref = (Q[:8] @ sub.T).topk(k, dim=1).indices.cpu().numpy()
+        agree = np.mean([len(set(got[i].tolist()) & set(ids[ref[i]].tolist())) / k for i in range(8)])
+        res.append({"category": c_, "allowed": int(ids.size), "ms": round(tf * 1e3, 2), "qps": round(B / tf), "subset_only": ok, "agreement_with_exact": float(agree)})
+    print(json.dumps({"config": 5, "rows": n, "dim": dim, "gen_s": round(tg, 1), "upload_s": round(tu, 1), "filtered_scan": res}))
