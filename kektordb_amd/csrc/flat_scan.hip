@@ -45,6 +45,32 @@ __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint
     return (k1 < k2) || (k1 == k2 && id1 < id2);
 }
 
+// worst entry of an entry-major list (stride FS_TQ): 8 entries per step so that the loads of a list living in
+// HBM scratch are in flight together instead of one L2 round trip per entry
+__device__ __forceinline__ void fs_find_worst(const float *key, const uint32_t *id, uint32_t kl, float &wmax,
+                                              uint32_t &wid, uint32_t &wpos) {
+    wmax = key[0];
+    wid = id[0];
+    wpos = 0;
+    for (uint32_t i0 = 1; i0 < kl; i0 += 8) {
+        float kk[8];
+        uint32_t ii[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + (uint32_t)u < kl ? i0 + (uint32_t)u : 0u;
+            kk[u] = key[(size_t)i * FS_TQ];
+            ii[u] = id[(size_t)i * FS_TQ];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + (uint32_t)u < kl && fs_better(wmax, wid, kk[u], ii[u])) {
+                wmax = kk[u];
+                wid = ii[u];
+                wpos = i0 + (uint32_t)u;
+            }
+    }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(256)
 flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128][ld] prepared*/, FsParams p) {
@@ -77,10 +103,13 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const uint32_t q0 = qtile * FS_TQ;
 
     // owner state: thread t < 128 owns query q0+t
-    const size_t list_base = ((size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid) * p.kl;
+    // running lists are ENTRY-major: entry i of the query owned by lane t sits at [i*128 + t], so the 128
+    // owner lanes touch consecutive words (coalesced in HBM scratch, conflict-free in LDS)
+    const size_t list_base = ((size_t)stripe * p.n_qtiles + qtile) * p.kl * FS_TQ + (uint32_t)tid;
     const bool lds_lists = p.kl <= (uint32_t)FS_LDS_KL;
-    float *my_key = lds_lists ? l_key + (size_t)tid * p.kl : p.part_key + list_base;
-    uint32_t *my_id = lds_lists ? l_id + (size_t)tid * p.kl : p.part_id + list_base;
+    float *my_key = lds_lists ? l_key + tid : p.part_key + list_base;
+    uint32_t *my_id = lds_lists ? l_id + tid : p.part_id + list_base;
+#define LST(i) ((size_t)(i) * FS_TQ)
     uint32_t my_cnt = 0, my_maxpos = 0;
     float my_max = INFINITY;
     uint32_t my_maxid = 0xffffffffu;
@@ -216,26 +245,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     const float key = q_key[tid * FS_QPER + (int)e];
                     const uint32_t rid = q_row[tid * FS_QPER + (int)e];
                     if (my_cnt < p.kl) {
-                        my_key[my_cnt] = key;
-                        my_id[my_cnt] = rid;
+                        my_key[LST(my_cnt)] = key;
+                        my_id[LST(my_cnt)] = rid;
                         my_cnt++;
                         if (my_cnt == p.kl) { // list full: find the worst
-                            my_max = my_key[0]; my_maxid = my_id[0]; my_maxpos = 0;
-                            for (uint32_t i = 1; i < p.kl; i++) {
-                                const float kk = my_key[i];
-                                const uint32_t ii = my_id[i];
-                                if (fs_better(my_max, my_maxid, kk, ii)) { my_max = kk; my_maxid = ii; my_maxpos = i; }
-                            }
+                            fs_find_worst(my_key, my_id, p.kl, my_max, my_maxid, my_maxpos);
                         }
                     } else if (fs_better(key, rid, my_max, my_maxid)) {
-                        my_key[my_maxpos] = key;
-                        my_id[my_maxpos] = rid;
-                        my_max = my_key[0]; my_maxid = my_id[0]; my_maxpos = 0;
-                        for (uint32_t i = 1; i < p.kl; i++) {
-                            const float kk = my_key[i];
-                            const uint32_t ii = my_id[i];
-                            if (fs_better(my_max, my_maxid, kk, ii)) { my_max = kk; my_maxid = ii; my_maxpos = i; }
-                        }
+                        my_key[LST(my_maxpos)] = key;
+                        my_id[LST(my_maxpos)] = rid;
+                        fs_find_worst(my_key, my_id, p.kl, my_max, my_maxid, my_maxpos);
                     }
                 }
                 if (my_cnt == p.kl) {
@@ -250,9 +269,10 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     if (tid < FS_TQ) {
         if (lds_lists)
             for (uint32_t i = 0; i < my_cnt; i++) {
-                p.part_key[list_base + i] = my_key[i];
-                p.part_id[list_base + i] = my_id[i];
+                p.part_key[list_base + LST(i)] = my_key[LST(i)];
+                p.part_id[list_base + LST(i)] = my_id[LST(i)];
             }
+#undef LST
         p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + q0 + (uint32_t)tid] = my_cnt;
     }
 }
@@ -292,8 +312,9 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
         if (tid == 0) { base = total; total += c; }
         __syncthreads();
         base = total - c;
-        const size_t lb = ((size_t)s * qstride + q) * p.kl;
-        for (uint32_t i = (uint32_t)tid; i < c; i += 256) ent[base + i] = fs_pack(p.part_key[lb + i], p.part_id[lb + i]);
+        const size_t lb = ((size_t)s * p.n_qtiles + q / FS_TQ) * p.kl * FS_TQ + (q % FS_TQ); // entry-major lists
+        for (uint32_t i = (uint32_t)tid; i < c; i += 256)
+            ent[base + i] = fs_pack(p.part_key[lb + (size_t)i * FS_TQ], p.part_id[lb + (size_t)i * FS_TQ]);
         __syncthreads();
     }
     const uint32_t n = total;

@@ -716,17 +716,8 @@ extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_
                           });
 }
 
-extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids,
-                                      uint32_t C, uint32_t flags, float *d_out, void *stream) {
-    KDB_CHECK_IDX(idx);
-    if (B == 0 || C == 0) return KDB_OK;
-    if (!d_queries || !d_ids || !d_out) {
-        kdb_set_error("distance_batch: null buffer");
-        return KDB_ERR_INVALID;
-    }
-    std::lock_guard<std::mutex> lk(idx->mu);
-    KDB_HIP(hipSetDevice(idx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+static int distance_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids, uint32_t C,
+                               uint32_t flags, float *d_out, hipStream_t s) {
     KdbView v = kdb_make_view(idx);
     void *d_q = nullptr;
     float *d_qnorm = nullptr;
@@ -740,6 +731,19 @@ extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, ui
     return KDB_OK;
 }
 
+extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids,
+                                      uint32_t C, uint32_t flags, float *d_out, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0 || C == 0) return KDB_OK;
+    if (!d_queries || !d_ids || !d_out) {
+        kdb_set_error("distance_batch: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    return distance_dev_locked(idx, d_queries, B, d_ids, C, flags, d_out, stream ? (hipStream_t)stream : idx->stream);
+}
+
 extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t B, const uint32_t *ids, uint32_t C,
                                   uint32_t flags, float *out) {
     KDB_CHECK_IDX(idx);
@@ -748,23 +752,19 @@ extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t
         kdb_set_error("distance_batch: null buffer");
         return KDB_ERR_INVALID;
     }
-    {
-        std::lock_guard<std::mutex> lk(idx->mu);
-        KDB_HIP(hipSetDevice(idx->device));
-        const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
-        const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
-        int rc = ensure_iobuf(idx, qbytes + 2 * ibytes + 256);
-        if (rc) return rc;
-    }
-    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
+    std::lock_guard<std::mutex> lk(idx->mu); // one lock for staging + launch + read-back
+    KDB_HIP(hipSetDevice(idx->device));
     const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
     const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
+    int rc = ensure_iobuf(idx, qbytes + 2 * ibytes + 256);
+    if (rc) return rc;
+    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
     float *d_q = reinterpret_cast<float *>(p);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + qbytes);
     float *d_out = reinterpret_cast<float *>(p + qbytes + ibytes);
     KDB_HIP(hipMemcpyAsync(d_q, queries, (size_t)B * idx->desc.dim * 4, hipMemcpyHostToDevice, idx->stream));
     KDB_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * C * 4, hipMemcpyHostToDevice, idx->stream));
-    int rc = kdb_distance_batch_dev(idx, d_q, B, d_ids, C, flags, d_out, idx->stream);
+    rc = distance_dev_locked(idx, d_q, B, d_ids, C, flags, d_out, idx->stream);
     if (rc) return rc;
     KDB_HIP(hipMemcpyAsync(out, d_out, (size_t)B * C * 4, hipMemcpyDeviceToHost, idx->stream));
     KDB_HIP(hipStreamSynchronize(idx->stream));
