@@ -71,7 +71,7 @@ __device__ __forceinline__ void fs_find_worst(const float *key, const uint32_t *
     }
 }
 
-template <int METRIC>
+template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
 flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128][ld] prepared*/, FsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -120,6 +120,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     }
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
+    const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: IEEE binary16 bits
     const uint32_t nslab = v.ld / FS_BK + ((v.ld % FS_BK) ? 1u : 0u); // ld is a multiple of 16; last slab may be half
     // staging map: thread t loads float4 #(t%8) of rows t/8 + 32*i (i<4) of both operands
     const int s_r = tid >> 3, s_c = tid & 7;
@@ -144,8 +145,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
             const bool in = col < v.ld;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                ra[i] = in ? *reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (PREC == KDB_PREC_F16) { // half the row bytes; widened to f32 on the way into LDS (exact)
+                    uint2 h = in ? *reinterpret_cast<const uint2 *>(rows16 + (size_t)a_id[i] * v.ld + col) : make_uint2(0u, 0u);
+                    ra[i] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
+                } else {
+                    ra[i] = in ? *reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 rb[i] = in ? *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -290,7 +299,7 @@ __device__ __forceinline__ float fs_unpack_key(unsigned long long x) {
 
 // Merge the per-stripe lists of one query (block = 256 threads), re-score L2 finalists exactly in
 // the wave order, write the first k ascending by (distance, id).
-template <int METRIC>
+template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
 flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t k, uint32_t npow2,
                   uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
@@ -354,8 +363,11 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
             const uint32_t r = base + (uint32_t)g;
             const bool act = r < nf;
             const uint32_t id = act ? (uint32_t)(ent[r] & 0xffffffffu) : 0u;
-            const float *row = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
-            float part = kdb_row_partial_f32<KDB_METRIC_L2>(row, qlds, v.ld, t);
+            float part;
+            if (PREC == KDB_PREC_F16)
+                part = kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
+            else
+                part = kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
             part = kdb_reduce16(part);
             if (act && t == 0) { fin_d[r] = part; fin_id[r] = id; }
         }
@@ -464,8 +476,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                          uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
                          uint32_t *d_out_count, hipStream_t s) {
     (void)d_qnorm;
-    if (v.precision != KDB_PREC_F32) {
-        kdb_set_error("flat scan: only float32 rows are supported in this version");
+    if (v.precision == KDB_PREC_I8) {
+        kdb_set_error("flat scan: int8 rows are not supported in this version (float32 and float16 are)");
         return KDB_ERR_UNSUPPORTED;
     }
     if (k == 0 || k > 128) {
@@ -537,25 +549,30 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t grid = stripes8 * n_qtiles;
     (void)kdb_stats_begin(idx, 2, B, 0);
     KDB_HIP(hipEventRecord(idx->ev0, s));
-    if (v.metric == KDB_METRIC_COSINE) {
-        KDB_HIP(hipFuncSetAttribute((const void *)flat_scan_kernel<KDB_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(flat_scan_kernel<KDB_METRIC_COSINE>, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
-    } else {
-        KDB_HIP(hipFuncSetAttribute((const void *)flat_scan_kernel<KDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(flat_scan_kernel<KDB_METRIC_L2>, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
-    }
+    auto launch_scan = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
+        return KDB_OK;
+    };
+    if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
+    else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (rc) return rc;
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     uint32_t npow2 = 64;
     while (npow2 < n_stripes * kl) npow2 <<= 1;
     const size_t mlds = (size_t)npow2 * 8 + 256 * 8 + (size_t)v.ld * 4 + 16;
-    if (v.metric == KDB_METRIC_COSINE) {
-        KDB_HIP(hipFuncSetAttribute((const void *)flat_merge_kernel<KDB_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(flat_merge_kernel<KDB_METRIC_COSINE>, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids, d_out_dist, d_out_count);
-    } else {
-        KDB_HIP(hipFuncSetAttribute((const void *)flat_merge_kernel<KDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(flat_merge_kernel<KDB_METRIC_L2>, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids, d_out_dist, d_out_count);
-    }
+    auto launch_merge = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids,
+                           d_out_dist, d_out_count);
+        return KDB_OK;
+    };
+    if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
+    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (rc) return rc;
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }

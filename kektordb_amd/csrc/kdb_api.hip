@@ -280,7 +280,7 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
     unsigned char *dst = reinterpret_cast<unsigned char *>(idx->d_rows) + (size_t)first_id * lb;
     if (lb != rb) KDB_HIP(hipMemsetAsync(dst, 0, (size_t)n * lb, idx->stream)); // zero the pad columns
     KDB_HIP(hipMemcpy2DAsync(dst, lb, rows, rb, rb, n, kind, idx->stream));
-    if (idx->desc.precision == KDB_PREC_F32 && idx->desc.metric == KDB_METRIC_L2) {
+    if (idx->desc.precision != KDB_PREC_I8 && idx->desc.metric == KDB_METRIC_L2) { // ||x||^2 for flat-scan ranking
         KdbView v = kdb_make_view(idx);
         int rc = kdb_launch_row_norms(v, idx->d_norms, first_id, n, idx->stream);
         if (rc) return rc;

@@ -309,14 +309,29 @@ __global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32
     const uint32_t r = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (uint32_t)g;
     const bool act = r < n;
     const uint32_t id = act ? first + r : 0u;
-    const float4 *r4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (uint32_t c = (uint32_t)t; c < (v.ld >> 2); c += 16) {
-        float4 x = r4[c];
-        a0 = __builtin_fmaf(x.x, x.x, a0);
-        a1 = __builtin_fmaf(x.y, x.y, a1);
-        a2 = __builtin_fmaf(x.z, x.z, a2);
-        a3 = __builtin_fmaf(x.w, x.w, a3);
+    if (v.precision == KDB_PREC_F16) {
+        const uint2 *r2 = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld);
+        for (uint32_t c = (uint32_t)t; c < (v.ld >> 2); c += 16) {
+            const uint2 h = r2[c];
+            const float x0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu));
+            const float x1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16));
+            const float x2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu));
+            const float x3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16));
+            a0 = __builtin_fmaf(x0, x0, a0);
+            a1 = __builtin_fmaf(x1, x1, a1);
+            a2 = __builtin_fmaf(x2, x2, a2);
+            a3 = __builtin_fmaf(x3, x3, a3);
+        }
+    } else {
+        const float4 *r4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld);
+        for (uint32_t c = (uint32_t)t; c < (v.ld >> 2); c += 16) {
+            float4 x = r4[c];
+            a0 = __builtin_fmaf(x.x, x.x, a0);
+            a1 = __builtin_fmaf(x.y, x.y, a1);
+            a2 = __builtin_fmaf(x.z, x.z, a2);
+            a3 = __builtin_fmaf(x.w, x.w, a3);
+        }
     }
     float p = kdb_reduce16((a0 + a1) + (a2 + a3));
     if (act && t == 0) norms[id] = p;

@@ -244,6 +244,23 @@ def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
     assert np.array_equal(ids2, ids3) and np.array_equal(cnt2, cnt3)
 
 
+def test_flat_scan_f16(oracle, hip):
+    """float16 rows (euclidean only, hnsw_index.go:210-213): MFMA ranking on the widened rows, exact re-score in
+    the f16 wave order -> bit-exact against the oracle"""
+    O = oracle
+    n, dim, k, B = 4000, 96, 10, 40
+    X = make_corpus(n, dim, "normal", seed=71)
+    orc, idx = build_pair(O, hip, X, 0, precision=O.F16, efc=20)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(B, dim, "normal", seed=72)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k)
+        assert int(cnt[b]) == len(oi) == k
+        assert np.array_equal(ids[b], oi), b
+        assert np.array_equal(dist[b].astype(np.float64), od)
+
+
 def test_bruteforce_f64_reference_semantics(oracle, hip):
     # BruteForceIndex (vector_index.go:104-162) scores squared L2 in f64: the f32 GPU scan must agree
     # within the stated tolerance
