@@ -36,6 +36,7 @@ struct FsParams {
     uint32_t rows_per_stripe; // multiple of FS_TR
     uint32_t n_stripes, n_qtiles;
     uint32_t B, kl;           // kl = per-stripe list length
+    uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or 2*kl (buffered mode)
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
     uint32_t *part_id;
     uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
@@ -43,6 +44,44 @@ struct FsParams {
 
 __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint32_t id2) {
     return (k1 < k2) || (k1 == k2 && id1 < id2);
+}
+
+// Buffered mode (lists longer than FS_LDS_KL): owner lanes only APPEND survivors to a 2*kl buffer; when it
+// fills, one wave selects the kl best of the query together: the kl-th smallest packed (ordered key, id) is
+// found by a 64-step bitwise search (per step: <=5 compares per lane + ballot/popcount), then the keepers are
+// compacted to the front.  Returns the new threshold (the kl-th best).  Whole wave, q wave-uniform.
+__device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id);
+__device__ __forceinline__ float fs_unpack_key(unsigned long long x);
+__device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
+    const uint32_t lane = (uint32_t)kdb_lane();
+    constexpr int SLOTS = 5; // cnt <= 2*144 = 288 <= 5*64
+    unsigned long long e[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; u++) {
+        const uint32_t i = lane + 64u * (uint32_t)u;
+        e[u] = i < cnt ? fs_pack(key[(size_t)i * FS_TQ], id[(size_t)i * FS_TQ]) : ~0ull;
+    }
+    unsigned long long T = 0; // smallest T with count(e <= T) >= kl
+    for (int bit = 63; bit >= 0; bit--) {
+        const unsigned long long test = T | ((1ull << bit) - 1ull);
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(e[u] <= test));
+        if (c < kl) T |= 1ull << bit;
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int u = 0; u < SLOTS; u++) { // keepers to the front, buffer order preserved
+        const bool keep = e[u] <= T;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const uint32_t pos = base + kdb_mbcnt(m);
+            key[(size_t)pos * FS_TQ] = fs_unpack_key(e[u]);
+            id[(size_t)pos * FS_TQ] = (uint32_t)(e[u] & 0xffffffffu);
+        }
+        base += (uint32_t)__builtin_popcountll(m);
+    }
+    return T;
 }
 
 // worst entry of an entry-major list (stride FS_TQ): 8 entries per step so that the loads of a list living in
@@ -82,8 +121,11 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     uint32_t *q_cnt = tau_id + FS_TQ;                                     // [128] survivors queued this round
     float *q_key = reinterpret_cast<float *>(q_cnt + FS_TQ);              // [128][FS_QPER]
     uint32_t *q_row = reinterpret_cast<uint32_t *>(q_key + FS_TQ * FS_QPER); // [128][FS_QPER]
-    float *l_key = reinterpret_cast<float *>(q_row + FS_TQ * FS_QPER);    // [128][kl] when kl <= FS_LDS_KL
+    float *l_key = reinterpret_cast<float *>(q_row + FS_TQ * FS_QPER);    // [kl][128] when kl <= FS_LDS_KL
     uint32_t *l_id = reinterpret_cast<uint32_t *>(l_key + FS_TQ * FS_LDS_KL);
+    uint32_t *l_cnt = l_id + FS_TQ * FS_LDS_KL;                           // [128] entries held (buffered mode)
+    uint32_t *need = l_cnt + FS_TQ;                                       // [128] queries whose buffer is full
+    uint32_t *n_need = need + FS_TQ;                                      // [4]
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -105,7 +147,8 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     // owner state: thread t < 128 owns query q0+t
     // running lists are ENTRY-major: entry i of the query owned by lane t sits at [i*128 + t], so the 128
     // owner lanes touch consecutive words (coalesced in HBM scratch, conflict-free in LDS)
-    const size_t list_base = ((size_t)stripe * p.n_qtiles + qtile) * p.kl * FS_TQ + (uint32_t)tid;
+    const size_t blk_base = ((size_t)stripe * p.n_qtiles + qtile) * p.cap * FS_TQ;
+    const size_t list_base = blk_base + (uint32_t)tid;
     const bool lds_lists = p.kl <= (uint32_t)FS_LDS_KL;
     float *my_key = lds_lists ? l_key + tid : p.part_key + list_base;
     uint32_t *my_id = lds_lists ? l_id + tid : p.part_id + list_base;
@@ -117,7 +160,9 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
         tau[tid] = INFINITY;
         tau_id[tid] = 0xffffffffu;
         q_cnt[tid] = 0;
+        l_cnt[tid] = 0;
     }
+    if (tid == 0) n_need[0] = 0;
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: IEEE binary16 bits
@@ -253,6 +298,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 for (uint32_t e = 0; e < nq; e++) {
                     const float key = q_key[tid * FS_QPER + (int)e];
                     const uint32_t rid = q_row[tid * FS_QPER + (int)e];
+                    if (!lds_lists) { // buffered mode: append; a full buffer is compacted by a whole wave below
+                        if (!fs_better(key, rid, tau[tid], tau_id[tid])) continue;
+                        if (my_cnt == p.cap) { // cannot happen: cap - kl >= FS_QPER survivors fit between compactions
+                            continue;
+                        }
+                        my_key[LST(my_cnt)] = key;
+                        my_id[LST(my_cnt)] = rid;
+                        my_cnt++;
+                        continue;
+                    }
                     if (my_cnt < p.kl) {
                         my_key[LST(my_cnt)] = key;
                         my_id[LST(my_cnt)] = rid;
@@ -266,14 +321,46 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                         fs_find_worst(my_key, my_id, p.kl, my_max, my_maxid, my_maxpos);
                     }
                 }
-                if (my_cnt == p.kl) {
+                if (lds_lists && my_cnt == p.kl) {
                     tau[tid] = my_max;
                     tau_id[tid] = my_maxid;
                 }
                 q_cnt[tid] = 0;
+                if (!lds_lists) {
+                    l_cnt[tid] = my_cnt;
+                    if (my_cnt + (uint32_t)FS_QPER > p.cap) need[atomicAdd(&n_need[0], 1u)] = (uint32_t)tid;
+                }
+            }
+            if (!lds_lists) { // cooperative compaction of the full buffers, one query per wave at a time
+                __syncthreads();
+                const uint32_t nn = n_need[0];
+                for (uint32_t w = (uint32_t)wave; w < nn; w += 4) {
+                    const uint32_t qq = need[w];
+                    const unsigned long long T = fs_compact_wave(p.part_key + blk_base + qq, p.part_id + blk_base + qq, l_cnt[qq], p.kl);
+                    if (lane == 0) {
+                        tau[qq] = fs_unpack_key(T);
+                        tau_id[qq] = (uint32_t)(T & 0xffffffffu);
+                        l_cnt[qq] = p.kl;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) n_need[0] = 0;
+                if (tid < FS_TQ) my_cnt = l_cnt[tid];
             }
             if (!__syncthreads_or(left ? 1 : 0)) break;
         }
+    }
+    if (!lds_lists) { // final compaction so that every list handed to the merge kernel holds <= kl entries
+        __syncthreads();
+        for (uint32_t qq = (uint32_t)wave; qq < (uint32_t)FS_TQ; qq += 4) {
+            const uint32_t c = l_cnt[qq];
+            if (c > p.kl) {
+                (void)fs_compact_wave(p.part_key + blk_base + qq, p.part_id + blk_base + qq, c, p.kl);
+                if (lane == 0) l_cnt[qq] = p.kl;
+            }
+        }
+        __syncthreads();
+        if (tid < FS_TQ) my_cnt = l_cnt[tid];
     }
     if (tid < FS_TQ) {
         if (lds_lists)
@@ -321,7 +408,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
         if (tid == 0) { base = total; total += c; }
         __syncthreads();
         base = total - c;
-        const size_t lb = ((size_t)s * p.n_qtiles + q / FS_TQ) * p.kl * FS_TQ + (q % FS_TQ); // entry-major lists
+        const size_t lb = ((size_t)s * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ); // entry-major lists
         for (uint32_t i = (uint32_t)tid; i < c; i += 256)
             ent[base + i] = fs_pack(p.part_key[lb + (size_t)i * FS_TQ], p.part_id[lb + (size_t)i * FS_TQ]);
         __syncthreads();
@@ -499,8 +586,16 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // stripes: enough workgroups to fill the chip twice, at least 8 tiles each, XCD multiple
     uint32_t want = (2048 + n_qtiles - 1) / n_qtiles;
     if (want > stripes_max) want = stripes_max;
+    // two workgroups fit a CU (LDS): when the merge capacity caps the stripe count just above a whole number of
+    // 512-workgroup rounds, round DOWN to whole rounds instead of paying a nearly empty tail round
+    if ((size_t)want * n_qtiles > 512 && (size_t)want * n_qtiles < 2048) {
+        const uint32_t rounds = want * n_qtiles / 512;
+        const uint32_t w2 = rounds * 512 / n_qtiles;
+        if (w2 >= 1) want = w2;
+    }
     const size_t max_part = (size_t)want * n_qtiles * FS_TQ;
-    const size_t part_bytes = max_part * kl * 8 + max_part * 4 + 1024;
+    const uint32_t cap = kl <= (uint32_t)FS_LDS_KL ? kl : 2 * kl; // buffered mode keeps 2*kl per (stripe, query)
+    const size_t part_bytes = max_part * cap * 8 + max_part * 4 + 1024;
     int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + part_bytes + (size_t)n_qtiles * FS_TQ * v.ld * 4 + 4096);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
@@ -538,13 +633,14 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     p.n_qtiles = n_qtiles;
     p.B = B;
     p.kl = kl;
+    p.cap = cap;
     const size_t n_part = (size_t)n_stripes * n_qtiles * FS_TQ;
     p.part_key = reinterpret_cast<float *>(part);
-    p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
-    p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
+    p.part_id = reinterpret_cast<uint32_t *>(part + n_part * cap * 4);
+    p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * cap * 8);
 
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
-                       (size_t)FS_TQ * FS_LDS_KL * 8;
+                       (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 16;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
     (void)kdb_stats_begin(idx, 2, B, 0);
