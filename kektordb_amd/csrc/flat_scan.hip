@@ -17,6 +17,7 @@
 // one stripe run on the same XCD so the stripe's rows are fetched from HBM once and shared in L2.
 #include "kdb_device.cuh"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -26,7 +27,7 @@ constexpr int FS_BK = 32;           // K slab (floats) per stage = 128 B per row
 constexpr int FS_LDS_STRIDE = 40;   // floats per LDS row (160 B)
 constexpr int FS_QPER = 16;         // survivor slots per query per round (per-query mini queues in LDS)
 constexpr int FS_LDS_KL = 16;       // running top-k lists live in LDS up to this length, else in HBM scratch
-constexpr uint32_t FS_MAX_MERGE = 8192;
+constexpr uint32_t FS_MAX_MERGE = 16384; // entries one merge workgroup gathers in LDS (128 KB)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -36,7 +37,7 @@ struct FsParams {
     uint32_t rows_per_stripe; // multiple of FS_TR
     uint32_t n_stripes, n_qtiles;
     uint32_t B, kl;           // kl = per-stripe list length
-    uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or 2*kl (buffered mode)
+    uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
     uint32_t *part_id;
     uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
@@ -46,42 +47,78 @@ __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint
     return (k1 < k2) || (k1 == k2 && id1 < id2);
 }
 
-// Buffered mode (lists longer than FS_LDS_KL): owner lanes only APPEND survivors to a 2*kl buffer; when it
-// fills, one wave selects the kl best of the query together: the kl-th smallest packed (ordered key, id) is
-// found by a 64-step bitwise search (per step: <=5 compares per lane + ballot/popcount), then the keepers are
-// compacted to the front.  Returns the new threshold (the kl-th best).  Whole wave, q wave-uniform.
+// Buffered mode (lists longer than FS_LDS_KL, and the small-batch kernel): survivors are only APPENDED to a
+// buffer; when it fills, one wave selects the kl best of the query together.  The kl-th smallest (ordered key,
+// id) pair is found by a bitwise search with compare + ballot + popcount: 32 steps over the keys, and 32 more
+// over the ids only when several entries share the boundary key.  Keepers are then compacted to the front.
+// Returns the new threshold packed as fs_pack() does.  Whole wave, arguments wave-uniform, cnt <= 320.
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id);
 __device__ __forceinline__ float fs_unpack_key(unsigned long long x);
+template <int STRIDE>
 __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
     const uint32_t lane = (uint32_t)kdb_lane();
-    constexpr int SLOTS = 5; // cnt <= 2*144 = 288 <= 5*64
-    unsigned long long e[SLOTS];
+    constexpr int SLOTS = 5;
+    const uint32_t nslot = (cnt + 63u) >> 6;
+    uint32_t ek[SLOTS], ei[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; u++) {
         const uint32_t i = lane + 64u * (uint32_t)u;
-        e[u] = i < cnt ? fs_pack(key[(size_t)i * FS_TQ], id[(size_t)i * FS_TQ]) : ~0ull;
+        ek[u] = 0xffffffffu;
+        ei[u] = 0xffffffffu;
+        if (i < cnt) {
+            ek[u] = (uint32_t)(fs_pack(key[(size_t)i * STRIDE], 0u) >> 32);
+            ei[u] = id[(size_t)i * STRIDE];
+        }
     }
-    unsigned long long T = 0; // smallest T with count(e <= T) >= kl
-    for (int bit = 63; bit >= 0; bit--) {
-        const unsigned long long test = T | ((1ull << bit) - 1ull);
+    uint32_t Tk = 0; // smallest Tk with count(key <= Tk) >= kl
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t test = Tk | ((1u << bit) - 1u);
         uint32_t c = 0;
 #pragma unroll
-        for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(e[u] <= test));
-        if (c < kl) T |= 1ull << bit;
+        for (int u = 0; u < SLOTS; u++)
+            if ((uint32_t)u < nslot) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
+        if (c < kl) Tk |= 1u << bit;
+    }
+    uint32_t c_lt = 0, c_eq = 0;
+#pragma unroll
+    for (int u = 0; u < SLOTS; u++)
+        if ((uint32_t)u < nslot) {
+            c_lt += (uint32_t)__builtin_popcountll(__ballot(ek[u] < Tk));
+            c_eq += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk));
+        }
+    const uint32_t need = kl - c_lt; // entries with the boundary key to keep (>= 1), smallest ids first
+    uint32_t Ti = 0;                 // smallest Ti with count(key == Tk && id <= Ti) >= need
+    if (c_eq == 1u) { // the usual case: one boundary entry, its id is the threshold id
+#pragma unroll
+        for (int u = 0; u < SLOTS; u++)
+            if ((uint32_t)u < nslot) {
+                const unsigned long long m = __ballot(ek[u] == Tk);
+                if (m) Ti = (uint32_t)__shfl((int)ei[u], __builtin_ctzll(m), 64);
+            }
+    } else {
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t test = Ti | ((1u << bit) - 1u);
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < SLOTS; u++)
+                if ((uint32_t)u < nslot) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk && ei[u] <= test));
+            if (c < need) Ti |= 1u << bit;
+        }
     }
     uint32_t base = 0;
 #pragma unroll
     for (int u = 0; u < SLOTS; u++) { // keepers to the front, buffer order preserved
-        const bool keep = e[u] <= T;
+        if ((uint32_t)u >= nslot) break;
+        const bool keep = ek[u] < Tk || (ek[u] == Tk && ei[u] <= Ti);
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const uint32_t pos = base + kdb_mbcnt(m);
-            key[(size_t)pos * FS_TQ] = fs_unpack_key(e[u]);
-            id[(size_t)pos * FS_TQ] = (uint32_t)(e[u] & 0xffffffffu);
+            key[(size_t)pos * STRIDE] = fs_unpack_key((unsigned long long)ek[u] << 32);
+            id[(size_t)pos * STRIDE] = ei[u];
         }
         base += (uint32_t)__builtin_popcountll(m);
     }
-    return T;
+    return ((unsigned long long)Tk << 32) | Ti;
 }
 
 // worst entry of an entry-major list (stride FS_TQ): 8 entries per step so that the loads of a list living in
@@ -336,7 +373,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 const uint32_t nn = n_need[0];
                 for (uint32_t w = (uint32_t)wave; w < nn; w += 4) {
                     const uint32_t qq = need[w];
-                    const unsigned long long T = fs_compact_wave(p.part_key + blk_base + qq, p.part_id + blk_base + qq, l_cnt[qq], p.kl);
+                    const unsigned long long T = fs_compact_wave<FS_TQ>(p.part_key + blk_base + qq, p.part_id + blk_base + qq, l_cnt[qq], p.kl);
                     if (lane == 0) {
                         tau[qq] = fs_unpack_key(T);
                         tau_id[qq] = (uint32_t)(T & 0xffffffffu);
@@ -355,7 +392,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
         for (uint32_t qq = (uint32_t)wave; qq < (uint32_t)FS_TQ; qq += 4) {
             const uint32_t c = l_cnt[qq];
             if (c > p.kl) {
-                (void)fs_compact_wave(p.part_key + blk_base + qq, p.part_id + blk_base + qq, c, p.kl);
+                (void)fs_compact_wave<FS_TQ>(p.part_key + blk_base + qq, p.part_id + blk_base + qq, c, p.kl);
                 if (lane == 0) l_cnt[qq] = p.kl;
             }
         }
@@ -373,6 +410,214 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small batches (B <= 64): the scan is HBM-bound (2*16 flop per row byte at most), a 128-query tile would
+// spend 8x the MFMA work on padding.  Here a workgroup owns 16 queries (whole, in LDS) and streams its stripe
+// of rows straight from HBM into MFMA A-operand registers: lane (fi, fg) of a wave loads the 16 bytes
+// k = 16s+4fg.. of row fi, so one load instruction covers 16 rows x 64 B and two consecutive steps use the
+// whole 128-byte line; 2 x FSS_CH loads per lane are in flight while the previous chunk is multiplied.
+// Same accumulation order as flat_scan_kernel (k = 16s+4g+j), same keys, same total order => same results.
+// Survivors are appended to per-query LDS buffers with an LDS atomic; buffers are compacted by whole waves.
+constexpr int FSS_TQ = 16;     // queries per workgroup
+constexpr int FSS_CH = 8;      // 16-element K steps per register chunk (128 floats of every row)
+constexpr int FSS_SLACK = 64;  // buffer = kl + one tile of rows + slack entries
+__host__ __device__ inline uint32_t fss_qstride(uint32_t ld) { return ld + ((40u + 64u - (ld & 63u)) & 63u); }
+
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t n_q16, uint32_t cap_s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t S = fss_qstride(v.ld);
+    float *qs = reinterpret_cast<float *>(smem);                              // [16][S]
+    float *b_key = qs + FSS_TQ * S;                                           // [16][cap_s]
+    uint32_t *b_id = reinterpret_cast<uint32_t *>(b_key + FSS_TQ * cap_s);    // [16][cap_s]
+    float *tau = reinterpret_cast<float *>(b_id + FSS_TQ * cap_s);            // [16]
+    uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FSS_TQ);            // [16]
+    uint32_t *cnt = tau_id + FSS_TQ;                                          // [16]
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, local = bid >> 3;
+    const uint32_t stripe = (local / n_q16) * 8u + xcd; // the query groups of one stripe share an XCD (L2)
+    const uint32_t qt = local % n_q16;
+    if (stripe >= p.n_stripes) return;
+    const uint32_t row_begin = stripe * p.rows_per_stripe;
+    uint32_t row_end = row_begin + p.rows_per_stripe;
+    if (row_end > p.n_scan) row_end = p.n_scan;
+    const uint32_t q0 = qt * FSS_TQ;
+    const uint32_t nq = p.B - q0 < (uint32_t)FSS_TQ ? p.B - q0 : (uint32_t)FSS_TQ;
+
+    for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 2); i += 256) {
+        const uint32_t n = i / (v.ld >> 2), c = i % (v.ld >> 2);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < nq) x = *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + n) * v.ld + c * 4u);
+        *reinterpret_cast<float4 *>(qs + n * S + c * 4u) = x;
+    }
+    if (tid < FSS_TQ) {
+        tau[tid] = INFINITY;
+        tau_id[tid] = 0xffffffffu;
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+
+    const float *rows = reinterpret_cast<const float *>(v.rows);
+    const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows);
+    const uint32_t nsteps = v.ld >> 4;
+    // a tile is cut into an EVEN number of register chunks (<= FSS_CH steps each), so that every tile starts
+    // in buffer A and the per-tile side loads below have a fixed place in the pipeline
+    const uint32_t nch = 2u * ((nsteps + 2u * FSS_CH - 1u) / (2u * FSS_CH));
+    const uint32_t cs = (nsteps + nch - 1u) / nch;
+    const uint32_t wrow = (uint32_t)wave * 32u; // this wave's 32 rows of the 128-row tile
+
+    // row ids of the two rows this lane LOADS (fi of each 16-row group); under a filter they come from scan_ids
+    // and are fetched one tile ahead so that the row loads never wait for them
+    uint32_t ld_id[2] = {0u, 0u}, ld_nx[2] = {0u, 0u};
+    auto load_ids = [&](uint32_t (&dst)[2], uint32_t tile) {
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const uint32_t rr = tile + wrow + (uint32_t)(a * 16 + fi);
+            dst[a] = rr < row_end ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
+        }
+    };
+    auto issue = [&](float4 (&dst)[2][FSS_CH], uint32_t ch) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int u = 0; u < FSS_CH; u++) {
+                const uint32_t step = ch * cs + (uint32_t)u;
+                const uint32_t col = step * 16u + (uint32_t)fg * 4u;
+                if ((uint32_t)u < cs && step < nsteps) {
+                    if (PREC == KDB_PREC_F16) {
+                        const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)ld_id[a] * v.ld + col);
+                        dst[a][u] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
+                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
+                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)),
+                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
+                    } else {
+                        dst[a][u] = *reinterpret_cast<const float4 *>(rows + (size_t)ld_id[a] * v.ld + col);
+                    }
+                }
+            }
+    };
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    auto multiply = [&](float4 (&src)[2][FSS_CH], uint32_t ch) {
+#pragma unroll
+        for (int u = 0; u < FSS_CH; u++) {
+            const uint32_t step = ch * cs + (uint32_t)u;
+            if ((uint32_t)u >= cs || step >= nsteps) break;
+            const float4 qf = *reinterpret_cast<const float4 *>(qs + (uint32_t)fi * S + step * 16u + (uint32_t)fg * 4u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float bv = j == 0 ? qf.x : j == 1 ? qf.y : j == 2 ? qf.z : qf.w;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const float av = j == 0 ? src[a][u].x : j == 1 ? src[a][u].y : j == 2 ? src[a][u].z : src[a][u].w;
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // lane holds, per 16-row group a: query fi, rows a*16 + fg*4 + r (r < 4).  Their ids (chunk 0 of the tile) and
+    // squared norms (chunk 1) are fetched while the tile is being multiplied.
+    uint32_t sel_id[8];
+    float sel_nrm[8];
+    auto sel_load_ids = [&](uint32_t tile) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t rr = tile + wrow + (uint32_t)((e >> 2) * 16 + fg * 4 + (e & 3));
+            sel_id[e] = rr < row_end ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
+        }
+    };
+    auto sel_load_norms = [&]() {
+        if (METRIC == KDB_METRIC_L2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) sel_nrm[e] = v.norms[sel_id[e]];
+        }
+    };
+    auto select = [&]() {
+        if ((uint32_t)fi < nq) {
+            const float t_k = tau[fi];
+            const uint32_t t_id = tau_id[fi];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t rid = sel_id[e];
+                if (rid == 0u) continue; // past the end of the stripe
+                const float dotv = acc[e >> 2][e & 3];
+                const float key = METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, sel_nrm[e]);
+                if (!fs_better(key, rid, t_k, t_id)) continue;
+                const uint32_t pos = atomicAdd(&cnt[fi], 1u); // < cap_s: every buffer has room for a whole tile
+                b_key[(uint32_t)fi * cap_s + pos] = key;
+                b_id[(uint32_t)fi * cap_s + pos] = rid;
+            }
+        }
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        kdb_lds_barrier();
+        for (uint32_t q = (uint32_t)wave; q < nq; q += 4) {
+            const uint32_t c = cnt[q];
+            if (c + (uint32_t)FS_TR > cap_s) { // could overflow during the next tile: keep the kl best
+                const unsigned long long T = fs_compact_wave<1>(b_key + q * cap_s, b_id + q * cap_s, c, p.kl);
+                if (lane == 0) {
+                    tau[q] = fs_unpack_key(T);
+                    tau_id[q] = (uint32_t)(T & 0xffffffffu);
+                    cnt[q] = p.kl;
+                }
+            }
+        }
+        kdb_lds_barrier();
+    };
+
+    float4 bufA[2][FSS_CH], bufB[2][FSS_CH];
+    uint32_t tile = row_begin, ch = 0;
+    if (tile < row_end) {
+        load_ids(ld_id, tile);
+        issue(bufA, 0);
+    }
+    // one pipeline stage: start the loads of the next (tile, chunk), multiply the current one
+    auto stage = [&](float4 (&cur)[2][FSS_CH], float4 (&nxt)[2][FSS_CH]) {
+        uint32_t ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + FS_TR; }
+        if (ch == 0) {
+            sel_load_ids(tile);
+            if (p.scan_ids && tile + FS_TR < row_end) load_ids(ld_nx, tile + FS_TR);
+        }
+        if (ch == 1) sel_load_norms();
+        if (ntile < row_end) {
+            if (nchk == 0) {
+                if (p.scan_ids) { ld_id[0] = ld_nx[0]; ld_id[1] = ld_nx[1]; }
+                else load_ids(ld_id, ntile);
+            }
+            issue(nxt, nchk);
+        }
+        multiply(cur, ch);
+        if (ch == nch - 1) select();
+        tile = ntile;
+        ch = nchk;
+    };
+    while (tile < row_end) { // nch is even: the pair (A,B) always ends on a tile boundary or in its middle
+        stage(bufA, bufB);
+        stage(bufB, bufA);
+    }
+
+    __syncthreads();
+    for (uint32_t q = (uint32_t)wave; q < nq; q += 4) {
+        uint32_t c = cnt[q];
+        if (c > p.kl) {
+            (void)fs_compact_wave<1>(b_key + q * cap_s, b_id + q * cap_s, c, p.kl);
+            c = p.kl;
+        }
+        const size_t lb = (size_t)stripe * p.cap * FS_TQ + (q0 + q); // layout of flat_merge_kernel, n_qtiles == 1
+        for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
+            p.part_key[lb + (size_t)i * FS_TQ] = b_key[q * cap_s + i];
+            p.part_id[lb + (size_t)i * FS_TQ] = b_id[q * cap_s + i];
+        }
+        if (lane == 0) p.part_cnt[(size_t)stripe * FS_TQ + q0 + q] = c;
+    }
+}
+
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id) {
     uint32_t u = __float_as_uint(key);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving map
@@ -384,64 +629,117 @@ __device__ __forceinline__ float fs_unpack_key(unsigned long long x) {
     return __uint_as_float(u);
 }
 
-// Merge the per-stripe lists of one query (block = 256 threads), re-score L2 finalists exactly in
-// the wave order, write the first k ascending by (distance, id).
+// Merge the per-stripe lists of one query (block = 256 threads): SELECT the best nf entries of the n gathered
+// ones (nf = k for cosine, the re-score set kl for L2) with a block-wide bitwise search for the nf-th smallest
+// (ordered key, id) -- 32 compare-and-count steps over the keys, 32 more over the ids only when the boundary key
+// is shared -- instead of sorting all n; re-score L2 finalists exactly in the wave order; rank the <= 256
+// finalists by counting and write the first k ascending by (distance, id).
+__device__ __forceinline__ uint32_t fs_block_sum(uint32_t v, uint32_t *red /*[8]*/, int tid, uint32_t step) {
+    const uint32_t w = (uint32_t)kdb_wave_sum_i((int)v);
+    uint32_t *slot = red + (step & 1u) * 4u; // two alternating sets: one barrier per step is enough
+    if ((tid & 63) == 0) slot[tid >> 6] = w;
+    __syncthreads();
+    return slot[0] + slot[1] + slot[2] + slot[3];
+}
+
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t k, uint32_t npow2,
+flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t k, uint32_t nmax,
                   uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [npow2]
-    float *fin_d = reinterpret_cast<float *>(ent + npow2);                  // [256]
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [nmax]
+    float *fin_d = reinterpret_cast<float *>(ent + nmax);                   // [256]
     uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + 256);           // [256]
-    float *qlds = reinterpret_cast<float *>(fin_id + 256);                  // [ld]
-    uint32_t &total = *reinterpret_cast<uint32_t *>(qlds + v.ld);           // all LDS in the dynamic region
+    uint32_t *red = fin_id + 256;                                           // [8]
+    uint32_t *ctl = red + 8;                                                // [4]: total, nfin
+    float *qlds = reinterpret_cast<float *>(ctl + 4);                       // [ld]
     const uint32_t q = blockIdx.x;
     const int tid = (int)threadIdx.x;
-    if (tid == 0) total = 0;
-    for (uint32_t i = (uint32_t)tid; i < npow2; i += 256) ent[i] = ~0ull;
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     const uint32_t qstride = p.n_qtiles * FS_TQ;
-    for (uint32_t s = 0; s < p.n_stripes; s++) {
-        const uint32_t c = p.part_cnt[(size_t)s * qstride + q];
-        uint32_t base = 0;
-        if (tid == 0) { base = total; total += c; }
+    uint32_t *sbase = reinterpret_cast<uint32_t *>(qlds + v.ld); // [n_stripes] first entry of every stripe's list
+    uint32_t *scnt = sbase + p.n_stripes;                        // [n_stripes]
+    for (uint32_t s0 = 0; s0 < p.n_stripes; s0 += 256) { // exclusive scan of the stripe counts, 256 at a time
+        const uint32_t sidx = s0 + (uint32_t)tid;
+        const uint32_t c = sidx < p.n_stripes ? p.part_cnt[(size_t)sidx * qstride + q] : 0u;
+        uint32_t inc = c; // wave-inclusive scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((tid & 63) >= o) inc += t;
+        }
+        if ((tid & 63) == 63) red[tid >> 6] = inc;
         __syncthreads();
-        base = total - c;
-        const size_t lb = ((size_t)s * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ); // entry-major lists
-        for (uint32_t i = (uint32_t)tid; i < c; i += 256)
-            ent[base + i] = fs_pack(p.part_key[lb + (size_t)i * FS_TQ], p.part_id[lb + (size_t)i * FS_TQ]);
+        uint32_t base = ctl[0];
+        for (int w = 0; w < (tid >> 6); w++) base += red[w];
+        if (sidx < p.n_stripes) {
+            sbase[sidx] = base + inc - c;
+            scnt[sidx] = c;
+        }
+        __syncthreads();
+        if (tid == 0) ctl[0] += red[0] + red[1] + red[2] + red[3];
         __syncthreads();
     }
-    const uint32_t n = total;
-    // bitonic sort ascending
-    for (uint32_t sz = 2; sz <= npow2; sz <<= 1)
-        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            __syncthreads();
-            for (uint32_t i = (uint32_t)tid; i < npow2 / 2; i += 256) {
-                const uint32_t lo = 2 * i - (i & (st - 1));
-                const uint32_t hi = lo + st;
-                const bool up = (lo & sz) == 0;
-                unsigned long long a = ent[lo], b = ent[hi];
-                if ((a > b) == up) { ent[lo] = b; ent[hi] = a; }
-            }
+    for (uint32_t e = (uint32_t)tid; e < p.n_stripes * p.kl; e += 256) { // gather: all loads independent
+        const uint32_t sidx = e / p.kl, i = e % p.kl;
+        if (i < scnt[sidx]) {
+            const size_t lb = ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ); // entry-major lists
+            ent[sbase[sidx] + i] = fs_pack(p.part_key[lb + (size_t)i * FS_TQ], p.part_id[lb + (size_t)i * FS_TQ]);
         }
+    }
     __syncthreads();
-    uint32_t nout = n < k ? n : k;
-    if (METRIC == KDB_METRIC_COSINE) {
-        for (uint32_t i = (uint32_t)tid; i < k; i += 256) {
-            if (i < nout) {
-                out_ids[(size_t)q * k + i] = (uint32_t)(ent[i] & 0xffffffffu);
-                out_dist[(size_t)q * k + i] = -fs_unpack_key(ent[i]); // raw dot
-            } else {
-                out_ids[(size_t)q * k + i] = 0u;
-                out_dist[(size_t)q * k + i] = INFINITY;
+    const uint32_t n = ctl[0];
+    uint32_t want = METRIC == KDB_METRIC_COSINE ? k : p.kl;
+    if (want > 256u) want = 256u;
+    const uint32_t nf = n < want ? n : want;
+    unsigned long long T = ~0ull;
+    if (n > want) {
+        uint32_t step = 0;
+        uint32_t Tk = 0;
+        for (int bit = 31; bit >= 0; bit--, step++) {
+            const uint32_t test = Tk | ((1u << bit) - 1u);
+            uint32_t c = 0;
+            for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += (uint32_t)(ent[i] >> 32) <= test ? 1u : 0u;
+            if (fs_block_sum(c, red, tid, step) < want) Tk |= 1u << bit;
+        }
+        uint32_t c_lt = 0, c_eq = 0;
+        for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+            const uint32_t kk = (uint32_t)(ent[i] >> 32);
+            c_lt += kk < Tk ? 1u : 0u;
+            c_eq += kk == Tk ? 1u : 0u;
+        }
+        c_lt = fs_block_sum(c_lt, red, tid, step++);
+        c_eq = fs_block_sum(c_eq, red, tid, step++);
+        const uint32_t need = want - c_lt;
+        uint32_t Ti = 0xffffffffu;
+        if (c_eq > need) { // several entries share the boundary key: the smallest ids win
+            Ti = 0;
+            for (int bit = 31; bit >= 0; bit--, step++) {
+                const uint32_t test = Ti | ((1u << bit) - 1u);
+                uint32_t c = 0;
+                for (uint32_t i = (uint32_t)tid; i < n; i += 256)
+                    c += ((uint32_t)(ent[i] >> 32) == Tk && (uint32_t)ent[i] <= test) ? 1u : 0u;
+                if (fs_block_sum(c, red, tid, step) < need) Ti |= 1u << bit;
             }
         }
-    } else {
-        // exact re-score of the best nf = min(n, kl) by approximate key
-        uint32_t nf = n < p.kl ? n : p.kl;
-        if (nf > 256) nf = 256;
+        T = ((unsigned long long)Tk << 32) | Ti;
+    }
+    // gather the finalists (any order)
+    for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+        const unsigned long long e = ent[i];
+        if (e <= T) {
+            const uint32_t pos = atomicAdd(&ctl[1], 1u);
+            if (pos < 256u) {
+                fin_d[pos] = fs_unpack_key(e);
+                fin_id[pos] = (uint32_t)(e & 0xffffffffu);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nout = nf < k ? nf : k;
+    if (METRIC == KDB_METRIC_L2) {
+        // exact re-score of the nf finalists (approximate key ||x||^2 - 2 q.x replaced by the wave-order distance)
         for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256)
             reinterpret_cast<float4 *>(qlds)[i] = reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld)[i];
         __syncthreads();
@@ -449,30 +747,30 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
         for (uint32_t base = (uint32_t)wave * 4u; base < nf; base += 16u) {
             const uint32_t r = base + (uint32_t)g;
             const bool act = r < nf;
-            const uint32_t id = act ? (uint32_t)(ent[r] & 0xffffffffu) : 0u;
+            const uint32_t id = act ? fin_id[r] : 0u;
             float part;
             if (PREC == KDB_PREC_F16)
                 part = kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
             else
                 part = kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
             part = kdb_reduce16(part);
-            if (act && t == 0) { fin_d[r] = part; fin_id[r] = id; }
+            if (act && t == 0) fin_d[r] = part;
         }
         __syncthreads();
-        if ((uint32_t)tid < nf) { // rank by counting
-            const float d = fin_d[tid];
-            const uint32_t id = fin_id[tid];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
-            if (rank < k) {
-                out_ids[(size_t)q * k + rank] = id;
-                out_dist[(size_t)q * k + rank] = d;
-            }
+    }
+    if ((uint32_t)tid < nf) { // rank by counting over the total order (distance key, id)
+        const float d = fin_d[tid];
+        const uint32_t id = fin_id[tid];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
+        if (rank < k) {
+            out_ids[(size_t)q * k + rank] = id;
+            out_dist[(size_t)q * k + rank] = METRIC == KDB_METRIC_COSINE ? -d : d; // cosine: raw dot
         }
-        for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
-            out_ids[(size_t)q * k + i] = 0u;
-            out_dist[(size_t)q * k + i] = INFINITY;
-        }
+    }
+    for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
+        out_ids[(size_t)q * k + i] = 0u;
+        out_dist[(size_t)q * k + i] = INFINITY;
     }
     if (tid == 0) out_count[q] = nout;
 }
@@ -549,6 +847,18 @@ merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t
 
 } // namespace
 
+// Batches up to this many queries use flat_scan_small_kernel (KDB_FLAT_SMALL_MAX overrides for measurements).
+static int kdb_flat_small_max() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("KDB_FLAT_SMALL_MAX");
+        v = e ? atoi(e) : 64;
+        if (v < 0) v = 0;
+        if (v > 128) v = 128; // the merge layout of the small kernel holds one 128-query tile
+    }
+    return v;
+}
+
 int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
                           const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
@@ -574,6 +884,11 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     if (B == 0) return KDB_OK;
     const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
     const uint32_t kl = v.metric == KDB_METRIC_COSINE ? k : (k + 16 > 144 ? 144 : k + 16);
+    // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
+    const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
+    const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
+    const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
 
     // ---- scan list
     uint32_t n_scan = v.count;
@@ -583,18 +898,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const bool need_ids = filter || idx->n_deleted > 0;
     uint32_t stripes_max = FS_MAX_MERGE / kl;
     if (stripes_max < 1) stripes_max = 1;
-    // stripes: enough workgroups to fill the chip twice, at least 8 tiles each, XCD multiple
-    uint32_t want = (2048 + n_qtiles - 1) / n_qtiles;
+    // stripes: ONE round of resident workgroups (two fit a CU: 512 in all).  Every stripe pays a start-up phase
+    // (threshold still open, everything is a survivor), so more, shorter stripes only cost: measured at 1M x 768,
+    // 512 workgroups beat 1024 and 2048 for every batch from 1 to 8192 queries.
+    uint32_t want = 512 / (small ? n_q16 : n_qtiles);
+    if (want < 1) want = 1;
     if (want > stripes_max) want = stripes_max;
-    // two workgroups fit a CU (LDS): when the merge capacity caps the stripe count just above a whole number of
-    // 512-workgroup rounds, round DOWN to whole rounds instead of paying a nearly empty tail round
-    if ((size_t)want * n_qtiles > 512 && (size_t)want * n_qtiles < 2048) {
-        const uint32_t rounds = want * n_qtiles / 512;
-        const uint32_t w2 = rounds * 512 / n_qtiles;
-        if (w2 >= 1) want = w2;
-    }
     const size_t max_part = (size_t)want * n_qtiles * FS_TQ;
-    const uint32_t cap = kl <= (uint32_t)FS_LDS_KL ? kl : 2 * kl; // buffered mode keeps 2*kl per (stripe, query)
+    // buffered mode: kl entries + room for max(kl, 64) appends between two compactions (<= 320 in all)
+    const uint32_t cap = (small || kl <= (uint32_t)FS_LDS_KL) ? kl : kl + (kl > 64u ? kl : 64u);
     const size_t part_bytes = max_part * cap * 8 + max_part * 4 + 1024;
     int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + part_bytes + (size_t)n_qtiles * FS_TQ * v.ld * 4 + 4096);
     if (rc) return rc;
@@ -620,7 +932,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     }
     uint32_t n_tiles = (n_scan + FS_TR - 1) / FS_TR;
     uint32_t n_stripes = want;
-    if (n_stripes > (n_tiles + 7) / 8) n_stripes = (n_tiles + 7) / 8; // >= 8 tiles per stripe
+    const uint32_t min_tiles = small ? 4u : 8u;
+    if (n_stripes > (n_tiles + min_tiles - 1) / min_tiles) n_stripes = (n_tiles + min_tiles - 1) / min_tiles;
     if (n_stripes < 1) n_stripes = 1;
     uint32_t tiles_per = (n_tiles + n_stripes - 1) / n_stripes;
     n_stripes = (n_tiles + tiles_per - 1) / tiles_per;
@@ -650,18 +963,27 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
+    auto launch_small = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        hipLaunchKernelGGL(kern, dim3(stripes8 * n_q16), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_q), p, n_q16,
+                           cap_s);
+        return KDB_OK;
+    };
+    if (small) {
+        if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+        else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
+        else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    } else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
-    uint32_t npow2 = 64;
-    while (npow2 < n_stripes * kl) npow2 <<= 1;
-    const size_t mlds = (size_t)npow2 * 8 + 256 * 8 + (size_t)v.ld * 4 + 16;
+    const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)n_stripes * 8 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, npow2, d_out_ids,
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
         return KDB_OK;
     };

@@ -47,6 +47,14 @@ __device__ __forceinline__ int kdb_reduce16_i(int p) {
     return p;
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads already in flight (register prefetch of the next
+// rows) stay in flight across it; __syncthreads() would drain them (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void kdb_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int kdb_wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
