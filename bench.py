@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all hardware threads")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) or gloo (test rigs: several ranks on one GPU)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the RCCL all-gather + merge even with one rank (plumbing check on a 1-GPU box)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,9 +98,13 @@ def main():
     local_rank = local_rank % max(ngpu, 1) if a.backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_exchange
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
@@ -126,7 +132,7 @@ def main():
     t0 = time.time()
     idx.build(n, batch=16384, ef_construction=a.efc, seed=1 + rank)     # GPU batched construction
     t_build = time.time() - t0
-    sh = ShardedSearch(K.COSINE, K.F32, id_base=rank * n, hip_index=idx)
+    sh = ShardedSearch(K.COSINE, K.F32, id_base=rank * n, hip_index=idx, force_exchange=a.force_exchange)
     log(f"[bench] rank {rank}: corpus {t_gen:.1f}s, GPU graph build {t_build:.1f}s")
 
     out_ids = torch.zeros((B, k), dtype=torch.int32, device=dev)
@@ -162,7 +168,7 @@ def main():
     log(f"[bench] ef sweep {sweep} -> ef={ef}")
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -175,7 +181,7 @@ def main():
         run_step(ef)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -241,7 +247,7 @@ def main():
             res["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -197,6 +197,12 @@ KDB_API int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, uint
 KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
                        const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
                        uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream);
+/* The same merge over the PACKED per-shard block that ONE all-gather delivers (one collective per query
+ * batch instead of three): shard g's block starts at d_packed + g*stride_words (32-bit words, stride >=
+ * 2*B*k + B) and holds ids[B][k] | raw distances[B][k] (f32 bits) | count[B].                         */
+KDB_API int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_packed,
+                              uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
+                              float *d_out_dist, uint32_t *d_out_count, void *stream);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each

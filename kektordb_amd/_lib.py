@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "kdb_index_upload_graph", "kdb_index_mark_deleted", "kdb_index_set_count", "kdb_index_graph_info",
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
-    "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_get_counters", "kdb_get_launch_stats",
+    "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_get_counters", "kdb_get_launch_stats",
     "kdb_index_sync",
 ]
 
@@ -106,6 +106,7 @@ def load():
     L.kdb_index_build.argtypes = [vp, u32, C.POINTER(BuildParams)]
     L.kdb_merge_topk.argtypes = [u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.kdb_merge_topk_packed_dev.argtypes = [vp, u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.kdb_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.kdb_get_launch_stats.argtypes = [vp, u32, C.POINTER(Counters)]
     L.kdb_index_sync.argtypes = [vp]

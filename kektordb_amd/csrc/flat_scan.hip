@@ -799,33 +799,35 @@ __global__ void any_bit_kernel(const uint32_t *bits, uint32_t words, uint32_t *o
 
 // Shard merge: G lists of <=k per query -> top-k. One 64-thread block per query.
 // negate = 1 when larger raw values are nearer (dot products of the f32 cosine path).
+// Shard g's ids/distances start at g*stride_e and its counts at g*stride_c (32-bit words): separate [G][B][k]
+// arrays use (B*k, B); the packed block one all-gather delivers uses (L, L) with L = 2*B*k + B.
 __global__ void __launch_bounds__(64)
 merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const float *in_dist,
-                  const uint32_t *in_count, const uint32_t *id_base, uint32_t *out_ids, float *out_dist,
-                  uint32_t *out_count) {
+                  const uint32_t *in_count, size_t stride_e, size_t stride_c, const uint32_t *id_base,
+                  uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
     const uint32_t q = blockIdx.x;
     const int lane = kdb_lane();
     uint32_t total = 0;
     for (uint32_t g = 0; g < G; g++) {
-        uint32_t c = in_count[(size_t)g * B + q];
+        uint32_t c = in_count[g * stride_c + q];
         total += c < k ? c : k;
     }
     const uint32_t nout = total < k ? total : k;
     const uint32_t n = G * k;
     for (uint32_t e = (uint32_t)lane; e < n; e += 64) {
         const uint32_t g = e / k, i = e % k;
-        uint32_t cg = in_count[(size_t)g * B + q];
+        uint32_t cg = in_count[g * stride_c + q];
         if (cg > k) cg = k;
         if (i >= cg) continue;
-        const size_t off = ((size_t)g * B + q) * k + i;
+        const size_t off = g * stride_e + (size_t)q * k + i;
         const float d = in_dist[off];
         const uint32_t id = in_ids[off] + (id_base ? id_base[g] : 0u);
         const float key = negate ? -d : d;
         uint32_t rank = 0;
         for (uint32_t g2 = 0; g2 < G; g2++) {
-            uint32_t c2 = in_count[(size_t)g2 * B + q];
+            uint32_t c2 = in_count[g2 * stride_c + q];
             if (c2 > k) c2 = k;
-            const size_t o2 = ((size_t)g2 * B + q) * k;
+            const size_t o2 = g2 * stride_e + (size_t)q * k;
             const uint32_t b2 = id_base ? id_base[g2] : 0u;
             for (uint32_t j = 0; j < c2; j++) {
                 const float d2 = in_dist[o2 + j];
@@ -860,11 +862,13 @@ static int kdb_flat_small_max() {
 }
 
 int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
-                          const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
-                          uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
+                          const float *d_in_dist, const uint32_t *d_in_count, size_t stride_e, size_t stride_c,
+                          const uint32_t *d_id_base, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                          hipStream_t s) {
     if (B == 0) return KDB_OK;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, s, negate, G, B, k, d_in_ids, d_in_dist, d_in_count,
-                       d_id_base, d_out_ids, d_out_dist, d_out_count);
+                       stride_e ? stride_e : (size_t)B * k, stride_c ? stride_c : (size_t)B, d_id_base, d_out_ids, d_out_dist,
+                       d_out_count);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }

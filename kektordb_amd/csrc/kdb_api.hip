@@ -819,8 +819,27 @@ extern "C" int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
     const int negate = idx->desc.metric == KDB_METRIC_COSINE && idx->desc.precision == KDB_PREC_F32;
-    return kdb_launch_merge_topk(negate, G, B, k, d_in_ids, d_in_dist, d_in_count, d_id_base, d_out_ids, d_out_dist,
+    return kdb_launch_merge_topk(negate, G, B, k, d_in_ids, d_in_dist, d_in_count, 0, 0, d_id_base, d_out_ids, d_out_dist,
                                  d_out_count, s);
+}
+
+extern "C" int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_packed,
+                                         uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
+                                         float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    const uint64_t block = 2ull * B * k + B;
+    if (!d_packed || !d_out_ids || !d_out_dist || !d_out_count || k == 0 || stride_words < block) {
+        kdb_set_error("merge_topk_packed: null buffer, k == 0 or stride %llu < 2*B*k+B = %llu", (unsigned long long)stride_words,
+                      (unsigned long long)block);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    const int negate = idx->desc.metric == KDB_METRIC_COSINE && idx->desc.precision == KDB_PREC_F32;
+    const size_t bk = (size_t)B * k;
+    return kdb_launch_merge_topk(negate, G, B, k, d_packed, reinterpret_cast<const float *>(d_packed + bk), d_packed + 2 * bk,
+                                 (size_t)stride_words, (size_t)stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count, s);
 }
 
 static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {

@@ -122,7 +122,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                          uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
                          uint32_t *d_out_count, hipStream_t s);
 int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
-                          const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
-                          uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, hipStream_t s);
+                          const float *d_in_dist, const uint32_t *d_in_count, size_t stride_e, size_t stride_c,
+                          const uint32_t *d_id_base, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                          hipStream_t s);
 // build.hip
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p);

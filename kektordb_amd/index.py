@@ -269,6 +269,13 @@ class HipIndex:
                                         _tptr(d_id_base), _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                         C.c_void_p(stream) if stream else None), "kdb_merge_topk_dev")
 
+    def merge_topk_packed_dev(self, G, B, k, d_packed, stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count,
+                              stream=None):
+        """merge over the packed per-shard blocks (ids | dist bits | count) that one all-gather delivers"""
+        check(self.L.kdb_merge_topk_packed_dev(self.h, G, B, k, _tptr(d_packed), stride_words, _tptr(d_id_base),
+                                               _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
+                                               C.c_void_p(stream) if stream else None), "kdb_merge_topk_packed_dev")
+
     # ---- the reference's per-query API --------------------------------------------------------------
     def score(self, raw: float) -> float:
         """The reference's f64 epilogue: float64(sum) (distance_go.go:67) / 1.0-float64(dot) (:127)."""

@@ -3,8 +3,9 @@
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Shard g owns the
 contiguous global ids [base_g + 1, base_g + n_g]; it holds its rows and its OWN HNSW graph built
 over only those rows.  A query batch is replicated on every rank; each rank searches its shard; ONE
-all-gather of the per-shard top-k (B*k ids + B*k raw distances + B counts: 84 B/query at k=10) is
-the only exchange step; every rank then merges G*k candidates per query with kdb_merge_topk(_dev).
+all-gather of the per-shard top-k (ONE packed block of B*k ids + B*k raw distances + B counts per rank:
+84 B/query at k=10) is the only exchange step; every rank then merges G*k candidates per query with
+kdb_merge_topk_packed_dev (kdb_merge_topk on the host path).
 The reference has no counterpart (single process); the oracle for a G-shard result is
 "G restatement indexes over the same ranges + merge" (tests/test_shard_gloo.py).
 
@@ -50,8 +51,10 @@ class ShardedSearch:
     """Top-k exchange + merge around a per-rank local search."""
 
     def __init__(self, metric: int, precision: int, id_base: int, group=None,
-                 hip_index: Optional["_index.HipIndex"] = None):
+                 hip_index: Optional["_index.HipIndex"] = None, force_exchange: bool = False):
         self.metric, self.precision = metric, precision
+        # force_exchange: run the all-gather + merge even with ONE rank (exercises the RCCL plumbing on a 1-GPU box)
+        self.force_exchange = bool(force_exchange) and dist.is_initialized()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -78,41 +81,38 @@ class ShardedSearch:
         B = d_queries.shape[0]
         dev = d_queries.device
         key = (B, k)
+        L = 2 * B * k + B  # packed block: ids[B][k] | dist[B][k] (f32 bits) | count[B], 32-bit words
         if key not in self._bufs:
-            self._bufs[key] = (torch.zeros((B, k), dtype=torch.int32, device=dev),
-                               torch.zeros((B, k), dtype=torch.float32, device=dev),
-                               torch.zeros((B,), dtype=torch.int32, device=dev),
-                               torch.zeros((self.world, B, k), dtype=torch.int32, device=dev),
-                               torch.zeros((self.world, B, k), dtype=torch.float32, device=dev),
-                               torch.zeros((self.world, B), dtype=torch.int32, device=dev))
-        l_ids, l_dist, l_cnt, g_ids, g_dist, g_cnt = self._bufs[key]
+            self._bufs[key] = (torch.zeros((L,), dtype=torch.int32, device=dev),
+                               torch.zeros((self.world, L), dtype=torch.int32, device=dev))
+        local, gathered = self._bufs[key]
+        l_ids = local[:B * k].view(B, k)
+        l_dist = local[B * k:2 * B * k].view(torch.float32).view(B, k)
+        l_cnt = local[2 * B * k:]
         self.stream.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         with torch.cuda.stream(self.stream):
             raw = self.stream.cuda_stream
-            tgt = (out_ids, out_dist, out_cnt) if self.world == 1 else (l_ids, l_dist, l_cnt)
+            tgt = (out_ids, out_dist, out_cnt) if self.world == 1 and not self.force_exchange else (l_ids, l_dist, l_cnt)
             if flat:
                 idx.flat_scan_batch_dev(d_queries, k, *tgt, d_allow, stream=raw)
             else:
                 idx.search_batch_dev(d_queries, k, ef, *tgt, d_allow, stream=raw)
-            if self.world == 1:
+            if self.world == 1 and not self.force_exchange:
                 return
-            # the one exchange step: all-gather of per-shard top-k (RCCL over xGMI)
+            # the one exchange step: ONE all-gather of the packed per-shard top-k (RCCL over xGMI)
             if dist.get_backend(self.group) == "nccl":
-                dist.all_gather_into_tensor(g_ids.view(-1), l_ids.view(-1), group=self.group)
-                dist.all_gather_into_tensor(g_dist.view(-1), l_dist.view(-1), group=self.group)
-                dist.all_gather_into_tensor(g_cnt.view(-1), l_cnt.view(-1), group=self.group)
+                dist.all_gather_into_tensor(gathered.view(-1), local, group=self.group)
             else:
                 # test rigs without RCCL (several ranks sharing one GPU under gloo): same exchange staged
                 # through host memory; everything else on this path is identical
-                for g_t, l_t in ((g_ids, l_ids), (g_dist, l_dist), (g_cnt, l_cnt)):
-                    h = l_t.cpu()
-                    parts = [torch.zeros_like(h) for _ in range(self.world)]
-                    dist.all_gather(parts, h, group=self.group)
-                    g_t.copy_(torch.stack(parts).to(dev))
+                h = local.cpu()
+                parts = [torch.zeros_like(h) for _ in range(self.world)]
+                dist.all_gather(parts, h, group=self.group)
+                gathered.copy_(torch.stack(parts).to(dev))
             if self._dev_bases is None:
                 self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
-            idx.merge_topk_dev(self.world, B, k, g_ids, g_dist, g_cnt, self._dev_bases, out_ids, out_dist, out_cnt,
-                               stream=raw)
+            idx.merge_topk_packed_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt,
+                                      stream=raw)
 
     # ---- host path (what a Go shim does with host buffers; also the gloo test path) -------------------
     def merge_host(self, l_ids: np.ndarray, l_dist: np.ndarray, l_cnt: np.ndarray, k: int
