@@ -30,6 +30,7 @@ constexpr int FS_LDS_KL = 16;       // running top-k lists live in LDS up to thi
 constexpr uint32_t FS_MAX_MERGE = 16384; // entries one merge workgroup gathers in LDS (128 KB)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FsParams {
     const uint32_t *scan_ids; // compacted ids (filter / deletes) or null = identity (id = r+1)
@@ -203,7 +204,11 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: IEEE binary16 bits
-    const uint32_t nslab = v.ld / FS_BK + ((v.ld % FS_BK) ? 1u : 0u); // ld is a multiple of 16; last slab may be half
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(v.rows); // PREC == I8: ld bytes per row
+    const unsigned char *queries8 = reinterpret_cast<const unsigned char *>(queries);
+    // a slab is 128 BYTES of every row in LDS: 32 floats (f32, or f16 widened), or 128 int8 components
+    constexpr uint32_t SLAB_ELEMS = PREC == KDB_PREC_I8 ? 128u : (uint32_t)FS_BK;
+    const uint32_t nslab = (v.ld + SLAB_ELEMS - 1u) / SLAB_ELEMS; // ld is a multiple of 16; the last slab may be partial
     // staging map: thread t loads float4 #(t%8) of rows t/8 + 32*i (i<4) of both operands
     const int s_r = tid >> 3, s_c = tid & 7;
 
@@ -223,10 +228,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
 
         float4 ra[4], rb[4];
         auto gload = [&](uint32_t slab) {
-            const uint32_t col = slab * FS_BK + (uint32_t)s_c * 4u;
+            const uint32_t col = slab * SLAB_ELEMS + (uint32_t)s_c * (SLAB_ELEMS / 8u); // 16 bytes per thread and row
             const bool in = col < v.ld;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                if (PREC == KDB_PREC_I8) { // 16 int8 components, bytes kept as they are
+                    ra[i] = in ? *reinterpret_cast<const float4 *>(rows8 + (size_t)a_id[i] * v.ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rb[i] = in ? *reinterpret_cast<const float4 *>(queries8 + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
                 if (PREC == KDB_PREC_F16) { // half the row bytes; widened to f32 on the way into LDS (exact)
                     uint2 h = in ? *reinterpret_cast<const uint2 *>(rows16 + (size_t)a_id[i] * v.ld + col) : make_uint2(0u, 0u);
                     ra[i] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
@@ -259,6 +270,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     fa[t] = *reinterpret_cast<const float4 *>(lds_a + (wr * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
                     fb[t] = *reinterpret_cast<const float4 *>(lds_b + (wq * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
                 }
+                if (PREC == KDB_PREC_I8) { // exact i32 dot: one 16x16x64 MFMA per tile and 64-byte step
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            acc[a][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                                                      __builtin_bit_cast(i32x4, fa[a]), __builtin_bit_cast(i32x4, fb[b]),
+                                                                      __builtin_bit_cast(i32x4, acc[a][b]), 0, 0, 0));
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -284,15 +305,19 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 const uint32_t rr = tile + (uint32_t)(wr * 64 + a * 16 + fg * 4 + r);
                 const bool live = rr < row_end;
                 float nrm = 0.f;
-                if (METRIC == KDB_METRIC_L2) {
+                if (METRIC == KDB_METRIC_L2 || PREC == KDB_PREC_I8) {
                     const uint32_t rid = live ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
                     nrm = v.norms[rid];
+                    if (PREC == KDB_PREC_I8) nrm = nrm == 0.f ? 0.f : 1.0f / nrm; // stored norm 0 => similarity 0
                 }
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    const float dotv = acc[a][b][r];
-                    // keys overwrite the accumulators: cosine -dot; L2 ||x||^2 - 2 q.x (ranking only)
-                    acc[a][b][r] = METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nrm);
+                    const float rawv = acc[a][b][r];
+                    const float dotv = PREC == KDB_PREC_I8 ? (float)__float_as_int(rawv) : rawv; // int8: exact i32 dot
+                    // keys overwrite the accumulators: cosine -dot; L2 ||x||^2 - 2 q.x; int8 -dot/||x|| (ranking only:
+                    // L2 and int8 finalists are re-scored exactly by the merge kernel)
+                    acc[a][b][r] = PREC == KDB_PREC_I8 ? -dotv * nrm
+                                   : METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nrm);
                     if (live) pend[a] |= 1ull << (b * 4 + r);
                 }
             }
@@ -644,8 +669,8 @@ __device__ __forceinline__ uint32_t fs_block_sum(uint32_t v, uint32_t *red /*[8]
 
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t k, uint32_t nmax,
-                  uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
+flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__restrict__ qnorm, FsParams p, uint32_t k,
+                  uint32_t nmax, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [nmax]
     float *fin_d = reinterpret_cast<float *>(ent + nmax);                   // [256]
@@ -690,7 +715,8 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
     }
     __syncthreads();
     const uint32_t n = ctl[0];
-    uint32_t want = METRIC == KDB_METRIC_COSINE ? k : p.kl;
+    constexpr bool RESCORE = METRIC == KDB_METRIC_L2 || PREC == KDB_PREC_I8; // selection keys were approximate
+    uint32_t want = RESCORE ? p.kl : k;
     if (want > 256u) want = 256u;
     const uint32_t nf = n < want ? n : want;
     unsigned long long T = ~0ull;
@@ -738,10 +764,14 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
     }
     __syncthreads();
     const uint32_t nout = nf < k ? nf : k;
-    if (METRIC == KDB_METRIC_L2) {
-        // exact re-score of the nf finalists (approximate key ||x||^2 - 2 q.x replaced by the wave-order distance)
-        for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256)
-            reinterpret_cast<float4 *>(qlds)[i] = reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld)[i];
+    if (RESCORE) {
+        // exact re-score of the nf finalists: the approximate key (||x||^2 - 2 q.x, or -dot/||x||) is replaced by
+        // the distance of the search path (wave-order squared L2; int8: i32 dot + f64 cosine scaling)
+        const uint32_t qwords = PREC == KDB_PREC_I8 ? (v.ld >> 4) : (v.ld >> 2); // 16-byte pieces of the query row
+        const float4 *qsrc = PREC == KDB_PREC_I8
+                                 ? reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(queries) + (size_t)q * v.ld)
+                                 : reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld);
+        for (uint32_t i = (uint32_t)tid; i < qwords; i += 256) reinterpret_cast<float4 *>(qlds)[i] = qsrc[i];
         __syncthreads();
         const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, t = lane & 15;
         for (uint32_t base = (uint32_t)wave * 4u; base < nf; base += 16u) {
@@ -749,11 +779,15 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
             const bool act = r < nf;
             const uint32_t id = act ? fin_id[r] : 0u;
             float part;
-            if (PREC == KDB_PREC_F16)
-                part = kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
-            else
-                part = kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t);
-            part = kdb_reduce16(part);
+            if (PREC == KDB_PREC_I8) {
+                const int dot = kdb_reduce16_i(kdb_row_partial_i8(reinterpret_cast<const int8_t *>(v.rows) + (size_t)id * v.ld,
+                                                                  reinterpret_cast<const int8_t *>(qlds), v.ld, t));
+                part = kdb_i8_distance(dot, qnorm[q], v.norms[id]);
+            } else if (PREC == KDB_PREC_F16) {
+                part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            } else {
+                part = kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            }
             if (act && t == 0) fin_d[r] = part;
         }
         __syncthreads();
@@ -765,7 +799,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint
         for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
         if (rank < k) {
             out_ids[(size_t)q * k + rank] = id;
-            out_dist[(size_t)q * k + rank] = METRIC == KDB_METRIC_COSINE ? -d : d; // cosine: raw dot
+            out_dist[(size_t)q * k + rank] = RESCORE ? d : -d; // f32 cosine: raw dot
         }
     }
     for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
@@ -876,23 +910,20 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
                          uint32_t *d_out_count, hipStream_t s) {
-    (void)d_qnorm;
-    if (v.precision == KDB_PREC_I8) {
-        kdb_set_error("flat scan: int8 rows are not supported in this version (float32 and float16 are)");
-        return KDB_ERR_UNSUPPORTED;
-    }
     if (k == 0 || k > 128) {
         kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
         return KDB_ERR_INVALID;
     }
     if (B == 0) return KDB_OK;
     const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
-    const uint32_t kl = v.metric == KDB_METRIC_COSINE ? k : (k + 16 > 144 ? 144 : k + 16);
+    // L2 and int8 select by an approximate key and re-score: 16 extra candidates absorb its rounding
+    const bool rescore = v.metric != KDB_METRIC_COSINE || v.precision == KDB_PREC_I8;
+    const uint32_t kl = !rescore ? k : (k + 16 > 144 ? 144 : k + 16);
     // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
     const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
     const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
-    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
+    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u && v.precision != KDB_PREC_I8;
 
     // ---- scan list
     uint32_t n_scan = v.count;
@@ -977,7 +1008,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
         else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
         else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
-    } else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
+    } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
+    else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
@@ -987,11 +1019,12 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)n_stripes * 8 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), p, k, nmax, d_out_ids,
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
+    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;

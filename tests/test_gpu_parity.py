@@ -262,6 +262,36 @@ def test_flat_scan_f16(oracle, hip):
         assert np.array_equal(dist[b].astype(np.float64), od)
 
 
+@pytest.mark.parametrize("n,dim,k,B", [(6000, 200, 10, 150), (3000, 768, 50, 9)])
+def test_flat_scan_int8(oracle, hip, n, dim, k, B):
+    """int8 rows (cosine only, hnsw_index.go:219-222): exact i32 dots on the int8 MFMA, ranking by -dot/||x||,
+    finalists re-scored with the f64 cosine scaling of the search path (hnsw_index.go:2429-2454)"""
+    O = oracle
+    X = make_corpus(n, dim, "normal", seed=81)
+    orc = O.OracleIndex(dim, 1, O.I8, 16, 40, seed=7)
+    orc.set_absmax(float(np.quantile(np.abs(X), 0.999)))
+    orc.add_many(X)
+    deleted = list(range(5, n, 40))
+    for d in deleted:
+        orc.mark_deleted(int(d))
+    idx = hip.HipIndex(dim, 1, O.I8, 16, 40, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_norms(orc.norms()[1:], 1)
+    idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    Q = make_corpus(B, dim, "normal", seed=82)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    same = 0
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k)
+        c = int(cnt[b])
+        assert c == len(oi) == k
+        assert_same_results_tol(ids[b, :c], dist[b, :c].astype(np.float64), oi, od)
+        assert not (set(ids[b, :c].tolist()) & set(deleted))
+        same += int(np.array_equal(ids[b, :c], oi))
+    assert same >= B - 2, f"{same}/{B} id lists identical"  # f32-rounded distances can swap exact near-ties only
+
+
 def test_bruteforce_f64_reference_semantics(oracle, hip):
     # BruteForceIndex (vector_index.go:104-162) scores squared L2 in f64: the f32 GPU scan must agree
     # within the stated tolerance
