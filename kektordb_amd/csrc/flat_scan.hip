@@ -149,7 +149,7 @@ __device__ __forceinline__ void fs_find_worst(const float *key, const uint32_t *
 }
 
 template <int METRIC, int PREC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2) // two workgroups per CU (LDS allows it): <= 256 VGPR+AGPR per lane
 flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128][ld] prepared*/, FsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lds_a = reinterpret_cast<float *>(smem);                       // [128][40]
@@ -164,6 +164,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     uint32_t *l_cnt = l_id + FS_TQ * FS_LDS_KL;                           // [128] entries held (buffered mode)
     uint32_t *need = l_cnt + FS_TQ;                                       // [128] queries whose buffer is full
     uint32_t *n_need = need + FS_TQ;                                      // [4]
+    uint32_t *sel_flags = n_need + 4;                                     // [4] (pushed, left) x 2 alternating rounds
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -201,6 +202,8 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
         l_cnt[tid] = 0;
     }
     if (tid == 0) n_need[0] = 0;
+    if (tid < 4) sel_flags[tid] = 0;
+    uint32_t sel_round = 0;
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: IEEE binary16 bits
@@ -296,8 +299,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
         }
 
         // ---- fused selection: lane holds, per MFMA tile (a,b): query qq = wq*64+b*16+fi,
-        //      rows rr = wr*64 + a*16 + fg*4 + r (r<4)
-        unsigned long long pend[4] = {0ull, 0ull, 0ull, 0ull}; // bit (b*4+r) of pend[a]
+        //      rows rr = wr*64 + a*16 + fg*4 + r (r<4).  Keys overwrite the accumulators (dead rows: +inf).
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -314,46 +316,75 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 for (int b = 0; b < 4; b++) {
                     const float rawv = acc[a][b][r];
                     const float dotv = PREC == KDB_PREC_I8 ? (float)__float_as_int(rawv) : rawv; // int8: exact i32 dot
-                    // keys overwrite the accumulators: cosine -dot; L2 ||x||^2 - 2 q.x; int8 -dot/||x|| (ranking only:
-                    // L2 and int8 finalists are re-scored exactly by the merge kernel)
-                    acc[a][b][r] = PREC == KDB_PREC_I8 ? -dotv * nrm
-                                   : METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nrm);
-                    if (live) pend[a] |= 1ull << (b * 4 + r);
+                    // cosine -dot; L2 ||x||^2 - 2 q.x; int8 -dot/||x|| (ranking only: L2 and int8 finalists are
+                    // re-scored exactly by the merge kernel)
+                    const float key = PREC == KDB_PREC_I8 ? -dotv * nrm
+                                      : METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nrm);
+                    acc[a][b][r] = live ? key : INFINITY;
                 }
             }
-        for (;;) {
-            __syncthreads(); // tau / queue stable
-            bool left = false;
+        // Steady state: almost no row beats the current k-th best.  Each lane first compares the MINIMUM of its 16
+        // keys of a query column with that query's threshold; only columns that pass are looked at entry by entry.
+        // A tile in which no lane of the workgroup queued anything costs one barrier.
+        uint32_t colmask = 0; // bit b: column b may hold survivors
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+        for (int b = 0; b < 4; b++) {
+            float m = acc[0][b][0];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) m = fminf(m, acc[a][b][r]);
+            if (m <= tau[wq * 64 + b * 16 + fi]) colmask |= 1u << b;
+        }
+        uint32_t pend[4] = {0u, 0u, 0u, 0u}; // bit (b*4+r) of pend[a]: survivor that found its mini queue full
+        bool first = true;
+        for (;;) {
+            bool pushed = false, left = false;
+            if (colmask) {
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
+                    if (!((colmask >> b) & 1u)) continue;
                     const int qq = wq * 64 + b * 16 + fi;
                     const float t_k = tau[qq];
                     const uint32_t t_id = tau_id[qq];
+                    bool again = false;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const unsigned long long bit = 1ull << (b * 4 + r);
-                        if (!(pend[a] & bit)) continue;
-                        const uint32_t rr = tile + (uint32_t)(wr * 64 + a * 16 + fg * 4 + r);
-                        const uint32_t rid = p.scan_ids ? p.scan_ids[rr] : rr + 1u;
-                        const float key = acc[a][b][r];
-                        if (!fs_better(key, rid, t_k, t_id)) {
-                            pend[a] &= ~bit; // cannot enter the list any more (tau only tightens)
-                            continue;
-                        }
-                        const uint32_t slot = atomicAdd(&q_cnt[qq], 1u);
-                        if (slot < (uint32_t)FS_QPER) {
-                            q_key[qq * FS_QPER + (int)slot] = key;
-                            q_row[qq * FS_QPER + (int)slot] = rid;
+                    for (int a = 0; a < 4; a++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t bit = 1u << (b * 4 + r);
+                            if (!first && !(pend[a] & bit)) continue;
                             pend[a] &= ~bit;
-                        } else {
-                            left = true; // this query's mini queue is full: retry next round
+                            const float key = acc[a][b][r];
+                            if (!(key <= t_k)) continue; // also drops NaN
+                            const uint32_t rr = tile + (uint32_t)(wr * 64 + a * 16 + fg * 4 + r);
+                            if (rr >= row_end) continue; // dead row of the last tile (its key is +inf)
+                            const uint32_t rid = p.scan_ids ? p.scan_ids[rr] : rr + 1u;
+                            if (!fs_better(key, rid, t_k, t_id)) continue; // tau only tightens: never again
+                            const uint32_t slot = atomicAdd(&q_cnt[qq], 1u);
+                            if (slot < (uint32_t)FS_QPER) {
+                                q_key[qq * FS_QPER + (int)slot] = key;
+                                q_row[qq * FS_QPER + (int)slot] = rid;
+                                pushed = true;
+                            } else {
+                                pend[a] |= bit; // this query's mini queue is full: retry next round
+                                again = true;
+                            }
                         }
                     }
+                    if (!again) colmask &= ~(1u << b);
+                    left = left || again;
                 }
             }
+            first = false;
+            const uint32_t fl = sel_round & 1u; // two alternating flag pairs: no reset race between rounds
+            if (pushed || left) sel_flags[fl * 2u] = 1u;
+            if (left) sel_flags[fl * 2u + 1u] = 1u;
             __syncthreads();
+            const bool any_pushed = sel_flags[fl * 2u] != 0u, any_left = sel_flags[fl * 2u + 1u] != 0u;
+            if (tid == 0) { sel_flags[(fl ^ 1u) * 2u] = 0u; sel_flags[(fl ^ 1u) * 2u + 1u] = 0u; }
+            sel_round++;
+            if (!any_pushed) break; // nothing queued anywhere in the workgroup: next tile
             if (tid < FS_TQ) { // drain: every owner lane takes ITS OWN queue, all lanes in parallel
                 uint32_t nq = q_cnt[tid];
                 if (nq > (uint32_t)FS_QPER) nq = FS_QPER;
@@ -362,9 +393,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     const uint32_t rid = q_row[tid * FS_QPER + (int)e];
                     if (!lds_lists) { // buffered mode: append; a full buffer is compacted by a whole wave below
                         if (!fs_better(key, rid, tau[tid], tau_id[tid])) continue;
-                        if (my_cnt == p.cap) { // cannot happen: cap - kl >= FS_QPER survivors fit between compactions
-                            continue;
-                        }
+                        if (my_cnt == p.cap) continue; // cannot happen: cap - kl >= FS_QPER survivors fit between compactions
                         my_key[LST(my_cnt)] = key;
                         my_id[LST(my_cnt)] = rid;
                         my_cnt++;
@@ -393,23 +422,26 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     if (my_cnt + (uint32_t)FS_QPER > p.cap) need[atomicAdd(&n_need[0], 1u)] = (uint32_t)tid;
                 }
             }
+            __syncthreads(); // thresholds, queues (and the work list of full buffers) are stable
             if (!lds_lists) { // cooperative compaction of the full buffers, one query per wave at a time
-                __syncthreads();
                 const uint32_t nn = n_need[0];
-                for (uint32_t w = (uint32_t)wave; w < nn; w += 4) {
-                    const uint32_t qq = need[w];
-                    const unsigned long long T = fs_compact_wave<FS_TQ>(p.part_key + blk_base + qq, p.part_id + blk_base + qq, l_cnt[qq], p.kl);
-                    if (lane == 0) {
-                        tau[qq] = fs_unpack_key(T);
-                        tau_id[qq] = (uint32_t)(T & 0xffffffffu);
-                        l_cnt[qq] = p.kl;
+                if (nn) {
+                    for (uint32_t w = (uint32_t)wave; w < nn; w += 4) {
+                        const uint32_t qq = need[w];
+                        const unsigned long long T = fs_compact_wave<FS_TQ>(p.part_key + blk_base + qq, p.part_id + blk_base + qq, l_cnt[qq], p.kl);
+                        if (lane == 0) {
+                            tau[qq] = fs_unpack_key(T);
+                            tau_id[qq] = (uint32_t)(T & 0xffffffffu);
+                            l_cnt[qq] = p.kl;
+                        }
                     }
+                    __syncthreads();
+                    if (tid == 0) n_need[0] = 0;
+                    if (tid < FS_TQ) my_cnt = l_cnt[tid];
+                    __syncthreads();
                 }
-                __syncthreads();
-                if (tid == 0) n_need[0] = 0;
-                if (tid < FS_TQ) my_cnt = l_cnt[tid];
             }
-            if (!__syncthreads_or(left ? 1 : 0)) break;
+            if (!any_left) break;
         }
     }
     if (!lds_lists) { // final compaction so that every list handed to the merge kernel holds <= kl entries
@@ -988,7 +1020,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * cap * 8);
 
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
-                       (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 16;
+                       (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 32;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
     (void)kdb_stats_begin(idx, 2, B, 0);
