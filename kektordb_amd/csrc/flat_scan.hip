@@ -34,15 +34,34 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FsParams {
     const uint32_t *scan_ids; // compacted ids (filter / deletes) or null = identity (id = r+1)
-    uint32_t n_scan;          // rows to scan
-    uint32_t rows_per_stripe; // multiple of FS_TR
-    uint32_t n_stripes, n_qtiles;
+    uint32_t n_scan;          // rows to scan when the host knows it (no id list); else read from n_scan_dev
+    const uint32_t *n_scan_dev; // filtered / deleted rows: written by compact_ids_kernel, never read back by the host
+    uint32_t want, min_tiles; // stripe count asked for, fewest tiles worth a stripe
+    uint32_t n_qtiles;
+    unsigned long long *ctr;  // statistics slot: [0] = rows scanned
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
     uint32_t *part_id;
     uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
 };
+
+// Stripe geometry, resolved ON THE DEVICE by every kernel of the scan (same integer arithmetic everywhere): the
+// number of rows that survive the filter is produced by a kernel of the same stream, so the host never waits for it.
+struct FsGeom { uint32_t n_scan, n_stripes, rows_per_stripe; };
+__device__ __forceinline__ FsGeom fs_resolve(const FsParams &p) {
+    FsGeom g;
+    g.n_scan = p.n_scan_dev ? *p.n_scan_dev : p.n_scan;
+    const uint32_t n_tiles = (g.n_scan + FS_TR - 1) / FS_TR;
+    uint32_t ns = p.want;
+    const uint32_t lim = (n_tiles + p.min_tiles - 1) / p.min_tiles;
+    if (ns > lim) ns = lim;
+    if (ns < 1) ns = 1;
+    const uint32_t tiles_per = (n_tiles + ns - 1) / ns;
+    g.n_stripes = tiles_per ? (n_tiles + tiles_per - 1) / tiles_per : 0u;
+    g.rows_per_stripe = tiles_per * FS_TR;
+    return g;
+}
 
 __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint32_t id2) {
     return (k1 < k2) || (k1 == k2 && id1 < id2);
@@ -176,11 +195,13 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const uint32_t xcd = bid & 7u, local = bid >> 3;
     const uint32_t stripe = (local / p.n_qtiles) * 8u + xcd;
     const uint32_t qtile = local % p.n_qtiles;
-    if (stripe >= p.n_stripes) return;
+    const FsGeom geo = fs_resolve(p);
+    if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
+    if (stripe >= geo.n_stripes) return;
 
-    const uint32_t row_begin = stripe * p.rows_per_stripe;
-    uint32_t row_end = row_begin + p.rows_per_stripe;
-    if (row_end > p.n_scan) row_end = p.n_scan;
+    const uint32_t row_begin = stripe * geo.rows_per_stripe;
+    uint32_t row_end = row_begin + geo.rows_per_stripe;
+    if (row_end > geo.n_scan) row_end = geo.n_scan;
     const uint32_t q0 = qtile * FS_TQ;
 
     // owner state: thread t < 128 owns query q0+t
@@ -499,10 +520,12 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     const uint32_t xcd = bid & 7u, local = bid >> 3;
     const uint32_t stripe = (local / n_q16) * 8u + xcd; // the query groups of one stripe share an XCD (L2)
     const uint32_t qt = local % n_q16;
-    if (stripe >= p.n_stripes) return;
-    const uint32_t row_begin = stripe * p.rows_per_stripe;
-    uint32_t row_end = row_begin + p.rows_per_stripe;
-    if (row_end > p.n_scan) row_end = p.n_scan;
+    const FsGeom geo = fs_resolve(p);
+    if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
+    if (stripe >= geo.n_stripes) return;
+    const uint32_t row_begin = stripe * geo.rows_per_stripe;
+    uint32_t row_end = row_begin + geo.rows_per_stripe;
+    if (row_end > geo.n_scan) row_end = geo.n_scan;
     const uint32_t q0 = qt * FSS_TQ;
     const uint32_t nq = p.B - q0 < (uint32_t)FSS_TQ ? p.B - q0 : (uint32_t)FSS_TQ;
 
@@ -715,11 +738,12 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     const uint32_t qstride = p.n_qtiles * FS_TQ;
-    uint32_t *sbase = reinterpret_cast<uint32_t *>(qlds + v.ld); // [n_stripes] first entry of every stripe's list
-    uint32_t *scnt = sbase + p.n_stripes;                        // [n_stripes]
-    for (uint32_t s0 = 0; s0 < p.n_stripes; s0 += 256) { // exclusive scan of the stripe counts, 256 at a time
+    const uint32_t n_stripes = fs_resolve(p).n_stripes;          // <= p.want
+    uint32_t *sbase = reinterpret_cast<uint32_t *>(qlds + v.ld); // [want] first entry of every stripe's list
+    uint32_t *scnt = sbase + p.want;                             // [want]
+    for (uint32_t s0 = 0; s0 < n_stripes; s0 += 256) { // exclusive scan of the stripe counts, 256 at a time
         const uint32_t sidx = s0 + (uint32_t)tid;
-        const uint32_t c = sidx < p.n_stripes ? p.part_cnt[(size_t)sidx * qstride + q] : 0u;
+        const uint32_t c = sidx < n_stripes ? p.part_cnt[(size_t)sidx * qstride + q] : 0u;
         uint32_t inc = c; // wave-inclusive scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -730,7 +754,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         __syncthreads();
         uint32_t base = ctl[0];
         for (int w = 0; w < (tid >> 6); w++) base += red[w];
-        if (sidx < p.n_stripes) {
+        if (sidx < n_stripes) {
             sbase[sidx] = base + inc - c;
             scnt[sidx] = c;
         }
@@ -738,7 +762,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         if (tid == 0) ctl[0] += red[0] + red[1] + red[2] + red[3];
         __syncthreads();
     }
-    for (uint32_t e = (uint32_t)tid; e < p.n_stripes * p.kl; e += 256) { // gather: all loads independent
+    for (uint32_t e = (uint32_t)tid; e < n_stripes * p.kl; e += 256) { // gather: all loads independent
         const uint32_t sidx = e / p.kl, i = e % p.kl;
         if (i < scnt[sidx]) {
             const size_t lb = ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ); // entry-major lists
@@ -841,20 +865,48 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (tid == 0) out_count[q] = nout;
 }
 
-// ids of rows that are live (and allowed): wave-aggregated atomic compaction.  Order is arbitrary;
-// results do not depend on it because selection uses the total order (key, id).
-__global__ void compact_ids_kernel(const uint32_t *deleted, const uint32_t *allow, uint32_t count, uint32_t *out,
-                                   uint32_t *out_n) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x + 1u;
-    bool keep = id <= count;
-    if (keep && ((deleted[id >> 5] >> (id & 31)) & 1u)) keep = false;
-    if (keep && allow && !((allow[id >> 5] >> (id & 31)) & 1u)) keep = false;
-    const unsigned long long m = __ballot(keep);
-    if (!m) return;
-    uint32_t base = 0;
-    if (kdb_lane() == __builtin_ctzll(m)) base = atomicAdd(out_n, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, __builtin_ctzll(m), 64);
-    if (keep) out[base + kdb_mbcnt(m)] = id;
+// ids of rows that are live (and allowed).  One thread per 32-bit word of the bitsets, one atomic per WORKGROUP
+// (8192 ids): a 1 % filter over 10M ids used to issue ~160k wave-level atomics on the one counter and spent
+// 0.8 ms there.  Order is arbitrary; results do not depend on it because selection uses the total order (key, id).
+// first_allowed (nullable): smallest id of the allow list, 0xffffffff when the list is EMPTY = no filter
+// (allowList.IsEmpty(), vector_index.go:130) -- decided here, on the device.
+__global__ void __launch_bounds__(256)
+compact_ids_kernel(const uint32_t *deleted, const uint32_t *allow, const uint32_t *first_allowed, uint32_t count,
+                   uint32_t *out, uint32_t *out_n) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t blk_base;
+    if (allow && first_allowed && *first_allowed == 0xffffffffu) allow = nullptr;
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x; // word index: ids 32w .. 32w+31
+    const uint32_t nwords = (count >> 5) + 1u;
+    uint32_t m = 0;
+    if (w < nwords) {
+        m = ~deleted[w];
+        if (allow) m &= allow[w];
+        if (w == 0) m &= ~1u; // id 0 does not exist
+        const uint32_t last = count & 31u; // ids above count
+        if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
+    }
+    const uint32_t c = (uint32_t)__builtin_popcount(m);
+    uint32_t inc = c; // wave-inclusive scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
+    }
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        blk_base = tot ? atomicAdd(out_n, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = blk_base + inc - c;
+    for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) pos += wsum[i];
+    while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        out[pos++] = w * 32u + bit;
+    }
 }
 
 __global__ void any_bit_kernel(const uint32_t *bits, uint32_t words, uint32_t *out) {
@@ -940,8 +992,8 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
 }
 
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
-                         uint32_t k, const uint32_t *d_allow, int filter, uint32_t *d_out_ids, float *d_out_dist,
-                         uint32_t *d_out_count, hipStream_t s) {
+                         uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
+                         float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
     if (k == 0 || k > 128) {
         kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
         return KDB_ERR_INVALID;
@@ -957,12 +1009,12 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u && v.precision != KDB_PREC_I8;
 
-    // ---- scan list
-    uint32_t n_scan = v.count;
-    const uint32_t *scan_ids = nullptr;
-    // scratch layout: [scan_ids: count u32][n_scan word + flag (64 B)][partials]
+    // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
+    //      waits for the device: the number of rows to scan stays in HBM and every kernel derives the stripe
+    //      geometry from it (fs_resolve).
+    // scratch layout: [scan_ids: count u32][n_scan word (256 B)][partials]
     const size_t ids_bytes = ((size_t)v.count * 4 + 255) / 256 * 256;
-    const bool need_ids = filter || idx->n_deleted > 0;
+    const bool need_ids = d_allow != nullptr || idx->n_deleted > 0;
     uint32_t stripes_max = FS_MAX_MERGE / kl;
     if (stripes_max < 1) stripes_max = 1;
     // stripes: ONE round of resident workgroups (two fit a CU: 512 in all).  Every stripe pays a start-up phase
@@ -971,59 +1023,50 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     uint32_t want = 512 / (small ? n_q16 : n_qtiles);
     if (want < 1) want = 1;
     if (want > stripes_max) want = stripes_max;
-    const size_t max_part = (size_t)want * n_qtiles * FS_TQ;
+    const uint32_t min_tiles = small ? 4u : 8u;
+    {   // never more stripes than the index could fill
+        const uint32_t max_tiles = (v.count + FS_TR - 1) / FS_TR;
+        const uint32_t lim = (max_tiles + min_tiles - 1) / min_tiles;
+        if (want > lim) want = lim;
+        if (want < 1) want = 1;
+    }
+    const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
     // buffered mode: kl entries + room for max(kl, 64) appends between two compactions (<= 320 in all)
     const uint32_t cap = (small || kl <= (uint32_t)FS_LDS_KL) ? kl : kl + (kl > 64u ? kl : 64u);
-    const size_t part_bytes = max_part * cap * 8 + max_part * 4 + 1024;
+    const size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
     int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + part_bytes + (size_t)n_qtiles * FS_TQ * v.ld * 4 + 4096);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
-    // region 0 (queries, written by the caller) sits at the END of scratch: see kdb_api
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
     uint32_t *d_nscan = reinterpret_cast<uint32_t *>(base + ids_bytes);
     unsigned char *part = base + ids_bytes + 256;
     if (need_ids) {
         KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
-        const uint32_t *use_allow = filter ? d_allow : nullptr;
-        hipLaunchKernelGGL(compact_ids_kernel, dim3((v.count + 255) / 256), dim3(256), 0, s, v.deleted, use_allow, v.count,
-                           d_ids, d_nscan);
+        hipLaunchKernelGGL(compact_ids_kernel, dim3(((v.count >> 5) + 256) / 256), dim3(256), 0, s, v.deleted, d_allow, d_first_allowed,
+                           v.count, d_ids, d_nscan);
         KDB_HIP(hipGetLastError());
-        KDB_HIP(hipMemcpyAsync(&n_scan, d_nscan, 4, hipMemcpyDeviceToHost, s));
-        KDB_HIP(hipStreamSynchronize(s));
-        scan_ids = d_ids;
     }
-    if (n_scan == 0) {
-        KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
-        KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
-        return KDB_OK;
-    }
-    uint32_t n_tiles = (n_scan + FS_TR - 1) / FS_TR;
-    uint32_t n_stripes = want;
-    const uint32_t min_tiles = small ? 4u : 8u;
-    if (n_stripes > (n_tiles + min_tiles - 1) / min_tiles) n_stripes = (n_tiles + min_tiles - 1) / min_tiles;
-    if (n_stripes < 1) n_stripes = 1;
-    uint32_t tiles_per = (n_tiles + n_stripes - 1) / n_stripes;
-    n_stripes = (n_tiles + tiles_per - 1) / tiles_per;
 
     FsParams p;
-    p.scan_ids = scan_ids;
-    p.n_scan = n_scan;
-    p.rows_per_stripe = tiles_per * FS_TR;
-    p.n_stripes = n_stripes;
+    p.scan_ids = need_ids ? d_ids : nullptr;
+    p.n_scan = v.count;
+    p.n_scan_dev = need_ids ? d_nscan : nullptr;
+    p.want = want;
+    p.min_tiles = min_tiles;
     p.n_qtiles = n_qtiles;
     p.B = B;
     p.kl = kl;
     p.cap = cap;
-    const size_t n_part = (size_t)n_stripes * n_qtiles * FS_TQ;
     p.part_key = reinterpret_cast<float *>(part);
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * cap * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * cap * 8);
+    const uint32_t n_stripes = want; // upper bound: workgroups of stripes past the resolved count return at once
 
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
                        (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 32;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
-    (void)kdb_stats_begin(idx, 2, B, 0);
+    p.ctr = kdb_stats_begin(idx, 2, B, 0);
     KDB_HIP(hipEventRecord(idx->ev0, s));
     auto launch_scan = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1048,7 +1091,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)n_stripes * 8 + 16;
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,

@@ -665,22 +665,19 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
         KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
         return KDB_OK;
     }
-    int filter = 0;
     const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
-    if (d_allow) { // allowList.IsEmpty() => no filter (vector_index.go:130)
-        uint32_t first = 0xffffffffu;
+    const uint32_t *d_first = nullptr;
+    if (d_allow) { // allowList.IsEmpty() => no filter (vector_index.go:130): decided on the device, no host round trip
         int rc = kdb_launch_first_allowed(d_allow, 2 * ((idx->count >> 6) + 1), idx->d_work + 8, s);
         if (rc) return rc;
-        KDB_HIP(hipMemcpyAsync(&first, idx->d_work + 8, 4, hipMemcpyDeviceToHost, s));
-        KDB_HIP(hipStreamSynchronize(s));
-        filter = first != 0xffffffffu;
+        d_first = idx->d_work + 8;
     }
     const uint32_t Bpad = (B + 127u) & ~127u;
     void *d_q = nullptr;
     float *d_qnorm = nullptr;
     int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
-    rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, filter, d_out_ids, d_out_dist, d_out_count, s);
+    rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, d_first, d_out_ids, d_out_dist, d_out_count, s);
     if (rc) return rc;
     return KDB_OK;
 }
@@ -858,7 +855,8 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
         r.n_hops = c[1];
         r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
     } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
-        r.bytes = (uint64_t)(idx->count - idx->n_deleted) * row_bytes + (uint64_t)idx->ring_B[slot] * row_bytes;
+        r.n_dist = c[0] * (uint64_t)idx->ring_B[slot]; // rows scanned (after filter / deletes) x queries
+        r.bytes = c[0] * row_bytes + (uint64_t)idx->ring_B[slot] * row_bytes;
     } else if (kind == 3) {
         r.n_dist = (uint64_t)idx->ring_B[slot] * idx->ring_C[slot];
         r.bytes = r.n_dist * row_bytes + r.n_dist * 8 + (uint64_t)idx->ring_B[slot] * row_bytes;
