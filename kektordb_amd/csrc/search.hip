@@ -36,7 +36,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, KDB_SEARCH_MINW)
+__global__ void __launch_bounds__(64, (NCH > 12 ? 2 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
@@ -443,6 +443,8 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
     case 128: return launch_search_t<KDB_PREC_F32, M, 2>(KDB_ARGS);                           \
     case 384: return launch_search_t<KDB_PREC_F32, M, 6>(KDB_ARGS);                           \
     case 768: return launch_search_t<KDB_PREC_F32, M, 12>(KDB_ARGS);                          \
+    case 1024: return launch_search_t<KDB_PREC_F32, M, 16>(KDB_ARGS);                         \
+    case 1536: return launch_search_t<KDB_PREC_F32, M, 24>(KDB_ARGS);                         \
     default: return launch_search_t<KDB_PREC_F32, M, 0>(KDB_ARGS);                            \
     }
         if (v.metric == KDB_METRIC_L2) { KDB_F32(KDB_METRIC_L2) }

@@ -92,5 +92,28 @@ else:               # 10M x 1536 cosine, clustered, category filter at 1% select
     kms = [c["kernel_ms"] for c in idx.launch_stats(min(len(groups), 64))]
     grouped = {"groups": len(groups), "ms": round(tg2 * 1e3, 2), "qps": round(B / tg2), "scan_kernel_ms_mean": round(float(np.mean(kms)), 3),
                "scan_kernel_GBps": round(float(np.mean([c["bytes"] for c in idx.launch_stats(min(len(groups), 64))])) / float(np.mean(kms)) / 1e6, 1)}
+    hn = None
+    if a.hnsw:  # the reference's own filtered path: HNSW traversal with the allow list (hnsw_index.go:2480-2549)
+        _, tb = timed(lambda: idx.build(n, batch=16384, ef_construction=200, seed=1))
+        ids0 = (torch.nonzero(cat == 0).flatten() + 1).cpu().numpy()
+        ab0 = torch.from_numpy(dense_bitset(ids0, n).view(np.int64)).to(dev)
+        idx.flat_scan_batch_dev(Q, k, oi, od, oc, d_allow=ab0); idx.sync()
+        gt = oi.cpu().numpy().copy()
+        hn = {"build_s": round(tb, 1), "filtered": [], "unfiltered": []}
+        for ef in (64, 256, 1024):
+            idx.search_batch_dev(Q, k, ef, oi, od, oc, ab0); idx.sync()
+            _, th = timed(lambda: (idx.search_batch_dev(Q, k, ef, oi, od, oc, ab0), idx.sync()))
+            got = oi.cpu().numpy()
+            hn["filtered"].append({"ef": ef, "ms": round(th * 1e3, 2), "qps": round(B / th),
+                                   "recall_vs_exact_filtered": round(float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(B)])), 4),
+                                   "n_dist_per_query": round(idx.launch_stats(1)[0]["n_dist"] / B, 1)})
+        idx.flat_scan_batch_dev(Q, k, oi, od, oc); idx.sync()
+        gt = oi.cpu().numpy().copy()
+        for ef in (64, 128):
+            idx.search_batch_dev(Q, k, ef, oi, od, oc); idx.sync()
+            _, th = timed(lambda: (idx.search_batch_dev(Q, k, ef, oi, od, oc), idx.sync()))
+            got = oi.cpu().numpy()
+            hn["unfiltered"].append({"ef": ef, "ms": round(th * 1e3, 2), "qps": round(B / th),
+                                     "recall": round(float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(B)])), 4)})
     print(json.dumps({"config": 5, "rows": n, "dim": dim, "gen_s": round(tg, 1), "upload_s": round(tu, 1), "filtered_scan": res,
-                      "per_query_category_grouped": grouped}))
+                      "per_query_category_grouped": grouped, "hnsw": hn}))
