@@ -64,7 +64,7 @@ struct BuildView {
 };
 
 // ---- phase 1 ------------------------------------------------------------------------------------
-template <int METRIC, int BS>
+template <int METRIC, int BS, int PREC>
 __global__ void __launch_bounds__(64)
 build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,7 +94,10 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         const uint32_t node = bv.first + bi;
         const int L = (int)v.levels[node];
         vis.begin_query();
-        {
+        if (PREC == KDB_PREC_F16) { // the node's own f16 row, widened (exactly) to the f32 query the search keeps in LDS
+            const uint16_t *src = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)node * v.ld;
+            for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = (float)__builtin_bit_cast(_Float16, src[i]);
+        } else {
             const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)node * v.ld);
             float4 *dst = reinterpret_cast<float4 *>(s.q);
             for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
@@ -106,7 +109,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         uint32_t ep = v.entry;
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;
-            search_layer<KDB_PREC_F32, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, ctr);
+            search_layer<PREC, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, ctr);
             if (insert) {
                 const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
                 const uint32_t nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc,
@@ -163,7 +166,7 @@ __device__ __forceinline__ void prune_carve(unsigned char *smem, PruneLds &p) {
 }
 
 // candidates c_id/c_key[0..n) sorted ascending -> s_id/s_key[0..n_sel). Whole workgroup (256 threads).
-template <int METRIC>
+template <int METRIC, int PREC>
 __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_t n, uint32_t maxm) {
     const int tid = (int)threadIdx.x;
     if (tid == 0) {
@@ -181,6 +184,7 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
         return;
     }
     const float *rows = reinterpret_cast<const float *>(v.rows);
+    const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: widened (exactly) into the f32 LDS tile
     for (uint32_t b0 = 0; b0 < n; b0 += PR_BLK) {
         const uint32_t nb = n - b0 < PR_BLK ? n - b0 : PR_BLK;
         const uint32_t ns = p.misc[0];
@@ -213,7 +217,17 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
                 const uint32_t id = r < nb ? p.c_id[b0 + r] : p.s_id[r - nb];
                 const uint32_t lr = r < nb ? r : PR_BLK + (r - nb);
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kc + c4 * 4 < v.ld) x = *reinterpret_cast<const float4 *>(rows + (size_t)id * v.ld + kc + c4 * 4);
+                if (kc + c4 * 4 < v.ld) {
+                    if (PREC == KDB_PREC_F16) {
+                        const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)id * v.ld + kc + c4 * 4);
+                        x = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)),
+                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
+                    } else {
+                        x = *reinterpret_cast<const float4 *>(rows + (size_t)id * v.ld + kc + c4 * 4);
+                    }
+                }
                 *reinterpret_cast<float4 *>(p.rows + (size_t)lr * PR_STRIDE + c4 * 4) = x;
             }
             __syncthreads();
@@ -298,7 +312,7 @@ __device__ __forceinline__ bool key_before(float k1, uint32_t i1, float k2, uint
 }
 
 // ---- phase 2: new node keeps selectNeighbors(cands); emits reverse requests ---------------------------
-template <int METRIC>
+template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
 build_select_kernel(KdbView v, BuildView bv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -331,7 +345,7 @@ build_select_kernel(KdbView v, BuildView bv) {
         p.c_key[i] = bv.cand_key[(size_t)task * bv.efc + i];
     }
     __syncthreads();
-    select_neighbors_wg<METRIC>(v, p, n, maxm);
+    select_neighbors_wg<METRIC, PREC>(v, p, n, maxm);
     const uint32_t nsel = p.misc[0];
     uint32_t *adj;
     float *akey;
@@ -376,7 +390,7 @@ build_select_kernel(KdbView v, BuildView bv) {
 }
 
 // ---- phase 3: per-target commit -----------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
 build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -451,7 +465,7 @@ build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
         p.c_key[rank] = my_key;
     }
     __syncthreads();
-    select_neighbors_wg<METRIC>(v, p, n, maxm);
+    select_neighbors_wg<METRIC, PREC>(v, p, n, maxm);
     const uint32_t nsel = p.misc[0];
     if ((uint32_t)tid < maxm) {
         adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
@@ -473,7 +487,7 @@ int occupancy_blocks(K kern, int threads, size_t lds) {
     return nb;
 }
 
-template <int METRIC>
+template <int METRIC, int PREC>
 int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     hipStream_t s = idx->stream;
     const uint32_t efc = bp && bp->ef_construction ? bp->ef_construction : idx->desc.ef_construction;
@@ -561,9 +575,9 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     const size_t lds_prune = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
                              (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
     const int bs = kdb_beam_slots(efc);
-    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2> : bs == 4 ? build_search_kernel<METRIC, 4> : build_search_kernel<METRIC, 6>;
-    auto kselect = build_select_kernel<METRIC>;
-    auto krev = build_reverse_kernel<METRIC>;
+    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
+    auto kselect = build_select_kernel<METRIC, PREC>;
+    auto krev = build_reverse_kernel<METRIC, PREC>;
     if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
     hipDeviceProp_t prop;
     KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
@@ -643,14 +657,15 @@ int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
         kdb_set_error("build: count %u outside 1..%u", count, idx->cap);
         return KDB_ERR_INVALID;
     }
-    if (idx->desc.precision != KDB_PREC_F32) {
-        kdb_set_error("build: GPU construction supports float32 rows only in this version");
+    if (idx->desc.precision == KDB_PREC_I8) { // the reference never builds an int8 graph from scratch: Compress keeps the f32 graph
+        kdb_set_error("build: GPU construction supports float32 and float16 rows (int8 indexes keep the graph they were compressed from)");
         return KDB_ERR_UNSUPPORTED;
     }
     if (idx->deg0 > PR_MAXSEL) {
         kdb_set_error("build: mMax0 %u exceeds %d", idx->deg0, PR_MAXSEL);
         return KDB_ERR_UNSUPPORTED;
     }
-    return idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE>(idx, count, p)
-                                                 : build_impl<KDB_METRIC_L2>(idx, count, p);
+    if (idx->desc.precision == KDB_PREC_F16) return build_impl<KDB_METRIC_L2, KDB_PREC_F16>(idx, count, p); // f16 is euclidean only
+    return idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE, KDB_PREC_F32>(idx, count, p)
+                                                 : build_impl<KDB_METRIC_L2, KDB_PREC_F32>(idx, count, p);
 }

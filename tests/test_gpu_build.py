@@ -94,3 +94,37 @@ def test_build_quality_close_to_sequential_add(oracle, hip):
         ids, _, _ = idx.search_batch(Q, 10, 50)
         rec.append(np.mean([len(set(ids[i].tolist()) & set(fi[i].tolist())) / 10 for i in range(100)]))
     assert rec[1] >= rec[0] - 0.03, rec
+
+
+def test_build_f16(oracle, hip):
+    """float16 index (euclidean only, hnsw_index.go:210-213): the GPU builder runs its searches and its
+    selectNeighbors on the f16 rows; the oracle searching the GPU-built graph over the same f16 rows returns
+    exactly what the HIP search returns"""
+    O = oracle
+    n, dim = 5000, 96
+    XQ = make_corpus(n + 60, dim, "clustered", seed=31).astype(np.float32)
+    X16 = XQ[:n].astype(np.float16)
+    Q = np.ascontiguousarray(XQ[n:])
+    idx = hip.HipIndex(dim, 0, O.F16, 16, 100, capacity=n)
+    idx.upload_rows(X16.view(np.uint16), 1)
+    idx.build(n, batch=1024, ef_construction=100, seed=5)
+    g = as_graph(idx.download_graph())
+    assert g.count == n and g.max_level >= 1
+    deg0 = np.diff(g.offsets[0][:n + 2].astype(np.int64))
+    assert deg0.max() <= 32 and (deg0[1:] > 0).mean() > 0.999
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 100, trace=True)
+    fi, fd, fc = idx.flat_scan_batch(Q, 10)
+    rec = np.mean([len(set(ids[b].tolist()) & set(fi[b].tolist())) / 10 for b in range(Q.shape[0])])
+    assert rec >= 0.90, rec
+    rows = np.zeros((n + 1, dim), dtype=np.uint16)
+    rows[1:] = X16.view(np.uint16)
+    from oracle.oracle import Graph
+    og = Graph(g.count, g.levels, g.max_level, g.entry, g.offsets, g.neighbors, g.deleted_bits)
+    orc = O.OracleIndex.from_graph(dim, 0, O.F16, 16, 100, rows, og)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    for b in range(30):
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=100, counters=True)
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], oi)
+        assert np.array_equal(dist[b, :c].astype(np.float64), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
