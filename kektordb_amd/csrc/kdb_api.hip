@@ -123,7 +123,7 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
     idx->last_kind = kind;
     idx->last_B = B;
     idx->last_C = C;
-    return idx->d_ctr + (size_t)slot * 2;
+    return idx->d_ctr + (size_t)slot * 4; // [0] n_dist / rows scanned, [1] n_hops, [2] work counter of the launch
 }
 
 int kdb_ensure_retry(kdb_index *idx, uint32_t n) {
@@ -242,8 +242,8 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     KDB_TRY(hipMemsetAsync(idx->d_deleted, 0, dw * 4, idx->stream));
     KDB_TRY(hipMalloc(&idx->d_work, 64 * 4));
     KDB_TRY(hipMemsetAsync(idx->d_work, 0, 64 * 4, idx->stream));
-    KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 16));
-    KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 16, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 32));
+    KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 32, idx->stream));
     KDB_TRY(hipStreamSynchronize(idx->stream));
 #undef KDB_TRY
     *out = idx;
@@ -564,10 +564,19 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         }
         if (!ep_allowed) entry = first;
     }
-    void *d_q = nullptr;
+    // float32 / float16 indexes: the search kernel prepares each query itself while it loads it into LDS (normalise for
+    // cosine, f16 round trip) straight from the caller's buffer; int8 needs the quantised copy + the query norms
+    const void *d_q = d_queries;
     float *d_qnorm = nullptr;
-    int rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_q, &d_qnorm, s);
-    if (rc) return rc;
+    uint32_t raw = 1u | ((idx->desc.metric == KDB_METRIC_COSINE && !(flags & KDB_SEARCH_PREPARED)) ? 2u : 0u);
+    int rc = KDB_OK;
+    if (idx->desc.precision == KDB_PREC_I8) {
+        void *d_qp = nullptr;
+        rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_qp, &d_qnorm, s);
+        if (rc) return rc;
+        d_q = d_qp;
+        raw = 0;
+    }
     uint32_t *tr_nd = nullptr, *tr_nh = nullptr;
     if (idx->trace_ndist && idx->trace_on_device) {
         tr_nd = idx->trace_ndist;
@@ -578,7 +587,7 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         tr_nd = reinterpret_cast<uint32_t *>(idx->d_scratch);
         tr_nh = tr_nd + B;
     }
-    rc = kdb_launch_search(idx, v, d_q, d_qnorm, B, k, effective_ef(ef, flags), d_allow, entry, d_out_ids, d_out_dist,
+    rc = kdb_launch_search(idx, v, d_q, d_qnorm, raw, B, k, effective_ef(ef, flags), d_allow, entry, d_out_ids, d_out_dist,
                            d_out_count, tr_nd, tr_nh, s);
     if (rc) return rc;
     if (idx->trace_ndist && !idx->trace_on_device) {
@@ -845,7 +854,7 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     if (hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
         hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess)
         ms = 0.f;
-    KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 2, 16, hipMemcpyDeviceToHost));
+    KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 4, 16, hipMemcpyDeviceToHost));
     kdb_counters r{};
     r.last_kernel_ms = ms;
     const uint64_t row_bytes = (uint64_t)idx->desc.dim * idx->elem;

@@ -109,7 +109,7 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
 // search.hip
 int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, void *d_out, float *d_qnorm,
                             int normalize, hipStream_t s);
-int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
                       uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s);

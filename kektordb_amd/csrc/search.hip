@@ -37,7 +37,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
 __global__ void __launch_bounds__(64, (NCH > 12 ? 2 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
-hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t B,
+hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
                    unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
@@ -91,6 +91,40 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
             for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
             qnorm = qnorms[qi];
+        } else if (raw) {
+            // the caller's own [B][dim] f32 buffer: query preparation (hnsw_index.go:404-434) happens here, no
+            // separate pass over the batch.  raw & 2: cosine => normalise (:3030-3045): sequential f32 sum of
+            // squares in index order, f64 sqrt, f32 multiply; a zero vector stays untouched.  Every lane runs the
+            // same sequential sum on broadcast LDS reads (no divergence, every lane ends with the sum).
+            const float *src = reinterpret_cast<const float *>(queries) + (size_t)qi * v.dim;
+            for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = i < v.dim ? src[i] : 0.f;
+            wave_lds_fence();
+            if (raw & 2u) {
+                float nsq = 0.f;
+                const uint32_t d4 = v.dim & ~3u;
+                for (uint32_t i = 0; i < d4; i += 4) {
+                    const float4 y = *reinterpret_cast<const float4 *>(s.q + i);
+                    float sq = y.x * y.x;
+                    nsq = nsq + sq;
+                    sq = y.y * y.y;
+                    nsq = nsq + sq;
+                    sq = y.z * y.z;
+                    nsq = nsq + sq;
+                    sq = y.w * y.w;
+                    nsq = nsq + sq;
+                }
+                for (uint32_t i = d4; i < v.dim; i++) {
+                    const float y = s.q[i];
+                    const float sq = y * y;
+                    nsq = nsq + sq;
+                }
+                if (nsq > 0.f) {
+                    const float inv = 1.0f / (float)sqrt((double)nsq);
+                    for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = s.q[i] * inv;
+                }
+            }
+            if (PREC == KDB_PREC_F16) // RNE round trip, as float16.Fromfloat32 (hnsw_index.go:425)
+                for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = (float)(_Float16)s.q[i];
         } else {
             const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) +
                                                                  (size_t)qi * v.ld);
@@ -373,7 +407,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 }
 
 template <int PREC, int METRIC, int NCH, int BS>
-static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
                             uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                             float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                             hipStream_t s) {
@@ -401,11 +435,10 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         int rc = kdb_ensure_visited(idx, grid);
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
-        KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
-        KDB_HIP(hipMemsetAsync(d_ctr, 0, 16, s));
+        KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, B, k, eff, d_allow, entry, beam_cap, vis_size,
-                           idx->d_visited, idx->d_work, d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, entry, beam_cap, vis_size,
+                           idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
@@ -417,12 +450,12 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
 }
 
 template <int PREC, int METRIC, int NCH>
-static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
                            uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                            float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef;
-#define KDB_A idx, v, d_q, d_qnorm, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+#define KDB_A idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
     switch (kdb_beam_slots(eff)) { // beam in registers (2/4/6 slots of 64 entries) or in LDS
     case 2: return launch_search_bs<PREC, METRIC, NCH, 2>(KDB_A);
     case 4: return launch_search_bs<PREC, METRIC, NCH, 4>(KDB_A);
@@ -432,11 +465,11 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
 #undef KDB_A
 }
 
-int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
                       uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s) {
-#define KDB_ARGS idx, v, d_q, d_qnorm, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+#define KDB_ARGS idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
     if (v.precision == KDB_PREC_F32) { // common row widths get fully unrolled row loads (NCH = ld/64)
 #define KDB_F32(M)                                                                            \
     switch (v.ld) {                                                                           \
