@@ -65,6 +65,50 @@ __device__ __forceinline__ int kdb_wave_sum_i(int v) {
 // t = lane & 15.  Lane t visits the 16-byte chunks c = t, t+16, ...; component j of each chunk
 // feeds accumulator j (f16: j & 3); partial = (a0+a1)+(a2+a3).  The caller reduces with
 // kdb_reduce16().  `row` may point at row 0 (all zero) for inactive groups.
+// Two rows at once (f32, ld == 64*NCH): all 2*NCH row loads are issued before the first FMA, so a hop with 5-8 new
+// neighbours costs ONE HBM round trip instead of two; every query fragment is read from LDS once for both rows.
+// Per row the accumulation order is exactly that of kdb_row_partial_f32.
+template <int METRIC, int NCH>
+__device__ __forceinline__ void kdb_row_partial2_f32(const float *__restrict__ row0, const float *__restrict__ row1,
+                                                     const float *q, int t, float &p0, float &p1) {
+    const float4 *r0 = reinterpret_cast<const float4 *>(row0);
+    const float4 *r1 = reinterpret_cast<const float4 *>(row1);
+    const float4 *q4 = reinterpret_cast<const float4 *>(q);
+    float4 x0[NCH], x1[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) x0[i] = r0[t + 16 * i];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) x1[i] = r1[t + 16 * i];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const float4 y = q4[t + 16 * i];
+        if (METRIC == KDB_METRIC_L2) {
+            float d0 = y.x - x0[i].x, d1 = y.y - x0[i].y, d2 = y.z - x0[i].z, d3 = y.w - x0[i].w;
+            a0 = __builtin_fmaf(d0, d0, a0);
+            a1 = __builtin_fmaf(d1, d1, a1);
+            a2 = __builtin_fmaf(d2, d2, a2);
+            a3 = __builtin_fmaf(d3, d3, a3);
+            d0 = y.x - x1[i].x, d1 = y.y - x1[i].y, d2 = y.z - x1[i].z, d3 = y.w - x1[i].w;
+            b0 = __builtin_fmaf(d0, d0, b0);
+            b1 = __builtin_fmaf(d1, d1, b1);
+            b2 = __builtin_fmaf(d2, d2, b2);
+            b3 = __builtin_fmaf(d3, d3, b3);
+        } else {
+            a0 = __builtin_fmaf(y.x, x0[i].x, a0);
+            a1 = __builtin_fmaf(y.y, x0[i].y, a1);
+            a2 = __builtin_fmaf(y.z, x0[i].z, a2);
+            a3 = __builtin_fmaf(y.w, x0[i].w, a3);
+            b0 = __builtin_fmaf(y.x, x1[i].x, b0);
+            b1 = __builtin_fmaf(y.y, x1[i].y, b1);
+            b2 = __builtin_fmaf(y.z, x1[i].z, b2);
+            b3 = __builtin_fmaf(y.w, x1[i].w, b3);
+        }
+    }
+    p0 = (a0 + a1) + (a2 + a3);
+    p1 = (b0 + b1) + (b2 + b3);
+}
+
 template <int METRIC, int NCH = 0>
 __device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ row, const float *q, uint32_t ld,
                                                      int t) {

@@ -59,6 +59,30 @@ template <int PREC, int METRIC, int NCH = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
+    if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 12) { // 8 rows per round trip (two per 16-lane group)
+        for (uint32_t base = 0; base < n; base += 8) {
+            const uint32_t r0 = base + (uint32_t)g, r1 = r0 + 4u;
+            const bool act0 = r0 < n, act1 = r1 < n;
+            const uint32_t id0 = act0 ? s.nb_id[r0] : 0u; // row 0 is all zero
+            const float *row0 = reinterpret_cast<const float *>(v.rows) + (size_t)id0 * v.ld;
+            if (base + 4u < n) { // wave-uniform
+                const uint32_t id1 = act1 ? s.nb_id[r1] : 0u;
+                const float *row1 = reinterpret_cast<const float *>(v.rows) + (size_t)id1 * v.ld;
+                float p0, p1;
+                kdb_row_partial2_f32<METRIC, NCH>(row0, row1, s.q, t, p0, p1);
+                const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p0));
+                const float k1 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p1));
+                if (act0 && t == 0) s.nb_d[r0] = k0;
+                if (act1 && t == 0) s.nb_d[r1] = k1;
+            } else {
+                const float p = kdb_row_partial_f32<METRIC, NCH>(row0, s.q, v.ld, t);
+                const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p));
+                if (act0 && t == 0) s.nb_d[r0] = k0;
+            }
+        }
+        wave_lds_fence();
+        return;
+    }
     for (uint32_t base = 0; base < n; base += 4) {
         const uint32_t r = base + (uint32_t)g;
         const bool act = r < n;

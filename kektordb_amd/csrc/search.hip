@@ -36,7 +36,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, (NCH > 12 ? 2 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64, (NCH > 12 ? 2 : (NCH > 4 && PREC == KDB_PREC_F32) ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
