@@ -213,6 +213,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "recall_at_10": round(recall, 4),
+        # id-range sharding: EVERY query visits EVERY shard, so merged answers/s (`value`) is expected to stay flat
+        # with N while the corpus grows N x; the work the job does per second is this many per-shard searches
+        "work_per_s": {"value": round(world * B * a.steps / elapsed, 1), "unit": "query x shard searches/s",
+                       "corpus_rows": n * world,
+                       "note": "weak scaling of the CORPUS: value = merged answers/s over n_gpus x rows_per_gpu rows"},
         "config": {
             "workload": f"BASELINE configs[1]: {n}x{dim} cosine k={k}, batched-query HNSW on MI355X "
                         f"(M=16, efConstruction={a.efc}, efSearch={ef}, batch {B} queries/step)",
