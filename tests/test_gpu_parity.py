@@ -426,3 +426,61 @@ def test_search_beam_and_visited_variants(oracle, hip, ef):
         assert np.array_equal(ids[b, :c], oi), (ef, b)
         assert np.array_equal(dist[b, :c].astype(np.float64), od)
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
+
+
+def test_concurrent_search_delete_and_scan(oracle, hip):
+    """Several caller threads on ONE handle (cgo calls arrive on any OS thread; the reference stresses the same with
+    TestConcurrencyChaos / TestDeleteWhileSearching, hnsw_stress_test.go:110-114): searches, exact scans and soft
+    deletes interleave; every answer has <= k entries, sorted, and never names an id whose delete had already
+    returned when the search was issued."""
+    import threading
+    O = oracle
+    n, dim, k = 4000, 64, 10
+    X = make_corpus(n, dim, "uniform", seed=91)
+    orc, idx = build_pair(O, hip, X, 0, efc=40)
+    Q = make_corpus(64, dim, "uniform", seed=92)
+    deleted_done = []      # ids whose mark_deleted call has returned
+    lock = threading.Lock()
+    errors = []
+
+    def searcher(flat):
+        try:
+            for it in range(25):
+                with lock:
+                    gone = set(deleted_done)
+                if flat:
+                    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+                else:
+                    ids, dist, cnt = idx.search_batch(Q, k, 40)
+                for b in range(Q.shape[0]):
+                    c = int(cnt[b])
+                    assert 0 < c <= k
+                    assert np.all(np.diff(dist[b, :c]) >= 0)
+                    assert not (set(ids[b, :c].tolist()) & gone), "deleted id returned"
+        except Exception as e:  # pragma: no cover - reported below
+            errors.append(repr(e))
+
+    def deleter():
+        try:
+            for d in range(5, n, 37):
+                idx.Delete([d])
+                with lock:
+                    deleted_done.append(d)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=searcher, args=(False,)) for _ in range(3)]
+    ts += [threading.Thread(target=searcher, args=(True,)), threading.Thread(target=deleter)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    # after the dust settles the index answers exactly like the oracle with the same deletes
+    for d in deleted_done:
+        orc.mark_deleted(int(d))
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    ids, dist, cnt = idx.search_batch(Q[:8], k, 40)
+    for b in range(8):
+        oi, od = orc.search(Q[b], k, ef=40)
+        assert np.array_equal(ids[b, :int(cnt[b])], oi)
