@@ -153,6 +153,17 @@ KDB_API int kdb_index_download_graph(kdb_index *idx, uint8_t *levels, uint64_t *
                              uint32_t *const *neighbors, uint64_t *level_sizes);
 KDB_API int kdb_index_download_rows(kdb_index *idx, uint32_t first_id, uint32_t n, void *rows);
 
+/* Heterogeneous batch: what a micro-batcher hands over when concurrent SearchWithScores callers carry DIFFERENT
+ * allow lists (ops.go builds one roaring bitmap per request).  d_allow_lists holds G dense bitsets back to back,
+ * words_per_list (>= (count>>6)+1) uint64 words each; query b uses list d_allow_of_query[b], KDB_NO_FILTER = no
+ * list.  Per query the result is exactly that of kdb_search_batch with its list (entry-point substitution, empty
+ * list => no results, hnsw_index.go:437-447, decided per list on the device).  Device pointers.                */
+#define KDB_NO_FILTER 0xffffffffu
+KDB_API int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
+                               const uint64_t *d_allow_lists, uint32_t G, uint64_t words_per_list,
+                               const uint32_t *d_allow_of_query, uint32_t flags, uint32_t *d_out_ids,
+                               float *d_out_dist, uint32_t *d_out_count, void *stream);
+
 /* SearchWithScores for B queries.  queries: [B][dim] f32, un-normalised (the library performs the
  * reference's query prep, hnsw_index.go:404-434).  allow_bits: NULL (nil allow-list) or
  * ((count>>6)+1) uint64 words (a zero bitmap is the non-nil EMPTY list -> zero results).

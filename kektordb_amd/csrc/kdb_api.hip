@@ -526,9 +526,15 @@ static uint32_t effective_ef(uint32_t ef, uint32_t flags) {
     return ef;
 }
 
+struct MultiLists { // heterogeneous batch (kdb_search_batch_multi_dev): G lists back to back + the list of every query
+    uint32_t G = 0;
+    uint64_t words64 = 0;
+    const uint32_t *d_of_query = nullptr;
+};
+
 static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
                              const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids, float *d_out_dist,
-                             uint32_t *d_out_count, hipStream_t s) {
+                             uint32_t *d_out_count, hipStream_t s, const MultiLists *ml = nullptr) {
     KdbView v = kdb_make_view(idx);
     if (B == 0) return KDB_OK;
     if (k == 0) {
@@ -546,7 +552,16 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
     }
     uint32_t entry = idx->entry;
     const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
-    if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447)
+    KdbMultiAllow ma;
+    if (ml && ml->G) { // one entry point per list, chosen on the device: no host round trip for any of the G lists
+        int rc = kdb_ensure_retry(idx, ml->G);
+        if (rc) return rc;
+        rc = kdb_launch_group_entries(v, d_allow, ml->G, (uint32_t)(ml->words64 * 2), entry, idx->d_retry, s);
+        if (rc) return rc;
+        ma.of_query = ml->d_of_query;
+        ma.group_entry = idx->d_retry;
+        ma.words32 = (uint32_t)(ml->words64 * 2);
+    } else if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447)
         uint32_t first = 0xffffffffu;
         int rc = kdb_launch_first_allowed(d_allow, 2 * ((idx->count >> 6) + 1), idx->d_work + 8, s);
         if (rc) return rc;
@@ -587,7 +602,7 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         tr_nd = reinterpret_cast<uint32_t *>(idx->d_scratch);
         tr_nh = tr_nd + B;
     }
-    rc = kdb_launch_search(idx, v, d_q, d_qnorm, raw, B, k, effective_ef(ef, flags), d_allow, entry, d_out_ids, d_out_dist,
+    rc = kdb_launch_search(idx, v, d_q, d_qnorm, raw, B, k, effective_ef(ef, flags), d_allow, ma, entry, d_out_ids, d_out_dist,
                            d_out_count, tr_nd, tr_nh, s);
     if (rc) return rc;
     if (idx->trace_ndist && !idx->trace_on_device) {
@@ -637,6 +652,33 @@ static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint
     KDB_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     KDB_HIP(hipStreamSynchronize(s));
     return KDB_OK;
+}
+
+extern "C" int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
+                                          const uint64_t *d_allow_lists, uint32_t G, uint64_t words_per_list,
+                                          const uint32_t *d_allow_of_query, uint32_t flags, uint32_t *d_out_ids,
+                                          float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0) return KDB_OK;
+    if (!d_queries || !d_out_ids || !d_out_dist || !d_out_count || k == 0) {
+        kdb_set_error("search_multi: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    if (G == 0 || !d_allow_lists || !d_allow_of_query) // no lists: the plain batch
+        return search_dev_locked(idx, d_queries, B, k, ef, nullptr, flags, d_out_ids, d_out_dist, d_out_count, s);
+    if (words_per_list < ((uint64_t)(idx->count >> 6) + 1)) {
+        kdb_set_error("search_multi: words_per_list %llu < (count>>6)+1 = %llu", (unsigned long long)words_per_list,
+                      (unsigned long long)(idx->count >> 6) + 1);
+        return KDB_ERR_INVALID;
+    }
+    MultiLists ml;
+    ml.G = G;
+    ml.words64 = words_per_list;
+    ml.d_of_query = d_allow_of_query;
+    return search_dev_locked(idx, d_queries, B, k, ef, d_allow_lists, flags, d_out_ids, d_out_dist, d_out_count, s, &ml);
 }
 
 extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef,

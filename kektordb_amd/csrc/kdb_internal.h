@@ -34,6 +34,14 @@ struct KdbView {
     uint32_t has_deleted;    // 0: no soft-deleted node, the per-neighbour Deleted lookup is skipped
 };
 
+// Heterogeneous batches: query b uses allow list of_query[b] (0xffffffff = none) of G dense bitsets laid out back to
+// back (words32 32-bit words each); group_entry[g] = the entry point of hnsw_index.go:437-447 for list g, 0 = no results.
+struct KdbMultiAllow {
+    const uint32_t *of_query = nullptr;
+    const uint32_t *group_entry = nullptr;
+    uint32_t words32 = 0;
+};
+
 struct kdb_index {
     kdb_index_desc desc;
     uint32_t ld = 0, deg0 = 0, deg_up = 0, cap = 0;
@@ -109,8 +117,10 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
 // search.hip
 int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, void *d_out, float *d_qnorm,
                             int normalize, hipStream_t s);
+int kdb_launch_group_entries(const KdbView &v, const uint32_t *d_allow_lists, uint32_t G, uint32_t words32, uint32_t entry,
+                             uint32_t *d_group_entry, hipStream_t s);
 int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
-                      uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                      uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s);
 int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,

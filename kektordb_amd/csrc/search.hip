@@ -38,7 +38,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
 __global__ void __launch_bounds__(64, (NCH > 12 ? 2 : (NCH > 4 && PREC == KDB_PREC_F32) ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
-                   uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, uint32_t entry,
+                   uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
                    unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
                    uint32_t *tr_ndist, uint32_t *tr_nhops) {
@@ -135,11 +135,21 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         wave_lds_fence();
 
         QCtr ctr{0, 0};
+        // the query's allow list and entry point: one list for the whole batch, or its own (heterogeneous batch)
+        const uint32_t *q_allow = allow;
         uint32_t ep = entry;
-        bool failed = false;
+        if (ma.of_query) {
+            const uint32_t g = ma.of_query[qi];
+            if (g == 0xffffffffu) q_allow = nullptr;
+            else {
+                q_allow = allow + (size_t)g * ma.words32;
+                ep = ma.group_entry[g]; // 0: empty list / no valid entry => no results (:437-447)
+            }
+        }
+        bool failed = ep == 0u;
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
-            search_layer<PREC, METRIC, NCH>(v, s, b, vis, allow, ep, l, 1u, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr);
             const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
@@ -151,7 +161,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
         uint32_t nout = 0;
         if (!failed) {
-            search_layer<PREC, METRIC, NCH>(v, s, b, vis, allow, ep, 0, ef, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
             // results = non traversal-only entries, ascending (:2596-2610), first k
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
                                    PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
@@ -323,6 +333,37 @@ prep_queries_kernel(KdbView v, const float *__restrict__ in, uint32_t B, void *o
     }
 }
 
+// Entry point per allow list of a heterogeneous batch (hnsw_index.go:437-447), one workgroup per list:
+// empty list -> 0 (no results); entry point allowed -> entry; else the smallest allowed id if it names a vector, else 0.
+__global__ void __launch_bounds__(256)
+group_entry_kernel(const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t entry, uint32_t *out) {
+    __shared__ uint32_t wmin[4];
+    const uint32_t *allow = lists + (size_t)blockIdx.x * words32;
+    uint32_t best = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < words32; i += 256) {
+        const uint32_t w = allow[i];
+        if (w) {
+            const uint32_t id = i * 32u + (uint32_t)__builtin_ctz(w);
+            if (id < best) best = id;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)best, o, 64);
+        best = t < best ? t : best;
+    }
+    if ((threadIdx.x & 63u) == 0) wmin[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t first = wmin[0];
+        for (int i = 1; i < 4; i++) first = wmin[i] < first ? wmin[i] : first;
+        const bool ep_allowed = ((allow[entry >> 5] >> (entry & 31u)) & 1u) != 0u;
+        uint32_t e = 0u;
+        if (first != 0xffffffffu) e = ep_allowed ? entry : ((first >= 1u && first <= count) ? first : 0u);
+        out[blockIdx.x] = e;
+    }
+}
+
 // smallest id set in the allow bitmap (allowList.Iterator().Next(), hnsw_index.go:437-447); 0 if none
 __global__ void first_allowed_kernel(const uint32_t *allow, uint32_t words, uint32_t *out) {
     uint32_t best = 0xffffffffu;
@@ -388,6 +429,14 @@ int kdb_launch_prep_queries(const KdbView &v, const float *d_in, uint32_t B, voi
     return KDB_OK;
 }
 
+int kdb_launch_group_entries(const KdbView &v, const uint32_t *d_allow_lists, uint32_t G, uint32_t words32, uint32_t entry,
+                             uint32_t *d_group_entry, hipStream_t s) {
+    if (G == 0) return KDB_OK;
+    hipLaunchKernelGGL(group_entry_kernel, dim3(G), dim3(256), 0, s, d_allow_lists, words32, v.count, entry, d_group_entry);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
 int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *d_out, hipStream_t s) {
     KDB_HIP(hipMemsetAsync(d_out, 0xff, 4, s));
     uint32_t blocks = (words + 255) / 256;
@@ -408,7 +457,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 
 template <int PREC, int METRIC, int NCH, int BS>
 static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
-                            uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                            uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
                             float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                             hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
@@ -437,7 +486,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, entry, beam_cap, vis_size,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
@@ -451,11 +500,11 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
 
 template <int PREC, int METRIC, int NCH>
 static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
-                           uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                           uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
                            float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef;
-#define KDB_A idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+#define KDB_A idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, ma, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
     switch (kdb_beam_slots(eff)) { // beam in registers (2/4/6 slots of 64 entries) or in LDS
     case 2: return launch_search_bs<PREC, METRIC, NCH, 2>(KDB_A);
     case 4: return launch_search_bs<PREC, METRIC, NCH, 4>(KDB_A);
@@ -466,10 +515,10 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
 }
 
 int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
-                      uint32_t k, uint32_t ef, const uint32_t *d_allow, uint32_t entry, uint32_t *d_out_ids,
+                      uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s) {
-#define KDB_ARGS idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
+#define KDB_ARGS idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, ma, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
     if (v.precision == KDB_PREC_F32) { // common row widths get fully unrolled row loads (NCH = ld/64)
 #define KDB_F32(M)                                                                            \
     switch (v.ld) {                                                                           \

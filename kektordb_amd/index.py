@@ -269,6 +269,19 @@ class HipIndex:
                                         _tptr(d_id_base), _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                         C.c_void_p(stream) if stream else None), "kdb_merge_topk_dev")
 
+    def search_batch_multi_dev(self, d_queries, k: int, ef: int, d_allow_lists, d_allow_of_query, d_out_ids, d_out_dist,
+                               d_out_count, stream=None):
+        """heterogeneous batch: d_allow_lists [G, words] int64/uint64 dense bitsets, d_allow_of_query [B] int32
+        (-1 = no filter); per query the result of search_batch with its own list"""
+        self._live()
+        _ready(stream)
+        B = int(d_queries.shape[0])
+        G, words = int(d_allow_lists.shape[0]), int(d_allow_lists.shape[1])
+        check(self.L.kdb_search_batch_multi_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow_lists), G, words,
+                                                _tptr(d_allow_of_query), self._flags(False), _tptr(d_out_ids), _tptr(d_out_dist),
+                                                _tptr(d_out_count), C.c_void_p(stream) if stream else None),
+              "kdb_search_batch_multi_dev")
+
     def merge_topk_packed_dev(self, G, B, k, d_packed, stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count,
                               stream=None):
         """merge over the packed per-shard blocks (ids | dist bits | count) that one all-gather delivers"""

@@ -484,3 +484,55 @@ def test_concurrent_search_delete_and_scan(oracle, hip):
     for b in range(8):
         oi, od = orc.search(Q[b], k, ef=40)
         assert np.array_equal(ids[b, :int(cnt[b])], oi)
+
+
+def test_search_heterogeneous_allow_lists(oracle, hip):
+    """kdb_search_batch_multi_dev: every query carries its own allow list (or none); per query the answer is
+    bit-exact what the oracle returns for that query with that list -- entry-point substitution, the non-nil EMPTY
+    list (no results), lists that name no vector (hnsw_index.go:437-447)."""
+    import torch
+    from kektordb_amd.index import dense_bitset
+    O = oracle
+    n, dim, k, ef = 3000, 48, 10, 50
+    X = make_corpus(n, dim, "uniform", seed=61)
+    orc, idx = build_pair(O, hip, X, 0, efc=60, deleted=list(range(7, n, 90)))
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(5)
+    words = (n >> 6) + 1
+    lists = []
+    for sel in (0.5, 0.2, 0.05):
+        a = np.nonzero(rng.random(n + 1) < sel)[0]
+        lists.append(dense_bitset(a[a >= 1], n))
+    lists.append(np.zeros(words, np.uint64))                    # EMPTY list: no results
+    lists.append(dense_bitset(np.array([1, 2, 3], np.uint64), n))  # tiny list
+    only_zero = np.zeros(words, np.uint64); only_zero[0] = 1    # bit of id 0 only: names no vector
+    lists.append(only_zero)
+    L = np.stack(lists)
+    B = 40
+    Q = make_corpus(B, dim, "uniform", seed=62)
+    of_q = rng.integers(-1, len(lists), size=B).astype(np.int32)  # -1 = no filter
+    of_q[:7] = [-1, 0, 1, 2, 3, 4, 5]
+    dev = torch.device("cuda:0")
+    dQ = torch.from_numpy(Q).to(dev)
+    dL = torch.from_numpy(L.view(np.int64)).to(dev)
+    dO = torch.from_numpy(of_q).to(dev)
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    od = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    idx.search_batch_multi_dev(dQ, k, ef, dL, dO, oi, od, oc)
+    idx.sync()
+    ids, dist, cnt = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy()
+    for b in range(B):
+        g = int(of_q[b])
+        want_i, want_d = orc.search(Q[b], k, ef=ef, allow=None if g < 0 else L[g])
+        c = int(cnt[b])
+        assert c == len(want_i), (b, g, c, len(want_i))
+        assert np.array_equal(ids[b, :c], want_i), (b, g)
+        assert np.array_equal(dist[b, :c].astype(np.float64), want_d), (b, g)
+    # and it agrees with the single-list entry point list by list
+    for g in range(len(lists)):
+        sel = np.nonzero(of_q == g)[0]
+        if sel.size == 0:
+            continue
+        i1, d1, c1 = idx.search_batch(Q[sel], k, ef, allow_bits=L[g])
+        assert np.array_equal(c1, cnt[sel]) and np.array_equal(i1, ids[sel])
