@@ -561,23 +561,15 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         ma.of_query = ml->d_of_query;
         ma.group_entry = idx->d_retry;
         ma.words32 = (uint32_t)(ml->words64 * 2);
-    } else if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447)
-        uint32_t first = 0xffffffffu;
-        int rc = kdb_launch_first_allowed(d_allow, 2 * ((idx->count >> 6) + 1), idx->d_work + 8, s);
+    } else if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447), decided on the device: an empty bitmap,
+        // or one whose smallest id names no vector while the entry point is not allowed, yields no results
+        const uint32_t words32 = 2u * ((idx->count >> 6) + 1u);
+        int rc = kdb_ensure_retry(idx, 1);
         if (rc) return rc;
-        uint32_t ep_word = 0;
-        KDB_HIP(hipMemcpyAsync(&first, idx->d_work + 8, 4, hipMemcpyDeviceToHost, s));
-        KDB_HIP(hipMemcpyAsync(&ep_word, d_allow + (entry >> 5), 4, hipMemcpyDeviceToHost, s));
-        KDB_HIP(hipStreamSynchronize(s));
-        const bool ep_allowed = ((ep_word >> (entry & 31)) & 1u) != 0;
-        // empty bitmap -> no results; an id-0 bit or ids beyond count never name a vector, so the
-        // reference's searchLayer would fail on the nil entry node and return [] as well
-        if (first == 0xffffffffu || (!ep_allowed && (first == 0 || first > idx->count))) {
-            KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
-            KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
-            return KDB_OK;
-        }
-        if (!ep_allowed) entry = first;
+        rc = kdb_launch_group_entries(v, d_allow, 1, words32, entry, idx->d_retry, s);
+        if (rc) return rc;
+        ma.group_entry = idx->d_retry; // of_query stays null: every query uses list 0
+        ma.words32 = words32;
     }
     // float32 / float16 indexes: the search kernel prepares each query itself while it loads it into LDS (normalise for
     // cosine, f16 round trip) straight from the caller's buffer; int8 needs the quantised copy + the query norms

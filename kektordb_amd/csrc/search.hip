@@ -138,8 +138,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         // the query's allow list and entry point: one list for the whole batch, or its own (heterogeneous batch)
         const uint32_t *q_allow = allow;
         uint32_t ep = entry;
-        if (ma.of_query) {
-            const uint32_t g = ma.of_query[qi];
+        if (ma.group_entry) { // of_query == nullptr: the whole batch shares list 0
+            const uint32_t g = ma.of_query ? ma.of_query[qi] : 0u;
             if (g == 0xffffffffu) q_allow = nullptr;
             else {
                 q_allow = allow + (size_t)g * ma.words32;
