@@ -188,6 +188,17 @@ KDB_API int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, uint
                             const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
                             float *d_out_dist, uint32_t *d_out_count, void *stream);
 
+/* Grouped exact scan -- the filtered path for a micro-batch whose callers carry DIFFERENT allow lists: the queries
+ * of group g are rows [group_offsets[g], group_offsets[g+1]) of d_queries (group_offsets: HOST array of G+1 entries,
+ * 0 ... B) and are scanned against the rows list g allows (a list that allows nothing yields no results; deleted
+ * rows never appear).  d_allow_lists: G dense bitsets back to back, words_per_list uint64 words each.
+ * max_total_allowed: an upper bound on the summed cardinalities of the lists (the shim has them from roaring in
+ * O(1)); 0 = let the library count (one small read-back).  float32 / float16 indexes.                          */
+KDB_API int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t G,
+                             const uint32_t *group_offsets, const uint64_t *d_allow_lists, uint64_t words_per_list,
+                             uint64_t max_total_allowed, uint32_t flags, uint32_t *d_out_ids, float *d_out_dist,
+                             uint32_t *d_out_count, void *stream);
+
 /* B queries x C candidate ids each (ids[B][C], id 0 = skip -> +inf): raw accumulates out[B][C].   */
 KDB_API int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t B, const uint32_t *ids, uint32_t C,
                        uint32_t flags, float *out);

@@ -18,6 +18,7 @@
 #include "kdb_device.cuh"
 #include <math.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -39,6 +40,11 @@ struct FsParams {
     uint32_t want, min_tiles; // stripe count asked for, fewest tiles worth a stripe
     uint32_t n_qtiles;
     unsigned long long *ctr;  // statistics slot: [0] = rows scanned
+    // grouped scan (one allow list per GROUP of queries, kdb_flat_scan_groups_dev); null = one list for the batch
+    const uint32_t *g_tile;   // [n_q16][3]: group, first query, number of queries (<= 16) of every 16-query tile
+    const uint32_t *g_nscan;  // [G] rows that survive group g's filter
+    const uint32_t *g_base;   // [G] where group g's ids start in scan_ids
+    const uint32_t *g_of_query; // [B]
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
@@ -49,9 +55,13 @@ struct FsParams {
 // Stripe geometry, resolved ON THE DEVICE by every kernel of the scan (same integer arithmetic everywhere): the
 // number of rows that survive the filter is produced by a kernel of the same stream, so the host never waits for it.
 struct FsGeom { uint32_t n_scan, n_stripes, rows_per_stripe; };
+__device__ __forceinline__ FsGeom fs_resolve_n(const FsParams &p, uint32_t n_scan);
 __device__ __forceinline__ FsGeom fs_resolve(const FsParams &p) {
+    return fs_resolve_n(p, p.n_scan_dev ? *p.n_scan_dev : p.n_scan);
+}
+__device__ __forceinline__ FsGeom fs_resolve_n(const FsParams &p, uint32_t n_scan) {
     FsGeom g;
-    g.n_scan = p.n_scan_dev ? *p.n_scan_dev : p.n_scan;
+    g.n_scan = n_scan;
     const uint32_t n_tiles = (g.n_scan + FS_TR - 1) / FS_TR;
     uint32_t ns = p.want;
     const uint32_t lim = (n_tiles + p.min_tiles - 1) / p.min_tiles;
@@ -520,14 +530,25 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     const uint32_t xcd = bid & 7u, local = bid >> 3;
     const uint32_t stripe = (local / n_q16) * 8u + xcd; // the query groups of one stripe share an XCD (L2)
     const uint32_t qt = local % n_q16;
-    const FsGeom geo = fs_resolve(p);
-    if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
+    // this tile's queries and scan list: the batch's, or its group's (grouped scan)
+    const uint32_t *scan_ids = p.scan_ids;
+    uint32_t q0 = qt * FSS_TQ;
+    uint32_t nq = p.B - q0 < (uint32_t)FSS_TQ ? p.B - q0 : (uint32_t)FSS_TQ;
+    FsGeom geo;
+    if (p.g_tile) {
+        const uint32_t grp = p.g_tile[qt * 3u];
+        q0 = p.g_tile[qt * 3u + 1u];
+        nq = p.g_tile[qt * 3u + 2u];
+        scan_ids = p.scan_ids + p.g_base[grp];
+        geo = fs_resolve_n(p, p.g_nscan[grp]);
+    } else {
+        geo = fs_resolve(p);
+        if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
+    }
     if (stripe >= geo.n_stripes) return;
     const uint32_t row_begin = stripe * geo.rows_per_stripe;
     uint32_t row_end = row_begin + geo.rows_per_stripe;
     if (row_end > geo.n_scan) row_end = geo.n_scan;
-    const uint32_t q0 = qt * FSS_TQ;
-    const uint32_t nq = p.B - q0 < (uint32_t)FSS_TQ ? p.B - q0 : (uint32_t)FSS_TQ;
 
     for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 2); i += 256) {
         const uint32_t n = i / (v.ld >> 2), c = i % (v.ld >> 2);
@@ -558,7 +579,7 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const uint32_t rr = tile + wrow + (uint32_t)(a * 16 + fi);
-            dst[a] = rr < row_end ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
+            dst[a] = rr < row_end ? (scan_ids ? scan_ids[rr] : rr + 1u) : 0u;
         }
     };
     auto issue = [&](float4 (&dst)[2][FSS_CH], uint32_t ch) {
@@ -608,7 +629,7 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const uint32_t rr = tile + wrow + (uint32_t)((e >> 2) * 16 + fg * 4 + (e & 3));
-            sel_id[e] = rr < row_end ? (p.scan_ids ? p.scan_ids[rr] : rr + 1u) : 0u;
+            sel_id[e] = rr < row_end ? (scan_ids ? scan_ids[rr] : rr + 1u) : 0u;
         }
     };
     auto sel_load_norms = [&]() {
@@ -662,12 +683,12 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
         if (nchk == nch) { nchk = 0; ntile = tile + FS_TR; }
         if (ch == 0) {
             sel_load_ids(tile);
-            if (p.scan_ids && tile + FS_TR < row_end) load_ids(ld_nx, tile + FS_TR);
+            if (scan_ids && tile + FS_TR < row_end) load_ids(ld_nx, tile + FS_TR);
         }
         if (ch == 1) sel_load_norms();
         if (ntile < row_end) {
             if (nchk == 0) {
-                if (p.scan_ids) { ld_id[0] = ld_nx[0]; ld_id[1] = ld_nx[1]; }
+                if (scan_ids) { ld_id[0] = ld_nx[0]; ld_id[1] = ld_nx[1]; }
                 else load_ids(ld_id, ntile);
             }
             issue(nxt, nchk);
@@ -689,12 +710,13 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
             (void)fs_compact_wave<1>(b_key + q * cap_s, b_id + q * cap_s, c, p.kl);
             c = p.kl;
         }
-        const size_t lb = (size_t)stripe * p.cap * FS_TQ + (q0 + q); // layout of flat_merge_kernel, n_qtiles == 1
+        const uint32_t qg = q0 + q; // layout of flat_merge_kernel: [stripe][query tile of 128][entry][query % 128]
+        const size_t lb = ((size_t)stripe * p.n_qtiles + qg / FS_TQ) * p.cap * FS_TQ + (qg % FS_TQ);
         for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
             p.part_key[lb + (size_t)i * FS_TQ] = b_key[q * cap_s + i];
             p.part_id[lb + (size_t)i * FS_TQ] = b_id[q * cap_s + i];
         }
-        if (lane == 0) p.part_cnt[(size_t)stripe * FS_TQ + q0 + q] = c;
+        if (lane == 0) p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + qg] = c;
     }
 }
 
@@ -738,7 +760,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     const uint32_t qstride = p.n_qtiles * FS_TQ;
-    const uint32_t n_stripes = fs_resolve(p).n_stripes;          // <= p.want
+    const uint32_t n_stripes = (p.g_of_query ? fs_resolve_n(p, p.g_nscan[p.g_of_query[q]]) : fs_resolve(p)).n_stripes; // <= p.want
     uint32_t *sbase = reinterpret_cast<uint32_t *>(qlds + v.ld); // [want] first entry of every stripe's list
     uint32_t *scnt = sbase + p.want;                             // [want]
     for (uint32_t s0 = 0; s0 < n_stripes; s0 += 256) { // exclusive scan of the stripe counts, 256 at a time
@@ -909,6 +931,94 @@ compact_ids_kernel(const uint32_t *deleted, const uint32_t *allow, const uint32_
     }
 }
 
+// ---- grouped scan: one id list per allow list, all lists compacted by three launches, nothing read back ----------
+// (a) rows that survive every list
+__global__ void __launch_bounds__(256)
+group_count_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t *g_n) {
+    const uint32_t g = blockIdx.y;
+    const uint32_t *allow = lists + (size_t)g * words32;
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nwords = (count >> 5) + 1u;
+    uint32_t m = 0;
+    if (w < nwords) {
+        m = ~deleted[w] & allow[w];
+        if (w == 0) m &= ~1u;
+        const uint32_t last = count & 31u;
+        if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
+    }
+    int c = kdb_wave_sum_i(__builtin_popcount(m));
+    if (c && (threadIdx.x & 63u) == 0) atomicAdd(&g_n[g], (uint32_t)c);
+}
+// (b) exclusive prefix over the groups (one workgroup); cursors start at the bases; total -> statistics
+__global__ void __launch_bounds__(256)
+group_prefix_kernel(const uint32_t *g_n, uint32_t G, uint32_t *g_base, uint32_t *g_cursor, unsigned long long *ctr) {
+    __shared__ uint32_t carry;
+    __shared__ uint32_t wsum[4];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < G; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint32_t c = g < G ? g_n[g] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
+        }
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t base = carry + inc - c;
+        for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) base += wsum[i];
+        if (g < G) {
+            g_base[g] = base;
+            g_cursor[g] = base;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && ctr) ctr[0] = carry;
+}
+// (c) fill: as compact_ids_kernel, one atomic per workgroup on the group's cursor
+__global__ void __launch_bounds__(256)
+group_fill_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t *g_cursor,
+                  uint32_t *out) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t blk_base;
+    const uint32_t g = blockIdx.y;
+    const uint32_t *allow = lists + (size_t)g * words32;
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nwords = (count >> 5) + 1u;
+    uint32_t m = 0;
+    if (w < nwords) {
+        m = ~deleted[w] & allow[w];
+        if (w == 0) m &= ~1u;
+        const uint32_t last = count & 31u;
+        if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
+    }
+    const uint32_t c = (uint32_t)__builtin_popcount(m);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
+    }
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        blk_base = tot ? atomicAdd(&g_cursor[g], tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = blk_base + inc - c;
+    for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) pos += wsum[i];
+    while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        out[pos++] = w * 32u + bit;
+    }
+}
+
 __global__ void any_bit_kernel(const uint32_t *bits, uint32_t words, uint32_t *out) {
     bool f = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) f |= bits[i] != 0u;
@@ -1047,7 +1157,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         KDB_HIP(hipGetLastError());
     }
 
-    FsParams p;
+    FsParams p{};
     p.scan_ids = need_ids ? d_ids : nullptr;
     p.n_scan = v.count;
     p.n_scan_dev = need_ids ? d_nscan : nullptr;
@@ -1100,6 +1210,164 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     };
     if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
     else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
+    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (rc) return rc;
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+// Grouped exact scan: the queries of group g (rows [group_offsets[g], group_offsets[g+1]) of the batch) are scanned
+// against the rows allowed by list g.  One launch sequence for all groups, nothing read back from the device
+// unless the caller gave no bound on the total number of allowed rows.
+int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
+                                uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
+                                uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,
+                                uint32_t *d_out_count, hipStream_t s) {
+    if (k == 0 || k > 128) {
+        kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
+        return KDB_ERR_INVALID;
+    }
+    if (v.precision == KDB_PREC_I8) {
+        kdb_set_error("grouped flat scan: int8 rows are not supported (float32 and float16 are)");
+        return KDB_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || G == 0) return KDB_OK;
+    const bool rescore = v.metric != KDB_METRIC_COSINE;
+    const uint32_t kl = !rescore ? k : (k + 16 > 144 ? 144 : k + 16);
+    const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
+    const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    if (lds_s > 150u * 1024u) {
+        kdb_set_error("grouped flat scan: %u-d rows need %zu bytes of LDS per workgroup", v.dim, lds_s);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    // 16-query tiles of every group + the group of every query (host: the caller's grouping is host knowledge)
+    std::vector<uint32_t> tiles, qgrp((size_t)B, 0u);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t a = group_offsets[g], b = group_offsets[g + 1];
+        if (b < a || b > B) {
+            kdb_set_error("grouped flat scan: group_offsets must be non-decreasing and end at B");
+            return KDB_ERR_INVALID;
+        }
+        for (uint32_t q = a; q < b; q++) qgrp[q] = g;
+        for (uint32_t q = a; q < b; q += FSS_TQ) {
+            tiles.push_back(g);
+            tiles.push_back(q);
+            tiles.push_back(b - q < (uint32_t)FSS_TQ ? b - q : (uint32_t)FSS_TQ);
+        }
+    }
+    if (group_offsets[0] != 0 || group_offsets[G] != B) {
+        kdb_set_error("grouped flat scan: group_offsets must start at 0 and end at B");
+        return KDB_ERR_INVALID;
+    }
+    const uint32_t T = (uint32_t)(tiles.size() / 3);
+    uint32_t stripes_max = FS_MAX_MERGE / kl;
+    // stripes per group: T*want workgroups should fill whole rounds of the resident slots (LDS decides how many
+    // workgroups share a CU); the fewest stripes that fill >= 90 % of their rounds win (every stripe pays a start-up)
+    hipDeviceProp_t prop;
+    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
+    const uint32_t per_cu = (uint32_t)(160u * 1024u / lds_s) > 0 ? (uint32_t)(160u * 1024u / lds_s) : 1u;
+    const uint32_t slots = (uint32_t)prop.multiProcessorCount * (per_cu > 2 ? 2u : per_cu);
+    uint32_t want = 1;
+    {
+        double best = 0.0;
+        const uint32_t lim = stripes_max < 64u ? stripes_max : 64u;
+        for (uint32_t w = 1; w <= lim; w++) {
+            const uint64_t blocks = (uint64_t)w * T;
+            if (blocks > 4ull * slots && w > 1) break;
+            const uint64_t rounds = (blocks + slots - 1) / slots;
+            const double fill = (double)blocks / (double)(rounds * slots);
+            if (fill > best + 1e-9) { best = fill; want = w; }
+            if (fill >= 0.9) { want = w; break; }
+        }
+    }
+    const uint32_t min_tiles = 4;
+    const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
+    const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const uint32_t nwords = (v.count >> 5) + 1u;
+    const dim3 ggrid((nwords + 255) / 256, G);
+
+    // group sizes first if the caller gave no bound (one 4*G-byte read-back)
+    int rc = kdb_ensure_scratch(idx, al((size_t)G * 4) * 3 + 4096);
+    if (rc) return rc;
+    uint64_t total = max_total_allowed;
+    if (total == 0) {
+        uint32_t *d_gn0 = reinterpret_cast<uint32_t *>(idx->d_scratch);
+        KDB_HIP(hipMemsetAsync(d_gn0, 0, (size_t)G * 4, s));
+        hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gn0);
+        KDB_HIP(hipGetLastError());
+        std::vector<uint32_t> gn(G);
+        KDB_HIP(hipMemcpyAsync(gn.data(), d_gn0, (size_t)G * 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        for (uint32_t g = 0; g < G; g++) total += gn[g];
+        if (total == 0) total = 1;
+    }
+    if (total > (uint64_t)G * v.count) total = (uint64_t)G * v.count;
+    const size_t ids_bytes = al((size_t)total * 4 + 1024);
+    const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
+    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) + al((size_t)B * 4) + part_bytes + 4096;
+    rc = kdb_ensure_scratch(idx, need);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
+    uint32_t *d_gn = reinterpret_cast<uint32_t *>(base + ids_bytes);
+    uint32_t *d_gbase = reinterpret_cast<uint32_t *>(base + ids_bytes + al((size_t)G * 4));
+    uint32_t *d_gcur = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4));
+    uint32_t *d_tiles = reinterpret_cast<uint32_t *>(base + ids_bytes + 3 * al((size_t)G * 4));
+    uint32_t *d_qgrp = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_tiles) + al(tiles.size() * 4));
+    unsigned char *part = reinterpret_cast<unsigned char *>(d_qgrp) + al((size_t)B * 4);
+
+    FsParams p{};
+    p.ctr = kdb_stats_begin(idx, 2, B, 0);
+    KDB_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_qgrp, qgrp.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemsetAsync(d_gn, 0, (size_t)G * 4, s));
+    hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gn);
+    hipLaunchKernelGGL(group_prefix_kernel, dim3(1), dim3(256), 0, s, d_gn, G, d_gbase, d_gcur, p.ctr);
+    hipLaunchKernelGGL(group_fill_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gcur, d_ids);
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipStreamSynchronize(s)); // the host tables (tiles, qgrp) are stack/heap objects of this call
+
+    p.scan_ids = d_ids;
+    p.n_scan = 0;
+    p.n_scan_dev = nullptr;
+    p.want = want;
+    p.min_tiles = min_tiles;
+    p.n_qtiles = n_qtiles;
+    p.B = B;
+    p.kl = kl;
+    p.cap = kl;
+    p.part_key = reinterpret_cast<float *>(part);
+    p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
+    p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
+    p.g_tile = d_tiles;
+    p.g_nscan = d_gn;
+    p.g_base = d_gbase;
+    p.g_of_query = d_qgrp;
+    p.ctr = nullptr; // written by group_prefix_kernel
+    const uint32_t stripes8 = (want + 7) / 8 * 8;
+    KDB_HIP(hipEventRecord(idx->ev0, s));
+    auto launch_small = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_q), p, T, cap_s);
+        return KDB_OK;
+    };
+    if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
+    else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (rc) return rc;
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipEventRecord(idx->ev1, s));
+    const uint32_t nmax = want * kl;
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
+    auto launch_merge = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
+                           d_out_dist, d_out_count);
+        return KDB_OK;
+    };
+    if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;

@@ -725,6 +725,39 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
     return KDB_OK;
 }
 
+extern "C" int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t G,
+                                        const uint32_t *group_offsets, const uint64_t *d_allow_lists,
+                                        uint64_t words_per_list, uint64_t max_total_allowed, uint32_t flags,
+                                        uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    if (B == 0) return KDB_OK;
+    if (!d_queries || !d_out_ids || !d_out_dist || !d_out_count || !group_offsets || !d_allow_lists || G == 0) {
+        kdb_set_error("flat_scan_groups: null buffer or no group");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    if (words_per_list < ((uint64_t)(idx->count >> 6) + 1)) {
+        kdb_set_error("flat_scan_groups: words_per_list %llu < (count>>6)+1", (unsigned long long)words_per_list);
+        return KDB_ERR_INVALID;
+    }
+    KdbView v = kdb_make_view(idx);
+    if (idx->count == 0) {
+        KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
+        KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+        return KDB_OK;
+    }
+    const uint32_t Bpad = (B + 127u) & ~127u;
+    void *d_q = nullptr;
+    float *d_qnorm = nullptr;
+    int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
+    if (rc) return rc;
+    return kdb_launch_flat_scan_groups(idx, v, d_q, d_qnorm, B, k, G, group_offsets,
+                                       reinterpret_cast<const uint32_t *>(d_allow_lists), (uint32_t)(words_per_list * 2),
+                                       max_total_allowed, d_out_ids, d_out_dist, d_out_count, s);
+}
+
 extern "C" int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k,
                                        const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids,
                                        float *d_out_dist, uint32_t *d_out_count, void *stream) {

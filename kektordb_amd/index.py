@@ -282,6 +282,20 @@ class HipIndex:
                                                 _tptr(d_out_count), C.c_void_p(stream) if stream else None),
               "kdb_search_batch_multi_dev")
 
+    def flat_scan_groups_dev(self, d_queries, k: int, group_offsets, d_allow_lists, d_out_ids, d_out_dist, d_out_count,
+                             max_total_allowed: int = 0, stream=None):
+        """grouped exact scan: queries [group_offsets[g], group_offsets[g+1]) use dense list g of d_allow_lists [G, words]"""
+        self._live()
+        _ready(stream)
+        off = np.ascontiguousarray(group_offsets, dtype=np.uint32)
+        B = int(d_queries.shape[0])
+        G, words = int(d_allow_lists.shape[0]), int(d_allow_lists.shape[1])
+        assert off.size == G + 1
+        check(self.L.kdb_flat_scan_groups_dev(self.h, _tptr(d_queries), B, k, G, _ptr(off), _tptr(d_allow_lists), words,
+                                              int(max_total_allowed), self._flags(False), _tptr(d_out_ids), _tptr(d_out_dist),
+                                              _tptr(d_out_count), C.c_void_p(stream) if stream else None),
+              "kdb_flat_scan_groups_dev")
+
     def merge_topk_packed_dev(self, G, B, k, d_packed, stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count,
                               stream=None):
         """merge over the packed per-shard blocks (ids | dist bits | count) that one all-gather delivers"""

@@ -536,3 +536,48 @@ def test_search_heterogeneous_allow_lists(oracle, hip):
             continue
         i1, d1, c1 = idx.search_batch(Q[sel], k, ef, allow_bits=L[g])
         assert np.array_equal(c1, cnt[sel]) and np.array_equal(i1, ids[sel])
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+def test_flat_scan_groups(oracle, hip, metric):
+    """kdb_flat_scan_groups_dev: one allow list per GROUP of queries in one launch sequence; per query the answer is
+    the exact scan of the oracle over the rows its group's list allows (deleted rows never appear; a list that allows
+    nothing yields no results)."""
+    import torch
+    from kektordb_amd.index import dense_bitset
+    O = oracle
+    n, dim, k = 6000, 96, 10
+    X = make_corpus(n, dim, "normal", seed=71)
+    deleted = list(range(4, n, 60))
+    orc, idx = build_pair(O, hip, X, metric, efc=20, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_MFMA if metric == 1 else O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(9)
+    words = (n >> 6) + 1
+    lists = []
+    for sel in (0.3, 0.02, 0.1, 0.004):
+        a = np.nonzero(rng.random(n + 1) < sel)[0]
+        lists.append(dense_bitset(a[a >= 1], n))
+    lists.append(np.zeros(words, np.uint64))  # allows nothing
+    L = np.stack(lists)
+    sizes = [20, 1, 37, 5, 3]                 # queries per group (ragged: more than one 16-query tile, single queries)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    B = int(off[-1])
+    Q = make_corpus(B, dim, "normal", seed=72)
+    dev = torch.device("cuda:0")
+    dQ, dL = torch.from_numpy(Q).to(dev), torch.from_numpy(L.view(np.int64)).to(dev)
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    od = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    for bound in (0, int(sum(int(np.unpackbits(l.view(np.uint8)).sum()) for l in lists))):
+        oi.zero_(); od.zero_(); oc.zero_()
+        idx.flat_scan_groups_dev(dQ, k, off, dL, oi, od, oc, max_total_allowed=bound)
+        idx.sync()
+        ids, dist, cnt = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy()
+        for g in range(len(sizes)):
+            for b in range(int(off[g]), int(off[g + 1])):
+                want_i, want_d = orc.flat_scan(Q[b], k, allow=L[g]) if L[g].any() else (np.zeros(0, np.uint32), np.zeros(0))
+                c = int(cnt[b])
+                assert c == len(want_i), (g, b, c, len(want_i))
+                assert np.array_equal(ids[b, :c], want_i), (g, b)
+                assert np.array_equal(raw_to_score(idx, dist[b, :c]), want_d), (g, b)
+                assert not (set(ids[b, :c].tolist()) & set(deleted))
