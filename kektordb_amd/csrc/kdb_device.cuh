@@ -185,6 +185,63 @@ __device__ __forceinline__ float kdb_row_partial_f16(const uint16_t *__restrict_
     return (a[0] + a[1]) + (a[2] + a[3]);
 }
 
+// R f16 rows at once with ld == 128*NCHH known at compile time: all R*NCHH 16-byte loads are issued before the
+// first FMA (8 rows of a hop in one HBM round trip for R = 2); every query fragment is read from LDS once for all
+// rows.  Per row the accumulation order is exactly that of kdb_row_partial_f16.
+template <int NCHH, int R>
+__device__ __forceinline__ void kdb_row_partialR_f16(const uint16_t *const (&rows)[R], const float *q, int t, float (&p)[R]) {
+    uint4 xb[R][NCHH];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < NCHH; i++) xb[r][i] = reinterpret_cast<const uint4 *>(rows[r])[t + 16 * i];
+    float a[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r][0] = a[r][1] = a[r][2] = a[r][3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCHH; i++) {
+        const float4 *q4 = reinterpret_cast<const float4 *>(q + 8 * (t + 16 * i));
+        const float4 y0 = q4[0], y1 = q4[1];
+        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned w[4] = {xb[r][i].x, xb[r][i].y, xb[r][i].z, xb[r][i].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned short hb = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+                const float x = (float)__builtin_bit_cast(_Float16, hb);
+                const float d = yy[j] - x;
+                a[r][j & 3] = __builtin_fmaf(d, d, a[r][j & 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
+}
+
+// R int8 rows at once with ld == 256*NCHI: R*NCHI 16-byte loads in flight, exact i32 dots.
+template <int NCHI, int R>
+__device__ __forceinline__ void kdb_row_partialR_i8(const int8_t *const (&rows)[R], const int8_t *q, int t, int (&p)[R]) {
+    int4 x[R][NCHI];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < NCHI; i++) x[r][i] = reinterpret_cast<const int4 *>(rows[r])[t + 16 * i];
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = 0;
+#pragma unroll
+    for (int i = 0; i < NCHI; i++) {
+        const int4 y = reinterpret_cast<const int4 *>(q)[t + 16 * i];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            p[r] = __builtin_amdgcn_sdot4(x[r][i].x, y.x, p[r], false);
+            p[r] = __builtin_amdgcn_sdot4(x[r][i].y, y.y, p[r], false);
+            p[r] = __builtin_amdgcn_sdot4(x[r][i].z, y.z, p[r], false);
+            p[r] = __builtin_amdgcn_sdot4(x[r][i].w, y.w, p[r], false);
+        }
+    }
+}
+
 // int8 rows, query in LDS as packed int8: exact i32 dot (order irrelevant).
 __device__ __forceinline__ int kdb_row_partial_i8(const int8_t *__restrict__ row, const int8_t *q, uint32_t ld, int t) {
     const int4 *r4 = reinterpret_cast<const int4 *>(row);

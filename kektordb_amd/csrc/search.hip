@@ -36,7 +36,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, (NCH > 12 ? 2 : (NCH > 4 && PREC == KDB_PREC_F32) ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64, ((NCH > 12 || (PREC == KDB_PREC_F16 && NCH > 4)) ? 2 : NCH > 4 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
@@ -533,8 +533,20 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
         if (v.metric == KDB_METRIC_COSINE) { KDB_F32(KDB_METRIC_COSINE) }
 #undef KDB_F32
     }
-    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2, 0>(KDB_ARGS);
-    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE, 0>(KDB_ARGS);
+    if (v.precision == KDB_PREC_F16 && v.metric == KDB_METRIC_L2) {
+        switch (v.ld) { // unrolled, two rows per group and trip
+        case 768: return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2, 12>(KDB_ARGS);
+        case 1536: return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2, 24>(KDB_ARGS);
+        default: return launch_search_t<KDB_PREC_F16, KDB_METRIC_L2, 0>(KDB_ARGS);
+        }
+    }
+    if (v.precision == KDB_PREC_I8 && v.metric == KDB_METRIC_COSINE) {
+        switch (v.ld) {
+        case 768: return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE, 12>(KDB_ARGS);
+        case 1536: return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE, 24>(KDB_ARGS);
+        default: return launch_search_t<KDB_PREC_I8, KDB_METRIC_COSINE, 0>(KDB_ARGS);
+        }
+    }
 #undef KDB_ARGS
     kdb_set_error("unsupported precision/metric combination");
     return KDB_ERR_UNSUPPORTED;
