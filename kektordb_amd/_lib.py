@@ -11,6 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libkektor_hip.so")
+# measurement builds (scripts/): another build of the SAME library, e.g. with different tuning macros
+LIB_PATH = os.environ.get("KEKTOR_HIP_LIB", LIB_PATH)
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol declared in include/kektor_hip.h (tests check the .so exports all of them)

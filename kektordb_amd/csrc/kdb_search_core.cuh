@@ -12,6 +12,12 @@
 #include "kdb_device.cuh"
 #include <math.h>
 
+#ifndef KDB_F32_DUAL
+#define KDB_F32_DUAL 1
+#endif
+#ifndef KDB_F16_ROWS
+#define KDB_F16_ROWS 2
+#endif
 namespace kdbcore {
 
 struct WaveLds {
@@ -59,7 +65,7 @@ template <int PREC, int METRIC, int NCH = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
-    if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 12) { // 8 rows per round trip (two per 16-lane group)
+    if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 12 && KDB_F32_DUAL) { // 8 rows per round trip (two per 16-lane group)
         for (uint32_t base = 0; base < n; base += 8) {
             const uint32_t r0 = base + (uint32_t)g, r1 = r0 + 4u;
             const bool act0 = r0 < n, act1 = r1 < n;
@@ -84,7 +90,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         return;
     }
     if constexpr (PREC == KDB_PREC_F16 && NCH > 0 && NCH % 2 == 0 && NCH <= 24) { // ld == 64*NCH: NCH/2 chunks per lane
-        constexpr int R = NCH <= 12 ? 2 : 1; // rows per 16-lane group and trip
+        constexpr int R = KDB_F16_ROWS; // rows per 16-lane group and trip
         for (uint32_t base = 0; base < n; base += 4u * R) {
             const uint16_t *rows[R];
             uint32_t rr[R];
@@ -106,7 +112,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         return;
     }
     if constexpr (PREC == KDB_PREC_I8 && NCH > 0 && NCH % 4 == 0 && NCH <= 24) { // ld == 64*NCH: NCH/4 chunks per lane
-        constexpr int R = NCH <= 12 ? 4 : 2;
+        constexpr int R = 2; // 8 rows per trip; more would cost the fourth wave per SIMD (registers)
         for (uint32_t base = 0; base < n; base += 4u * R) {
             const int8_t *rows[R];
             uint32_t rr[R], ids[R];
