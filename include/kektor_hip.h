@@ -125,6 +125,20 @@ KDB_API const char *kdb_last_error(void);
 KDB_API int kdb_index_create(const kdb_index_desc *desc, kdb_index **out);
 KDB_API void kdb_index_destroy(kdb_index *idx);
 
+/* Incremental refresh of the mirror after writers (Add / AddBatch / optimizer) touched a FEW nodes, instead of a full
+ * kdb_index_upload_graph:
+ *   1. kdb_index_upload_rows for the new ids (they continue at count+1, as nodeCounter does, hnsw_index.go:590);
+ *   2. kdb_index_append_nodes(first_id, n, levels) -- registers them (levels as len(Connections)-1), lists empty;
+ *   3. kdb_index_patch_adjacency(level, ...) per level -- replaces the lists of the touched nodes (new nodes and
+ *      every node whose Connections[level] changed: reverse links, re-prunes); lists keep the stored order;
+ *   4. kdb_index_set_entry(entrypointID, maxLevel).
+ * Searches issued between the steps see a graph that is consistent per list, exactly as concurrent readers of the
+ * reference do under its fine-grained shard locks.                                                            */
+KDB_API int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels);
+KDB_API int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_t n, const uint32_t *ids,
+                              const uint64_t *offsets /* n+1 */, const uint32_t *neighbors);
+KDB_API int kdb_index_set_entry(kdb_index *idx, uint32_t entry, int32_t max_level);
+
 /* Rows in stored form, row-major, `n` rows for ids first_id..first_id+n-1 (cosine/f32 rows already
  * normalised, f16 as IEEE binary16 bits, int8 quantised).  *_dev takes a device pointer.          */
 KDB_API int kdb_index_upload_rows(kdb_index *idx, uint32_t first_id, uint32_t n, const void *rows);

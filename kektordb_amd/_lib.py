@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "kdb_index_upload_graph", "kdb_index_mark_deleted", "kdb_index_set_count", "kdb_index_graph_info",
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
-    "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
+    "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
     "kdb_index_sync",
 ]
 
@@ -102,6 +102,9 @@ def load():
     L.kdb_search_batch_dev.argtypes = [vp, vp, u32, u32, u32, vp, u32, vp, vp, vp, vp]
     L.kdb_search_batch_multi_dev.argtypes = [vp, vp, u32, u32, u32, vp, u32, C.c_uint64, vp, u32, vp, vp, vp, vp]
     L.kdb_flat_scan_groups_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, C.c_uint64, C.c_uint64, u32, vp, vp, vp, vp]
+    L.kdb_index_append_nodes.argtypes = [vp, u32, u32, vp]
+    L.kdb_index_patch_adjacency.argtypes = [vp, u32, u32, vp, vp, vp]
+    L.kdb_index_set_entry.argtypes = [vp, u32, i32]
     L.kdb_search_set_trace.argtypes = [vp, vp, vp, C.c_int]
     L.kdb_flat_scan_batch.argtypes = [vp, vp, u32, u32, vp, u32, vp, vp, vp]
     L.kdb_flat_scan_batch_dev.argtypes = [vp, vp, u32, u32, vp, u32, vp, vp, vp, vp]

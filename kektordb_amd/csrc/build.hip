@@ -528,6 +528,8 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     KDB_HIP(hipMemsetAsync(idx->d_adj_up, 0, (slots * idx->deg_up + 4) * 4, s));
     KDB_HIP(hipMemcpyAsync(idx->d_levels, levels.data(), n1, hipMemcpyHostToDevice, s));
     KDB_HIP(hipMemcpyAsync(idx->d_up_idx, up_idx.data(), n1 * 4, hipMemcpyHostToDevice, s));
+    idx->h_levels = levels; // host copies for the incremental refresh entry points
+    idx->h_up_idx = up_idx;
     // ---- workspace
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t max_tasks = (size_t)max_batch * 2 + 64; // level-0 tasks + upper tasks (<< batch)

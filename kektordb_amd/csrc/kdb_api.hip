@@ -424,6 +424,127 @@ extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
     idx->entry = g->entry;
     idx->max_level = g->max_level;
     idx->has_graph = true;
+    idx->h_levels = std::move(levels);
+    idx->h_up_idx = std::move(up_idx);
+    return KDB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Incremental refresh of the mirror (writers touched a few nodes: no full re-upload)
+// ---------------------------------------------------------------------------------------------
+extern "C" int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels) {
+    KDB_CHECK_IDX(idx);
+    if (n == 0) return KDB_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!levels || first_id != idx->count + 1 || (uint64_t)first_id + n - 1 > idx->cap) {
+        kdb_set_error("append_nodes: ids must continue at count+1 = %u and stay within capacity %u", idx->count + 1, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    if (idx->h_levels.size() != (size_t)idx->count + 1) {
+        if (idx->count != 0) {
+            kdb_set_error("append_nodes: the index holds no host-side level table (upload or build a graph first, or start empty)");
+            return KDB_ERR_STATE;
+        }
+        idx->h_levels.assign(1, 0);
+        idx->h_up_idx.assign(1, 0);
+    }
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    size_t slots = idx->up_slots;
+    std::vector<uint32_t> up_new(n);
+    for (uint32_t i = 0; i < n; i++) {
+        up_new[i] = (uint32_t)slots;
+        slots += levels[i];
+    }
+    if (slots > idx->up_slots_cap || !idx->d_adj_up) { // grow the upper pool, keep what it holds
+        const size_t ncap = slots + slots / 2 + 1024;
+        uint32_t *nbuf = nullptr;
+        KDB_HIP(hipMalloc(&nbuf, (ncap * idx->deg_up + 1) * 4));
+        KDB_HIP(hipMemsetAsync(nbuf, 0, (ncap * idx->deg_up + 1) * 4, s));
+        if (idx->d_adj_up && idx->up_slots)
+            KDB_HIP(hipMemcpyAsync(nbuf, idx->d_adj_up, idx->up_slots * idx->deg_up * 4, hipMemcpyDeviceToDevice, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
+        idx->d_adj_up = nbuf;
+        idx->up_slots_cap = ncap;
+    } else { // recycled pool memory: the new nodes' upper rows start empty
+        KDB_HIP(hipMemsetAsync(idx->d_adj_up + idx->up_slots * idx->deg_up, 0, (slots - idx->up_slots) * idx->deg_up * 4, s));
+    }
+    KDB_HIP(hipMemsetAsync(idx->d_adj0 + (size_t)first_id * idx->deg0, 0, (size_t)n * idx->deg0 * 4, s));
+    KDB_HIP(hipMemcpyAsync(idx->d_levels + first_id, levels, n, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(idx->d_up_idx + first_id, up_new.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    idx->h_levels.insert(idx->h_levels.end(), levels, levels + n);
+    idx->h_up_idx.insert(idx->h_up_idx.end(), up_new.begin(), up_new.end());
+    idx->up_slots = slots;
+    idx->count += n;
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_t n, const uint32_t *ids,
+                                         const uint64_t *offsets, const uint32_t *neighbors) {
+    KDB_CHECK_IDX(idx);
+    if (n == 0) return KDB_OK;
+    if (!ids || !offsets || (!neighbors && offsets[n] != offsets[0])) {
+        kdb_set_error("patch_adjacency: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->h_levels.size() != (size_t)idx->count + 1) {
+        kdb_set_error("patch_adjacency: no graph to patch");
+        return KDB_ERR_STATE;
+    }
+    const uint32_t deg = level == 0 ? idx->deg0 : idx->deg_up;
+    std::vector<uint32_t> rows((size_t)n * deg, 0u), slots(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t id = ids[i];
+        if (id == 0 || id > idx->count || idx->h_levels[id] < level) {
+            kdb_set_error("patch_adjacency: node %u does not exist at level %u", id, level);
+            return KDB_ERR_INVALID;
+        }
+        const uint64_t a = offsets[i], b = offsets[i + 1];
+        if (b < a || b - a > deg) {
+            kdb_set_error("patch_adjacency: node %u has %llu links at level %u (cap %u)", id, (unsigned long long)(b - a), level, deg);
+            return KDB_ERR_INVALID;
+        }
+        for (uint64_t e = a; e < b; e++) {
+            if (neighbors[e] == 0 || neighbors[e] > idx->count) {
+                kdb_set_error("patch_adjacency: neighbour id %u of node %u out of range", neighbors[e], id);
+                return KDB_ERR_INVALID;
+            }
+            rows[(size_t)i * deg + (e - a)] = neighbors[e];
+        }
+        slots[i] = level == 0 ? id : idx->h_up_idx[id] + (level - 1);
+    }
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    int rc = kdb_ensure_scratch(idx, al(rows.size() * 4) + al((size_t)n * 4) + 256);
+    if (rc) return rc;
+    uint32_t *d_rows = reinterpret_cast<uint32_t *>(idx->d_scratch);
+    uint32_t *d_slots = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(idx->d_scratch) + al(rows.size() * 4));
+    KDB_HIP(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_slots, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    rc = kdb_launch_adj_scatter(level == 0 ? idx->d_adj0 : idx->d_adj_up, deg, n, d_slots, d_rows, s);
+    if (rc) return rc;
+    KDB_HIP(hipStreamSynchronize(s)); // host buffers are consumed before returning
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_set_entry(kdb_index *idx, uint32_t entry, int32_t max_level) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (max_level >= 0 && (entry == 0 || entry > idx->count)) {
+        kdb_set_error("set_entry: entry point %u outside 1..%u", entry, idx->count);
+        return KDB_ERR_INVALID;
+    }
+    if (max_level >= 0 && idx->h_levels.size() == (size_t)idx->count + 1 && (int)idx->h_levels[entry] < max_level) {
+        kdb_set_error("set_entry: node %u has level %u < max_level %d", entry, idx->h_levels[entry], max_level);
+        return KDB_ERR_INVALID;
+    }
+    idx->entry = entry;
+    idx->max_level = max_level;
+    idx->has_graph = max_level >= 0;
     return KDB_OK;
 }
 

@@ -370,6 +370,13 @@ group_entry_kernel(const uint32_t *lists, uint32_t words32, uint32_t count, uint
     }
 }
 
+// incremental refresh: row slot[i] of an adjacency array (deg ids per row) <- src[i][0..deg)
+__global__ void adj_scatter_kernel(uint32_t *dst, uint32_t deg, uint32_t n, const uint32_t *slots, const uint32_t *src) {
+    const uint32_t i = blockIdx.x * (blockDim.x / 32u) + threadIdx.x / 32u, e = threadIdx.x & 31u;
+    if (i >= n) return;
+    for (uint32_t c = e; c < deg; c += 32u) dst[(size_t)slots[i] * deg + c] = src[(size_t)i * deg + c];
+}
+
 // smallest id set in the allow bitmap (allowList.Iterator().Next(), hnsw_index.go:437-447); 0 if none
 __global__ void first_allowed_kernel(const uint32_t *allow, uint32_t words, uint32_t *out) {
     uint32_t best = 0xffffffffu;
@@ -439,6 +446,13 @@ int kdb_launch_group_entries(const KdbView &v, const uint32_t *d_allow_lists, ui
                              uint32_t *d_group_entry, hipStream_t s) {
     if (G == 0) return KDB_OK;
     hipLaunchKernelGGL(group_entry_kernel, dim3(G), dim3(256), 0, s, d_allow_lists, words32, v.count, entry, d_group_entry);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+int kdb_launch_adj_scatter(uint32_t *d_dst, uint32_t deg, uint32_t n, const uint32_t *d_slots, const uint32_t *d_src, hipStream_t s) {
+    if (n == 0) return KDB_OK;
+    hipLaunchKernelGGL(adj_scatter_kernel, dim3((n + 7) / 8), dim3(256), 0, s, d_dst, deg, n, d_slots, d_src);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }

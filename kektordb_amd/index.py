@@ -140,6 +140,26 @@ class HipIndex:
         a = np.ascontiguousarray(ids, dtype=np.uint32)
         check(self.L.kdb_index_mark_deleted(self.h, _ptr(a), a.size), "mark_deleted")
 
+    # ---- incremental refresh (writers touched a few nodes) ----------------------------------------------
+    def append_nodes(self, first_id: int, levels):
+        lv = np.ascontiguousarray(levels, dtype=np.uint8)
+        check(self.L.kdb_index_append_nodes(self.h, int(first_id), lv.size, _ptr(lv)), "kdb_index_append_nodes")
+
+    def patch_adjacency(self, level: int, ids, lists):
+        """lists: one sequence of neighbour ids per node of `ids` (stored order)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.zeros(ids.size + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in lists])
+        nb = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists]) if len(lists) else
+                                  np.zeros(0, np.uint32), dtype=np.uint32)
+        if nb.size == 0:
+            nb = np.zeros(1, np.uint32)
+        check(self.L.kdb_index_patch_adjacency(self.h, int(level), ids.size, _ptr(ids), _ptr(off), _ptr(nb)),
+              "kdb_index_patch_adjacency")
+
+    def set_entry(self, entry: int, max_level: int):
+        check(self.L.kdb_index_set_entry(self.h, int(entry), int(max_level)), "kdb_index_set_entry")
+
     def build(self, count: int, batch: int = 0, ef_construction: int = 0, seed: int = 1):
         """GPU batched construction over rows 1..count (addBatchInternal, hnsw_index.go:1479-2088)."""
         p = _lib.BuildParams(batch, ef_construction, seed, 0, 0)

@@ -128,3 +128,63 @@ def test_build_f16(oracle, hip):
         assert np.array_equal(ids[b, :c], oi)
         assert np.array_equal(dist[b, :c].astype(np.float64), od)
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_incremental_refresh_matches_full_upload(oracle, hip, metric):
+    """The mirror refresh a shim does after writers touched a few nodes: new rows + append_nodes + patch_adjacency of
+    exactly the lists that changed + set_entry.  The refreshed index must hold the same graph as a full upload of the
+    reference-shaped graph (the oracle's sequential Add: reverse links and re-prunes rewrite old nodes' lists) and
+    answer bit for bit like the oracle."""
+    O = oracle
+    n1, n2, dim = 1500, 700, 32
+    X = make_corpus(n1 + n2, dim, "uniform", seed=41)
+    orc = O.OracleIndex(dim, metric, O.F32, 8, 40, seed=3)
+    orc.add_many(X[:n1])
+    g1 = orc.export_graph()
+    idx = hip.HipIndex(dim, metric, 0, 8, 40, capacity=n1 + n2 + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_graph_obj(g1)
+    orc.add_many(X[n1:])                      # writers: 700 sequential Adds
+    g2 = orc.export_graph()
+    rows2 = orc.rows()
+    idx.upload_rows(rows2[n1 + 1:], n1 + 1)
+    idx.append_nodes(n1 + 1, g2.levels[n1 + 1:n1 + n2 + 1])
+    n_patched = 0
+    for l in range(g2.max_level + 1):
+        ids, lists = [], []
+        for i in range(1, n1 + n2 + 1):
+            if g2.levels[i] < l:
+                continue
+            new = g2.neighbors[l][int(g2.offsets[l][i]):int(g2.offsets[l][i + 1])]
+            if i <= n1 and l <= g1.max_level and g1.levels[i] >= l:
+                old = g1.neighbors[l][int(g1.offsets[l][i]):int(g1.offsets[l][i + 1])]
+                if np.array_equal(old, new):
+                    continue
+            ids.append(i)
+            lists.append(new)
+        if ids:
+            idx.patch_adjacency(l, ids, lists)
+            n_patched += len(ids)
+    idx.set_entry(g2.entry, g2.max_level)
+    assert n_patched < (n1 + n2) * (g2.max_level + 1)   # a real delta, not everything
+    # same graph as the full export
+    c, e, ml, lv, offs, nbrs = idx.download_graph()
+    assert (c, e, ml) == (g2.count, g2.entry, g2.max_level) and np.array_equal(lv[:c + 1], g2.levels[:c + 1])
+    for l in range(ml + 1):
+        assert np.array_equal(offs[l][:c + 2], g2.offsets[l][:c + 2]) and np.array_equal(nbrs[l], g2.neighbors[l])
+    # same answers as the oracle
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(24, dim, "uniform", seed=42)
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 40, trace=True)
+    for b in range(24):
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=40, counters=True)
+        c_ = int(cnt[b])
+        assert np.array_equal(ids[b, :c_], oi)
+        assert np.array_equal(np.array([idx.score(x) for x in dist[b, :c_]]), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    # patches are validated
+    with pytest.raises(Exception):
+        idx.patch_adjacency(0, [n1 + n2 + 5], [[1]])
+    with pytest.raises(Exception):
+        idx.patch_adjacency(0, [1], [list(range(1, 40))])   # longer than mMax0 = 16
