@@ -70,6 +70,21 @@ class Index {
         kdb_build_params p{batch, 0, seed, 0, 0};
         check(kdb_index_build(h_, count, &p), "build");
     }
+    // incremental refresh of the mirror after writers touched a few nodes (see kdb_index_append_nodes)
+    void AppendNodes(uint32_t firstID, const std::vector<uint8_t> &levels) {
+        check(kdb_index_append_nodes(h_, firstID, (uint32_t)levels.size(), levels.data()), "append_nodes");
+    }
+    void PatchAdjacency(uint32_t level, const std::vector<uint32_t> &ids, const std::vector<std::vector<uint32_t>> &lists) {
+        std::vector<uint64_t> off(ids.size() + 1, 0);
+        std::vector<uint32_t> nb;
+        for (size_t i = 0; i < ids.size(); i++) {
+            nb.insert(nb.end(), lists[i].begin(), lists[i].end());
+            off[i + 1] = nb.size();
+        }
+        if (nb.empty()) nb.push_back(0);
+        check(kdb_index_patch_adjacency(h_, level, (uint32_t)ids.size(), ids.data(), off.data(), nb.data()), "patch_adjacency");
+    }
+    void SetEntry(uint32_t entry, int32_t maxLevel) { check(kdb_index_set_entry(h_, entry, maxLevel), "set_entry"); }
     void Delete(const std::vector<uint32_t> &ids) { check(kdb_index_mark_deleted(h_, ids.data(), (uint32_t)ids.size()), "delete"); }
 
     // core.VectorIndex.SearchWithScores: one query; empty slice on any error, closed index or empty allow list
