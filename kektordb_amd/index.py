@@ -335,8 +335,11 @@ class HipIndex:
         allowList: None (nil) or a dense uint64 bitset over internal ids (the shim converts roaring)."""
         if self._closed:
             return []
+        q = np.asarray(query, dtype=np.float32)
+        if q.ndim != 1 or q.shape[0] != self.dim:
+            return []  # dimension mismatch is an error of searchInternal: logged, empty slice (:356-359)
         try:
-            ids, dist, cnt = self.search_batch(np.asarray(query, dtype=np.float32)[None, :], k, efSearch, allowList)
+            ids, dist, cnt = self.search_batch(q[None, :], k, efSearch, allowList)
         except KdbError:
             return []  # the reference logs and returns an empty slice (:356-359)
         n = int(cnt[0])

@@ -581,3 +581,36 @@ def test_flat_scan_groups(oracle, hip, metric):
                 assert np.array_equal(ids[b, :c], want_i), (g, b)
                 assert np.array_equal(raw_to_score(idx, dist[b, :c]), want_d), (g, b)
                 assert not (set(ids[b, :c].tolist()) & set(deleted))
+
+
+def test_error_behaviour_on_gpu(oracle, hip):
+    """Misuse returns an error code + message and leaves the handle usable (nothing throws across the ABI; the
+    reference's SearchWithScores swallows errors to an empty slice, hnsw_index.go:356-359)."""
+    O = oracle
+    X = make_corpus(400, 24, "uniform", seed=5)
+    orc, idx = build_pair(O, hip, X, 0, efc=20)
+    Q = make_corpus(3, 24, "uniform", seed=6)
+    good = idx.search_batch(Q, 5, 20)
+    with pytest.raises(hip.KdbError):           # k == 0
+        idx.search_batch(Q, 0, 20)
+    with pytest.raises(hip.KdbError):           # exact scan keeps at most 128 results per query
+        idx.flat_scan_batch(Q, 129)
+    with pytest.raises(hip.KdbError):           # rows outside the capacity
+        idx.upload_rows(X[:10], 405)
+    with pytest.raises(hip.KdbError):           # norms only exist for int8 indexes
+        idx.upload_norms(np.ones(4, np.float32), 1)
+    with pytest.raises(hip.KdbError):           # an ef whose beam + visited set cannot fit LDS
+        idx.search_batch(Q, 5, 30000)
+    # wrong query width: the mirror follows the reference (empty result, no exception)
+    assert idx.SearchWithScores(np.ones(7, np.float32), 5, None, 0) == []
+    # rows without a graph: maxLevel is -1, the search returns [] (hnsw_index.go:383-385); the exact scan works
+    bare = hip.HipIndex(24, 0, 0, 16, 50, capacity=400)
+    bare.upload_rows(X, 1)
+    bare.set_count(400)
+    bi, bd, bc = bare.search_batch(Q, 5, 20)
+    assert np.all(bc == 0)
+    fi, fd, fc = bare.flat_scan_batch(Q, 5)
+    assert np.all(fc == 5)
+    # the first handle still answers exactly as before
+    again = idx.search_batch(Q, 5, 20)
+    assert all(np.array_equal(a, b) for a, b in zip(good, again))
