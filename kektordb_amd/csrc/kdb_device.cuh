@@ -109,6 +109,41 @@ __device__ __forceinline__ void kdb_row_partial2_f32(const float *__restrict__ r
     p1 = (b0 + b1) + (b2 + b3);
 }
 
+// R rows at once (generalises kdb_row_partial2_f32): R*NCH loads in flight, per row the same accumulation order.
+template <int METRIC, int NCH, int R>
+__device__ __forceinline__ void kdb_row_partialR_f32(const float *const (&rows)[R], const float *q, int t, float (&p)[R]) {
+    const float4 *q4 = reinterpret_cast<const float4 *>(q);
+    float4 x[R][NCH];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < NCH; i++) x[r][i] = reinterpret_cast<const float4 *>(rows[r])[t + 16 * i];
+    float a[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r][0] = a[r][1] = a[r][2] = a[r][3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const float4 y = q4[t + 16 * i];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (METRIC == KDB_METRIC_L2) {
+                const float d0 = y.x - x[r][i].x, d1 = y.y - x[r][i].y, d2 = y.z - x[r][i].z, d3 = y.w - x[r][i].w;
+                a[r][0] = __builtin_fmaf(d0, d0, a[r][0]);
+                a[r][1] = __builtin_fmaf(d1, d1, a[r][1]);
+                a[r][2] = __builtin_fmaf(d2, d2, a[r][2]);
+                a[r][3] = __builtin_fmaf(d3, d3, a[r][3]);
+            } else {
+                a[r][0] = __builtin_fmaf(y.x, x[r][i].x, a[r][0]);
+                a[r][1] = __builtin_fmaf(y.y, x[r][i].y, a[r][1]);
+                a[r][2] = __builtin_fmaf(y.z, x[r][i].z, a[r][2]);
+                a[r][3] = __builtin_fmaf(y.w, x[r][i].w, a[r][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
+}
+
 template <int METRIC, int NCH = 0>
 __device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ row, const float *q, uint32_t ld,
                                                      int t) {
