@@ -12,6 +12,9 @@
 #include "kdb_device.cuh"
 #include <math.h>
 
+#ifndef KDB_F32_ROWS6
+#define KDB_F32_ROWS6 2
+#endif
 #ifndef KDB_F32_ROWS
 #define KDB_F32_ROWS 3 // measured at 768-d: 12 rows per trip (224 VGPRs, 2 waves/SIMD) beat 8 by 3-6 %
 #endif
@@ -69,7 +72,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
     if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 12 && KDB_F32_DUAL) { // 4*R rows per round trip
-        constexpr int R = NCH <= 6 ? 4 : KDB_F32_ROWS;
+        constexpr int R = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : KDB_F32_ROWS;
         for (uint32_t base = 0; base < n;) {
             const uint32_t left = n - base;
             if (left > 4u * (R - 1) || R == 1) { // wave-uniform: a full-width trip

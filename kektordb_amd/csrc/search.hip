@@ -33,6 +33,9 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #ifndef KDB_F16_MINW
 #define KDB_F16_MINW 3 // measured at 1M x 768: 3 waves/SIMD with 11 spilled registers beat 2 waves without
 #endif
+#ifndef KDB_F32_MINW6
+#define KDB_F32_MINW6 4 // 384-d rows are latency/issue-bound: occupancy over rows in flight (measured +16 %)
+#endif
 #ifndef KDB_F32_MINW
 #define KDB_F32_MINW 2 // measured: 2 waves/SIMD without spills equal 3 at ef=64 and win 4-5 % at ef 128-200
 #endif
@@ -42,7 +45,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 4 ? KDB_F32_MINW : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
