@@ -13,6 +13,7 @@ ap.add_argument("--efs", default="50,100,200")
 ap.add_argument("--efc", type=int, default=200)
 ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--metric", type=int, default=1)
+ap.add_argument("--sortq", type=int, default=0, help="1: order the query batch by nearest cluster centre (locality experiment)")
 ap.add_argument("--sorted", type=int, default=0, help="1: ids cluster-contiguous (locality experiment)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -33,7 +34,10 @@ def gen(n, seed_off=0):
         x = x / x.norm(dim=1, keepdim=True)
     return x.contiguous()
 
-t0 = time.time(); X = gen(a.n); Q = gen(a.nq); torch.cuda.synchronize(); print("gen %.2fs" % (time.time() - t0))
+t0 = time.time(); X = gen(a.n); Q = gen(a.nq)
+if a.sortq and hasattr(gen, "cent"):
+    Q = Q[torch.argsort((Q @ gen.cent.T).argmax(dim=1))].contiguous()
+torch.cuda.synchronize(); print("gen %.2fs" % (time.time() - t0))
 idx = K.HipIndex(a.dim, a.metric, 0, 16, a.efc, capacity=a.n)
 idx.upload_rows(X, 1)
 t0 = time.time(); idx.build(a.n, batch=a.batch, ef_construction=a.efc, seed=1); print("build %.2fs" % (time.time() - t0))
