@@ -509,15 +509,25 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
 constexpr int FSS_TQ = 16;     // queries per workgroup
 constexpr int FSS_CH = 8;      // 16-element K steps per register chunk (128 floats of every row)
 constexpr int FSS_SLACK = 64;  // buffer = kl + one tile of rows + slack entries
+template <int PREC>
+__host__ __device__ inline size_t fss_q_bytes(uint32_t ld);
 __host__ __device__ inline uint32_t fss_qstride(uint32_t ld) { return ld + ((40u + 64u - (ld & 63u)) & 63u); }
+
+template <int PREC>
+__host__ __device__ inline size_t fss_q_bytes(uint32_t ld) {
+    return PREC == KDB_PREC_I8 ? (((size_t)FSS_TQ * (ld + 16u) + 255u) & ~(size_t)255u) : (size_t)FSS_TQ * fss_qstride(ld) * 4u;
+}
 
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
 flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t n_q16, uint32_t cap_s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // queries in LDS: [16][S] floats (f32, f16 widened), or [16][S8] bytes (int8, stride ld+16: conflict-free b128 reads)
     const uint32_t S = fss_qstride(v.ld);
-    float *qs = reinterpret_cast<float *>(smem);                              // [16][S]
-    float *b_key = qs + FSS_TQ * S;                                           // [16][cap_s]
+    const uint32_t S8 = v.ld + 16u;
+    float *qs = reinterpret_cast<float *>(smem);
+    unsigned char *qs8 = smem;
+    float *b_key = reinterpret_cast<float *>(smem + fss_q_bytes<PREC>(v.ld));  // [16][cap_s]
     uint32_t *b_id = reinterpret_cast<uint32_t *>(b_key + FSS_TQ * cap_s);    // [16][cap_s]
     float *tau = reinterpret_cast<float *>(b_id + FSS_TQ * cap_s);            // [16]
     uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FSS_TQ);            // [16]
@@ -550,11 +560,21 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     uint32_t row_end = row_begin + geo.rows_per_stripe;
     if (row_end > geo.n_scan) row_end = geo.n_scan;
 
-    for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 2); i += 256) {
-        const uint32_t n = i / (v.ld >> 2), c = i % (v.ld >> 2);
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < nq) x = *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + n) * v.ld + c * 4u);
-        *reinterpret_cast<float4 *>(qs + n * S + c * 4u) = x;
+    if (PREC == KDB_PREC_I8) { // prepared int8 queries: ld bytes per row
+        const unsigned char *q8 = reinterpret_cast<const unsigned char *>(queries);
+        for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 4); i += 256) {
+            const uint32_t n = i / (v.ld >> 4), c = i % (v.ld >> 4);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < nq) x = *reinterpret_cast<const float4 *>(q8 + (size_t)(q0 + n) * v.ld + c * 16u);
+            *reinterpret_cast<float4 *>(qs8 + n * S8 + c * 16u) = x;
+        }
+    } else {
+        for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 2); i += 256) {
+            const uint32_t n = i / (v.ld >> 2), c = i % (v.ld >> 2);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < nq) x = *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + n) * v.ld + c * 4u);
+            *reinterpret_cast<float4 *>(qs + n * S + c * 4u) = x;
+        }
     }
     if (tid < FSS_TQ) {
         tau[tid] = INFINITY;
@@ -565,7 +585,9 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows);
-    const uint32_t nsteps = v.ld >> 4;
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(v.rows);
+    // one step = one 16-byte load per lane: 16 k-values of a f32/f16 row, 64 of an int8 row
+    const uint32_t nsteps = PREC == KDB_PREC_I8 ? (v.ld + 63u) >> 6 : v.ld >> 4;
     // a tile is cut into an EVEN number of register chunks (<= FSS_CH steps each), so that every tile starts
     // in buffer A and the per-tile side loads below have a fixed place in the pipeline
     const uint32_t nch = 2u * ((nsteps + 2u * FSS_CH - 1u) / (2u * FSS_CH));
@@ -590,7 +612,11 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
                 const uint32_t step = ch * cs + (uint32_t)u;
                 const uint32_t col = step * 16u + (uint32_t)fg * 4u;
                 if ((uint32_t)u < cs && step < nsteps) {
-                    if (PREC == KDB_PREC_F16) {
+                    if (PREC == KDB_PREC_I8) { // bytes as they are; the last step of a row may be partial
+                        const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
+                        dst[a][u] = cb < v.ld ? *reinterpret_cast<const float4 *>(rows8 + (size_t)ld_id[a] * v.ld + cb)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else if (PREC == KDB_PREC_F16) {
                         const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)ld_id[a] * v.ld + col);
                         dst[a][u] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
                                                 (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
@@ -609,6 +635,17 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
         for (int u = 0; u < FSS_CH; u++) {
             const uint32_t step = ch * cs + (uint32_t)u;
             if ((uint32_t)u >= cs || step >= nsteps) break;
+            if (PREC == KDB_PREC_I8) { // exact i32 dots: one 16x16x64 MFMA per 16-row group and step
+                const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
+                const float4 q16 = cb < v.ld ? *reinterpret_cast<const float4 *>(qs8 + (uint32_t)fi * S8 + cb)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+                    acc[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                                          __builtin_bit_cast(i32x4, src[a][u]), __builtin_bit_cast(i32x4, q16),
+                                                          __builtin_bit_cast(i32x4, acc[a]), 0, 0, 0));
+                continue;
+            }
             const float4 qf = *reinterpret_cast<const float4 *>(qs + (uint32_t)fi * S + step * 16u + (uint32_t)fg * 4u);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -633,7 +670,7 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
         }
     };
     auto sel_load_norms = [&]() {
-        if (METRIC == KDB_METRIC_L2) {
+        if (METRIC == KDB_METRIC_L2 || PREC == KDB_PREC_I8) {
 #pragma unroll
             for (int e = 0; e < 8; e++) sel_nrm[e] = v.norms[sel_id[e]];
         }
@@ -646,8 +683,10 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
             for (int e = 0; e < 8; e++) {
                 const uint32_t rid = sel_id[e];
                 if (rid == 0u) continue; // past the end of the stripe
-                const float dotv = acc[e >> 2][e & 3];
-                const float key = METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, sel_nrm[e]);
+                const float rawv = acc[e >> 2][e & 3];
+                const float dotv = PREC == KDB_PREC_I8 ? (float)__float_as_int(rawv) : rawv;
+                const float key = PREC == KDB_PREC_I8 ? -dotv * (sel_nrm[e] == 0.f ? 0.f : 1.0f / sel_nrm[e])
+                                  : METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, sel_nrm[e]);
                 if (!fs_better(key, rid, t_k, t_id)) continue;
                 const uint32_t pos = atomicAdd(&cnt[fi], 1u); // < cap_s: every buffer has room for a whole tile
                 b_key[(uint32_t)fi * cap_s + pos] = key;
@@ -1116,8 +1155,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
     const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
-    const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
-    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u && v.precision != KDB_PREC_I8;
+    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
+                         (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
     //      waits for the device: the number of rows to scan stays in HBM and every kernel derives the stripe
@@ -1190,7 +1230,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_OK;
     };
     if (small) {
-        if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+        if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
+        else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
         else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
         else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
@@ -1228,15 +1269,12 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
         return KDB_ERR_INVALID;
     }
-    if (v.precision == KDB_PREC_I8) {
-        kdb_set_error("grouped flat scan: int8 rows are not supported (float32 and float16 are)");
-        return KDB_ERR_UNSUPPORTED;
-    }
     if (B == 0 || G == 0) return KDB_OK;
-    const bool rescore = v.metric != KDB_METRIC_COSINE;
+    const bool rescore = v.metric != KDB_METRIC_COSINE || v.precision == KDB_PREC_I8;
     const uint32_t kl = !rescore ? k : (k + 16 > 144 ? 144 : k + 16);
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
-    const size_t lds_s = (size_t)FSS_TQ * fss_qstride(v.ld) * 4 + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
+                         (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
     if (lds_s > 150u * 1024u) {
         kdb_set_error("grouped flat scan: %u-d rows need %zu bytes of LDS per workgroup", v.dim, lds_s);
         return KDB_ERR_UNSUPPORTED;
@@ -1353,7 +1391,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_q), p, T, cap_s);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
+    else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
@@ -1367,7 +1406,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
+    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;

@@ -262,7 +262,7 @@ def test_flat_scan_f16(oracle, hip):
         assert np.array_equal(dist[b].astype(np.float64), od)
 
 
-@pytest.mark.parametrize("n,dim,k,B", [(6000, 200, 10, 150), (3000, 768, 50, 9)])
+@pytest.mark.parametrize("n,dim,k,B", [(6000, 200, 10, 150), (3000, 768, 50, 9), (2500, 200, 10, 5), (4000, 96, 20, 40)])
 def test_flat_scan_int8(oracle, hip, n, dim, k, B):
     """int8 rows (cosine only, hnsw_index.go:219-222): exact i32 dots on the int8 MFMA, ranking by -dot/||x||,
     finalists re-scored with the f64 cosine scaling of the search path (hnsw_index.go:2429-2454)"""
@@ -614,3 +614,42 @@ def test_error_behaviour_on_gpu(oracle, hip):
     # the first handle still answers exactly as before
     again = idx.search_batch(Q, 5, 20)
     assert all(np.array_equal(a, b) for a, b in zip(good, again))
+
+
+def test_flat_scan_groups_int8(oracle, hip):
+    """the grouped exact scan on an int8 index (i8 MFMA, finalists re-scored with the f64 cosine scaling)"""
+    import torch
+    from kektordb_amd.index import dense_bitset
+    O = oracle
+    n, dim, k = 4000, 128, 10
+    X = make_corpus(n, dim, "normal", seed=83)
+    orc = O.OracleIndex(dim, 1, O.I8, 16, 40, seed=7)
+    orc.set_absmax(float(np.quantile(np.abs(X / np.linalg.norm(X, axis=1, keepdims=True)), 0.999)))
+    orc.add_many(X)
+    idx = hip.HipIndex(dim, 1, O.I8, 16, 40, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_norms(orc.norms()[1:], 1)
+    idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    rng = np.random.default_rng(4)
+    lists = []
+    for sel in (0.25, 0.03):
+        a = np.nonzero(rng.random(n + 1) < sel)[0]
+        lists.append(dense_bitset(a[a >= 1], n))
+    L = np.stack(lists)
+    off = np.array([0, 18, 25], dtype=np.uint32)
+    B = 25
+    Q = make_corpus(B, dim, "normal", seed=84)
+    dev = torch.device("cuda:0")
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    od = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    idx.flat_scan_groups_dev(torch.from_numpy(Q).to(dev), k, off, torch.from_numpy(L.view(np.int64)).to(dev), oi, od, oc)
+    idx.sync()
+    ids, dist, cnt = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy()
+    for g in range(2):
+        for b in range(int(off[g]), int(off[g + 1])):
+            want_i, want_d = orc.flat_scan(Q[b], k, allow=L[g])
+            c = int(cnt[b])
+            assert c == len(want_i)
+            assert_same_results_tol(ids[b, :c], dist[b, :c].astype(np.float64), want_i, want_d)
