@@ -32,6 +32,7 @@ constexpr uint32_t FS_MAX_MERGE = 16384; // entries one merge workgroup gathers 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct FsParams {
     const uint32_t *scan_ids; // compacted ids (filter / deletes) or null = identity (id = r+1)
@@ -240,8 +241,9 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: IEEE binary16 bits
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(v.rows); // PREC == I8: ld bytes per row
     const unsigned char *queries8 = reinterpret_cast<const unsigned char *>(queries);
-    // a slab is 128 BYTES of every row in LDS: 32 floats (f32, or f16 widened), or 128 int8 components
-    constexpr uint32_t SLAB_ELEMS = PREC == KDB_PREC_I8 ? 128u : (uint32_t)FS_BK;
+    // a slab is 128 BYTES of every row in LDS: 32 floats (f32), 64 halfs (f16, raw: the f16 MFMA ranks, the merge
+    // kernel re-scores exactly), or 128 int8 components
+    constexpr uint32_t SLAB_ELEMS = PREC == KDB_PREC_I8 ? 128u : PREC == KDB_PREC_F16 ? 64u : (uint32_t)FS_BK;
     const uint32_t nslab = (v.ld + SLAB_ELEMS - 1u) / SLAB_ELEMS; // ld is a multiple of 16; the last slab may be partial
     // staging map: thread t loads float4 #(t%8) of rows t/8 + 32*i (i<4) of both operands
     const int s_r = tid >> 3, s_c = tid & 7;
@@ -272,16 +274,20 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                                : make_float4(0.f, 0.f, 0.f, 0.f);
                     continue;
                 }
-                if (PREC == KDB_PREC_F16) { // half the row bytes; widened to f32 on the way into LDS (exact)
-                    uint2 h = in ? *reinterpret_cast<const uint2 *>(rows16 + (size_t)a_id[i] * v.ld + col) : make_uint2(0u, 0u);
-                    ra[i] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
-                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
-                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)),
-                                        (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
-                } else {
-                    ra[i] = in ? *reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (PREC == KDB_PREC_F16) { // 8 raw halfs of the row; the query (f32 values that are exact halfs) packed alike
+                    ra[i] = in ? *reinterpret_cast<const float4 *>(rows16 + (size_t)a_id[i] * v.ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    f16x8 hq = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (in) {
+                        const float4 *qp = reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col);
+                        const float4 y0 = qp[0], y1 = qp[1];
+                        hq = (f16x8){(_Float16)y0.x, (_Float16)y0.y, (_Float16)y0.z, (_Float16)y0.w,
+                                     (_Float16)y1.x, (_Float16)y1.y, (_Float16)y1.z, (_Float16)y1.w};
+                    }
+                    rb[i] = __builtin_bit_cast(float4, hq);
+                    continue;
                 }
+                ra[i] = in ? *reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 rb[i] = in ? *reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -303,6 +309,15 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 for (int t = 0; t < 4; t++) {
                     fa[t] = *reinterpret_cast<const float4 *>(lds_a + (wr * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
                     fb[t] = *reinterpret_cast<const float4 *>(lds_b + (wq * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
+                }
+                if (PREC == KDB_PREC_F16) { // ranking only: f16 x f16 products are exact in f32, the sum order is the MFMA's
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[a]), __builtin_bit_cast(f16x8, fb[b]),
+                                                                               acc[a][b], 0, 0, 0);
+                    continue;
                 }
                 if (PREC == KDB_PREC_I8) { // exact i32 dot: one 16x16x64 MFMA per tile and 64-byte step
 #pragma unroll

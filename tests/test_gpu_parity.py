@@ -245,11 +245,13 @@ def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
     assert np.array_equal(ids2, ids3) and np.array_equal(cnt2, cnt3)
 
 
-def test_flat_scan_f16(oracle, hip):
-    """float16 rows (euclidean only, hnsw_index.go:210-213): MFMA ranking on the widened rows, exact re-score in
-    the f16 wave order -> bit-exact against the oracle"""
+@pytest.mark.parametrize("B", [40, 150])
+def test_flat_scan_f16(oracle, hip, B):
+    """float16 rows (euclidean only, hnsw_index.go:210-213): MFMA ranking (small batches: rows widened onto the f32
+    MFMA; large batches: the f16 MFMA on the raw halfs), exact re-score in the f16 wave order -> bit-exact against
+    the oracle"""
     O = oracle
-    n, dim, k, B = 4000, 96, 10, 40
+    n, dim, k = 4000, 96, 10
     X = make_corpus(n, dim, "normal", seed=71)
     orc, idx = build_pair(O, hip, X, 0, precision=O.F16, efc=20)
     orc.set_arith(O.ARITH_HIP_WAVE)
