@@ -46,6 +46,7 @@ struct FsParams {
     const uint32_t *g_nscan;  // [G] rows that survive group g's filter
     const uint32_t *g_base;   // [G] where group g's ids start in scan_ids
     const uint32_t *g_of_query; // [B]
+    uint32_t lists_query_major; // per-stripe lists: 0 = [tile][entry][128 queries] (tile kernel), 1 = [query][entry] (small kernel)
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
@@ -764,11 +765,11 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
             (void)fs_compact_wave<1>(b_key + q * cap_s, b_id + q * cap_s, c, p.kl);
             c = p.kl;
         }
-        const uint32_t qg = q0 + q; // layout of flat_merge_kernel: [stripe][query tile of 128][entry][query % 128]
-        const size_t lb = ((size_t)stripe * p.n_qtiles + qg / FS_TQ) * p.cap * FS_TQ + (qg % FS_TQ);
+        const uint32_t qg = q0 + q; // query-major lists: [stripe][query][entry] (contiguous for the merge kernel)
+        const size_t lb = ((size_t)stripe * p.n_qtiles * FS_TQ + qg) * p.cap;
         for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
-            p.part_key[lb + (size_t)i * FS_TQ] = b_key[q * cap_s + i];
-            p.part_id[lb + (size_t)i * FS_TQ] = b_id[q * cap_s + i];
+            p.part_key[lb + i] = b_key[q * cap_s + i];
+            p.part_id[lb + i] = b_id[q * cap_s + i];
         }
         if (lane == 0) p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + qg] = c;
     }
@@ -808,7 +809,8 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + 256);           // [256]
     uint32_t *red = fin_id + 256;                                           // [8]
     uint32_t *ctl = red + 8;                                                // [4]: total, nfin
-    float *qlds = reinterpret_cast<float *>(ctl + 4);                       // [ld]
+    uint32_t *hist = ctl + 4;                                               // [256] radix-select bins
+    float *qlds = reinterpret_cast<float *>(hist + 256);                    // [ld]
     const uint32_t q = blockIdx.x;
     const int tid = (int)threadIdx.x;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -838,11 +840,26 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         if (tid == 0) ctl[0] += red[0] + red[1] + red[2] + red[3];
         __syncthreads();
     }
-    for (uint32_t e = (uint32_t)tid; e < n_stripes * p.kl; e += 256) { // gather: all loads independent
-        const uint32_t sidx = e / p.kl, i = e % p.kl;
-        if (i < scnt[sidx]) {
-            const size_t lb = ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ); // entry-major lists
-            ent[sbase[sidx] + i] = fs_pack(p.part_key[lb + (size_t)i * FS_TQ], p.part_id[lb + (size_t)i * FS_TQ]);
+    // gather, one stripe per thread at a time (query-major lists of the small kernel are contiguous runs)
+    for (uint32_t sidx = (uint32_t)tid; sidx < n_stripes; sidx += 256) {
+        const uint32_t c = scnt[sidx];
+        const size_t lb = p.lists_query_major ? ((size_t)sidx * qstride + q) * p.cap
+                                              : ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ);
+        const size_t est = p.lists_query_major ? 1 : (size_t)FS_TQ;
+        for (uint32_t i0 = 0; i0 < c; i0 += 8) { // 8 entries' loads in flight together
+            float kk[8];
+            uint32_t ii[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + (uint32_t)u < c ? i0 + (uint32_t)u : i0;
+                kk[u] = p.part_key[lb + i * est];
+                ii[u] = p.part_id[lb + i * est];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (i0 + (uint32_t)u >= c) break;
+                ent[sbase[sidx] + i0 + (uint32_t)u] = fs_pack(kk[u], ii[u]);
+            }
         }
     }
     __syncthreads();
@@ -852,14 +869,51 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (want > 256u) want = 256u;
     const uint32_t nf = n < want ? n : want;
     unsigned long long T = ~0ull;
-    if (n > want) {
+    if (n > want && n <= 256u) { // few survivors: rank by counting, one pass instead of a 32-step search
+        unsigned long long e = ~0ull;
+        uint32_t rank = 0;
+        if ((uint32_t)tid < n) {
+            e = ent[tid];
+            for (uint32_t j = 0; j < n; j++) rank += ent[j] < e ? 1u : 0u;
+            if (rank == want - 1u) reinterpret_cast<unsigned long long *>(red)[0] = e; // the boundary entry
+        }
+        __syncthreads();
+        T = reinterpret_cast<const unsigned long long *>(red)[0];
+        __syncthreads();
+    } else if (n > want) {
         uint32_t step = 0;
-        uint32_t Tk = 0;
-        for (int bit = 31; bit >= 0; bit--, step++) {
-            const uint32_t test = Tk | ((1u << bit) - 1u);
-            uint32_t c = 0;
-            for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += (uint32_t)(ent[i] >> 32) <= test ? 1u : 0u;
-            if (fs_block_sum(c, red, tid, step) < want) Tk |= 1u << bit;
+        // radix select on the ordered 32-bit keys, 8 bits per pass: histogram of the next byte of the entries that
+        // still match the prefix (LDS atomics on 256 bins), the bin in which the running count crosses `want` extends
+        // the prefix.  4 passes instead of 32 compare-and-count steps.
+        uint32_t Tk = 0, rem = want; // rem: how many more entries are needed from the still-matching set
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t pmask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+                const uint32_t kk = (uint32_t)(ent[i] >> 32);
+                if ((kk & pmask) == (Tk & pmask)) atomicAdd(&hist[(kk >> shift) & 0xffu], 1u);
+            }
+            __syncthreads();
+            // inclusive scan of the 256 bins (4 waves x 64 lanes), then the first bin whose cumulative count >= rem
+            const uint32_t hv = hist[tid];
+            uint32_t inc = hv;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+                if ((tid & 63) >= o) inc += t;
+            }
+            if ((tid & 63) == 63) red[tid >> 6] = inc;
+            __syncthreads();
+            for (int w = 0; w < (tid >> 6); w++) inc += red[w];
+            if (inc >= rem && inc - hv < rem) { // exactly one bin satisfies this
+                red[4] = (uint32_t)tid;
+                red[5] = rem - (inc - hv);
+            }
+            __syncthreads();
+            Tk |= red[4] << shift;
+            rem = red[5];
+            __syncthreads();
         }
         uint32_t c_lt = 0, c_eq = 0;
         for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
@@ -1225,6 +1279,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     p.part_key = reinterpret_cast<float *>(part);
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * cap * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * cap * 8);
+    p.lists_query_major = small ? 1u : 0u;
     const uint32_t n_stripes = want; // upper bound: workgroups of stripes past the resolved count return at once
 
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
@@ -1257,7 +1312,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
@@ -1394,6 +1449,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.part_key = reinterpret_cast<float *>(part);
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
+    p.lists_query_major = 1u;
     p.g_tile = d_tiles;
     p.g_nscan = d_gn;
     p.g_base = d_gbase;
@@ -1414,7 +1470,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = want * kl;
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
