@@ -33,6 +33,7 @@ constexpr uint32_t FS_MAX_MERGE = 16384; // entries one merge workgroup gathers 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int FS_PREC_F32R = 3; // internal: float32 rows RANKED on the f16 MFMA (converted while staging), re-scored exactly
 
 struct FsParams {
     const uint32_t *scan_ids; // compacted ids (filter / deletes) or null = identity (id = r+1)
@@ -46,6 +47,13 @@ struct FsParams {
     const uint32_t *g_nscan;  // [G] rows that survive group g's filter
     const uint32_t *g_base;   // [G] where group g's ids start in scan_ids
     const uint32_t *g_of_query; // [B]
+    // f16-ranked float32 scan: error band of the approximate scores, queries that could not be settled inside it
+    float band;               // 2*eps (keys are -dot)
+    uint32_t *fb_count;       // number of queries sent to the exact pass
+    uint32_t *fb_list;        // their indices
+    // exact pass over those queries: how many there are (device), where their results go
+    const uint32_t *b_dev;
+    const uint32_t *q_map;
     uint32_t lists_query_major; // per-stripe lists: 0 = [tile][entry][128 queries] (tile kernel), 1 = [query][entry] (small kernel)
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
@@ -210,6 +218,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const FsGeom geo = fs_resolve(p);
     if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
     if (stripe >= geo.n_stripes) return;
+    if (p.b_dev && qtile * FS_TQ >= *p.b_dev) return; // exact pass: only the query tiles that hold unsettled queries
 
     const uint32_t row_begin = stripe * geo.rows_per_stripe;
     uint32_t row_end = row_begin + geo.rows_per_stripe;
@@ -244,7 +253,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const unsigned char *queries8 = reinterpret_cast<const unsigned char *>(queries);
     // a slab is 128 BYTES of every row in LDS: 32 floats (f32), 64 halfs (f16, raw: the f16 MFMA ranks, the merge
     // kernel re-scores exactly), or 128 int8 components
-    constexpr uint32_t SLAB_ELEMS = PREC == KDB_PREC_I8 ? 128u : PREC == KDB_PREC_F16 ? 64u : (uint32_t)FS_BK;
+    constexpr uint32_t SLAB_ELEMS = PREC == KDB_PREC_I8 ? 128u : (PREC == KDB_PREC_F16 || PREC == FS_PREC_F32R) ? 64u : (uint32_t)FS_BK;
     const uint32_t nslab = (v.ld + SLAB_ELEMS - 1u) / SLAB_ELEMS; // ld is a multiple of 16; the last slab may be partial
     // staging map: thread t loads float4 #(t%8) of rows t/8 + 32*i (i<4) of both operands
     const int s_r = tid >> 3, s_c = tid & 7;
@@ -273,6 +282,22 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     ra[i] = in ? *reinterpret_cast<const float4 *>(rows8 + (size_t)a_id[i] * v.ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                     rb[i] = in ? *reinterpret_cast<const float4 *>(queries8 + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
+                if (PREC == FS_PREC_F32R) { // 8 floats of the row and of the query -> 8 halfs each (RNE)
+                    f16x8 hr = {0, 0, 0, 0, 0, 0, 0, 0}, hq = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (in) {
+                        const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col);
+                        const float4 x0 = rp[0], x1 = rp[1];
+                        hr = (f16x8){(_Float16)x0.x, (_Float16)x0.y, (_Float16)x0.z, (_Float16)x0.w,
+                                     (_Float16)x1.x, (_Float16)x1.y, (_Float16)x1.z, (_Float16)x1.w};
+                        const float4 *qp = reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col);
+                        const float4 y0 = qp[0], y1 = qp[1];
+                        hq = (f16x8){(_Float16)y0.x, (_Float16)y0.y, (_Float16)y0.z, (_Float16)y0.w,
+                                     (_Float16)y1.x, (_Float16)y1.y, (_Float16)y1.z, (_Float16)y1.w};
+                    }
+                    ra[i] = __builtin_bit_cast(float4, hr);
+                    rb[i] = __builtin_bit_cast(float4, hq);
                     continue;
                 }
                 if (PREC == KDB_PREC_F16) { // 8 raw halfs of the row; the query (f32 values that are exact halfs) packed alike
@@ -311,7 +336,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     fa[t] = *reinterpret_cast<const float4 *>(lds_a + (wr * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
                     fb[t] = *reinterpret_cast<const float4 *>(lds_b + (wq * 64 + t * 16 + fi) * FS_LDS_STRIDE + s * 16 + fg * 4);
                 }
-                if (PREC == KDB_PREC_F16) { // ranking only: f16 x f16 products are exact in f32, the sum order is the MFMA's
+                if (PREC == KDB_PREC_F16 || PREC == FS_PREC_F32R) { // ranking only: f16 x f16 products are exact in f32, the sum order is the MFMA's
 #pragma unroll
                     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -799,7 +824,7 @@ __device__ __forceinline__ uint32_t fs_block_sum(uint32_t v, uint32_t *red /*[8]
     return slot[0] + slot[1] + slot[2] + slot[3];
 }
 
-template <int METRIC, int PREC>
+template <int METRIC, int PREC, int BAND>
 __global__ void __launch_bounds__(256)
 flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__restrict__ qnorm, FsParams p, uint32_t k,
                   uint32_t nmax, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
@@ -813,12 +838,15 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     float *qlds = reinterpret_cast<float *>(hist + 256);                    // [ld]
     const uint32_t q = blockIdx.x;
     const int tid = (int)threadIdx.x;
+    if (p.b_dev && q >= *p.b_dev) return;               // exact pass over the unsettled queries only
+    const uint32_t qo = p.q_map ? p.q_map[q] : q;       // where this query's answer goes
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     const uint32_t qstride = p.n_qtiles * FS_TQ;
     const uint32_t n_stripes = (p.g_of_query ? fs_resolve_n(p, p.g_nscan[p.g_of_query[q]]) : fs_resolve(p)).n_stripes; // <= p.want
     uint32_t *sbase = reinterpret_cast<uint32_t *>(qlds + v.ld); // [want] first entry of every stripe's list
     uint32_t *scnt = sbase + p.want;                             // [want]
+    float *sworst = reinterpret_cast<float *>(scnt + p.want);    // [want] worst key a stripe kept (band mode)
     for (uint32_t s0 = 0; s0 < n_stripes; s0 += 256) { // exclusive scan of the stripe counts, 256 at a time
         const uint32_t sidx = s0 + (uint32_t)tid;
         const uint32_t c = sidx < n_stripes ? p.part_cnt[(size_t)sidx * qstride + q] : 0u;
@@ -846,6 +874,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const size_t lb = p.lists_query_major ? ((size_t)sidx * qstride + q) * p.cap
                                               : ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ);
         const size_t est = p.lists_query_major ? 1 : (size_t)FS_TQ;
+        float worst = -INFINITY;
         for (uint32_t i0 = 0; i0 < c; i0 += 8) { // 8 entries' loads in flight together
             float kk[8];
             uint32_t ii[8];
@@ -859,15 +888,18 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
             for (int u = 0; u < 8; u++) {
                 if (i0 + (uint32_t)u >= c) break;
                 ent[sbase[sidx] + i0 + (uint32_t)u] = fs_pack(kk[u], ii[u]);
+                worst = kk[u] > worst ? kk[u] : worst;
             }
         }
+        if (BAND) sworst[sidx] = worst;
     }
     __syncthreads();
     const uint32_t n = ctl[0];
-    constexpr bool RESCORE = METRIC == KDB_METRIC_L2 || PREC == KDB_PREC_I8; // selection keys were approximate
-    uint32_t want = RESCORE ? p.kl : k;
+    // Every scan ranks on a key that is approximate or summed in another order (MFMA order, ||x||^2 - 2 q.x, -dot/||x||,
+    // f16 products) and RE-SCORES its finalists in the order of the graph search, so a (query, row) pair has the same
+    // distance bits whichever kernel produced it.  want = how many finalists the selection below isolates.
+    uint32_t want = BAND ? k : p.kl;
     if (want > 256u) want = 256u;
-    const uint32_t nf = n < want ? n : want;
     unsigned long long T = ~0ull;
     if (n > want && n <= 256u) { // few survivors: rank by counting, one pass instead of a 32-step search
         unsigned long long e = ~0ull;
@@ -937,6 +969,27 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         }
         T = ((unsigned long long)Tk << 32) | Ti;
     }
+    uint32_t nf = n < want ? n : want;
+    if (BAND && n > want) {
+        // f16-ranked scores carry an error <= eps: every true top-k row has an approximate key within band = 2*eps of
+        // the k-th best approximate key.  All of those are re-scored -- provided the lists still hold them all: a
+        // stripe that kept kl entries and whose worst kept key is inside the band may have dropped some.
+        const unsigned long long Tb = fs_pack(fs_unpack_key(T) + p.band, 0xffffffffu);
+        uint32_t c = 0, sat = 0;
+        for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += ent[i] <= Tb ? 1u : 0u;
+        for (uint32_t sidx = (uint32_t)tid; sidx < n_stripes; sidx += 256)
+            sat += (scnt[sidx] >= p.kl && fs_pack(sworst[sidx], 0u) <= Tb) ? 1u : 0u;
+        __syncthreads(); // the reduction scratch may still be read by a slower thread of the selection above
+        const uint32_t n_band = fs_block_sum(c, red, tid, 0);
+        const uint32_t n_sat = fs_block_sum(sat, red, tid, 1);
+        __syncthreads();
+        if (n_band > 256u || n_sat) { // not settled here: the exact pass answers this query
+            if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = qo;
+            return;
+        }
+        T = Tb;
+        nf = n_band;
+    }
     // gather the finalists (any order)
     for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
         const unsigned long long e = ent[i];
@@ -950,9 +1003,9 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     }
     __syncthreads();
     const uint32_t nout = nf < k ? nf : k;
-    if (RESCORE) {
-        // exact re-score of the nf finalists: the approximate key (||x||^2 - 2 q.x, or -dot/||x||) is replaced by
-        // the distance of the search path (wave-order squared L2; int8: i32 dot + f64 cosine scaling)
+    {
+        // exact re-score of the nf finalists in the order of the search path (wave-order squared L2 / dot; int8: i32
+        // dot + the f64 cosine scaling)
         const uint32_t qwords = PREC == KDB_PREC_I8 ? (v.ld >> 4) : (v.ld >> 2); // 16-byte pieces of the query row
         const float4 *qsrc = PREC == KDB_PREC_I8
                                  ? reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(queries) + (size_t)q * v.ld)
@@ -971,6 +1024,8 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
                 part = kdb_i8_distance(dot, qnorm[q], v.norms[id]);
             } else if (PREC == KDB_PREC_F16) {
                 part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            } else if (METRIC == KDB_METRIC_COSINE) { // key = -dot
+                part = -kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_COSINE>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
             } else {
                 part = kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
             }
@@ -984,15 +1039,25 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         uint32_t rank = 0;
         for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
         if (rank < k) {
-            out_ids[(size_t)q * k + rank] = id;
-            out_dist[(size_t)q * k + rank] = RESCORE ? d : -d; // f32 cosine: raw dot
+            out_ids[(size_t)qo * k + rank] = id;
+            out_dist[(size_t)qo * k + rank] = (METRIC == KDB_METRIC_COSINE && PREC == KDB_PREC_F32) ? -d : d; // f32 cosine: raw dot
         }
     }
     for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
-        out_ids[(size_t)q * k + i] = 0u;
-        out_dist[(size_t)q * k + i] = INFINITY;
+        out_ids[(size_t)qo * k + i] = 0u;
+        out_dist[(size_t)qo * k + i] = INFINITY;
     }
-    if (tid == 0) out_count[q] = nout;
+    if (tid == 0) out_count[qo] = nout;
+}
+
+// exact pass of the f16-ranked scan: the prepared vectors of the unsettled queries, made contiguous
+__global__ void gather_queries_kernel(const float *__restrict__ src, uint32_t ld, const uint32_t *list, const uint32_t *count,
+                                      float *__restrict__ dst) {
+    const uint32_t i = blockIdx.x;
+    if (i >= *count) return;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src + (size_t)list[i] * ld);
+    float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)i * ld);
+    for (uint32_t c = threadIdx.x; c < (ld >> 2); c += blockDim.x) d4[c] = s4[c];
 }
 
 // ids of rows that are live (and allowed).  One thread per 32-bit word of the bitsets, one atomic per WORKGROUP
@@ -1218,15 +1283,17 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     }
     if (B == 0) return KDB_OK;
     const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
-    // L2 and int8 select by an approximate key and re-score: 16 extra candidates absorb its rounding
-    const bool rescore = v.metric != KDB_METRIC_COSINE || v.precision == KDB_PREC_I8;
-    const uint32_t kl = !rescore ? k : (k + 16 > 144 ? 144 : k + 16);
+    // every scan selects by a key that is approximate or summed in another order and re-scores its finalists in the
+    // order of the graph search: 16 extra candidates absorb the difference
+    const uint32_t kl = k + 16 > 144 ? 144 : k + 16;
     // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
     const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
     const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
                          (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
+    // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly
+    const bool rank16 = !small && v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE && !getenv("KDB_FLAT_EXACT_ONLY");
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
     //      waits for the device: the number of rows to scan stays in HBM and every kernel derives the stripe
@@ -1253,12 +1320,17 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // buffered mode: kl entries + room for max(kl, 64) appends between two compactions (<= 320 in all)
     const uint32_t cap = (small || kl <= (uint32_t)FS_LDS_KL) ? kl : kl + (kl > 64u ? kl : 64u);
     const size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
-    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + part_bytes + (size_t)n_qtiles * FS_TQ * v.ld * 4 + 4096);
+    const size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
+    const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
+    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + part_bytes + 4096);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
     uint32_t *d_nscan = reinterpret_cast<uint32_t *>(base + ids_bytes);
-    unsigned char *part = base + ids_bytes + 256;
+    float *d_fbq = reinterpret_cast<float *>(base + ids_bytes + 256);
+    uint32_t *d_fblist = reinterpret_cast<uint32_t *>(base + ids_bytes + 256 + fbq_bytes);
+    uint32_t *d_fbcount = d_nscan + 4; // inside the 256-byte header
+    unsigned char *part = base + ids_bytes + 256 + fbq_bytes + fbl_bytes;
     if (need_ids) {
         KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
         hipLaunchKernelGGL(compact_ids_kernel, dim3(((v.count >> 5) + 256) / 256), dim3(256), 0, s, v.deleted, d_allow, d_first_allowed,
@@ -1287,6 +1359,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
     p.ctr = kdb_stats_begin(idx, 2, B, 0);
+    unsigned long long *stat_slot = p.ctr;
+    KDB_HIP(hipMemsetAsync(stat_slot, 0, 32, s));
     KDB_HIP(hipEventRecord(idx->ev0, s));
     auto launch_scan = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1306,23 +1380,53 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
     else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
+    else if (rank16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
-    auto launch_merge = [&](auto kern) -> int {
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
+    auto launch_merge = [&](auto kern, const FsParams &pp, const void *qv) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(qv), d_qnorm, pp, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
-    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
-    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
-    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (rank16) {
+        // eps bounds |q.x (wave order) - sum f16(q)f16(x) (MFMA order)| for rows and queries of norm <= 1: f16 rounding
+        // of both factors (2^-10 and its square), f32 summation in either order (dim * 2^-23); band = 2 * eps
+        // rows of norm R widen it by R (queries are normalised by the preparation step)
+        const float rmax = idx->max_norm2 > 1.0f ? sqrtf(idx->max_norm2) : 1.0f;
+        p.band = 2.0f * (9.9e-4f + (float)v.dim * 2.4e-7f) * rmax * 1.001f;
+        p.fb_count = d_fbcount;
+        p.fb_list = d_fblist;
+        KDB_HIP(hipMemsetAsync(d_fbcount, 0, 4, s));
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p, d_q);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        // the exact pass over the queries the band could not settle (usually none: every launch below returns at
+        // once); their number never leaves the device
+        hipLaunchKernelGGL(gather_queries_kernel, dim3(B), dim3(64), 0, s, reinterpret_cast<const float *>(d_q), v.ld, d_fblist,
+                           d_fbcount, d_fbq);
+        FsParams p2 = p;
+        p2.b_dev = d_fbcount;
+        p2.q_map = d_fblist;
+        p2.ctr = nullptr;
+        p2.fb_count = nullptr;
+        p2.fb_list = nullptr;
+        auto kx = flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>;
+        KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
+        KDB_HIP(hipGetLastError());
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
+        // statistics: how many queries the exact pass settled (kdb_counters.n_hops of a flat-scan launch)
+        KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbcount, 4, hipMemcpyDeviceToDevice, s));
+    } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>, p, d_q);
+    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, 0>, p, d_q);
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p, d_q);
+    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p, d_q);
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     return KDB_OK;
@@ -1340,8 +1444,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         return KDB_ERR_INVALID;
     }
     if (B == 0 || G == 0) return KDB_OK;
-    const bool rescore = v.metric != KDB_METRIC_COSINE || v.precision == KDB_PREC_I8;
-    const uint32_t kl = !rescore ? k : (k + 16 > 144 ? 144 : k + 16);
+    const uint32_t kl = k + 16 > 144 ? 144 : k + 16; // finalists are re-scored in the order of the graph search
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
     const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
                          (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
@@ -1470,17 +1573,17 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = want * kl;
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 8 + 16;
+    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
     auto launch_merge = [&](auto kern) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
-    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
-    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
-    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>);
+    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, 0>);
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>);
+    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>);
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     return KDB_OK;

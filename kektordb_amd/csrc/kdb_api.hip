@@ -280,12 +280,25 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
     unsigned char *dst = reinterpret_cast<unsigned char *>(idx->d_rows) + (size_t)first_id * lb;
     if (lb != rb) KDB_HIP(hipMemsetAsync(dst, 0, (size_t)n * lb, idx->stream)); // zero the pad columns
     KDB_HIP(hipMemcpy2DAsync(dst, lb, rows, rb, rb, n, kind, idx->stream));
-    if (idx->desc.precision != KDB_PREC_I8 && idx->desc.metric == KDB_METRIC_L2) { // ||x||^2 for flat-scan ranking
+    // ||x||^2 per row: ranking key of the L2 flat scan; for float32 rows also the largest one (error band of the
+    // f16-ranked cosine scan: the reference normalises cosine rows at insert, the mirror does not assume it)
+    const bool want_norms = idx->desc.precision != KDB_PREC_I8 &&
+                            (idx->desc.metric == KDB_METRIC_L2 || idx->desc.precision == KDB_PREC_F32);
+    uint32_t max_bits = 0;
+    if (want_norms) {
         KdbView v = kdb_make_view(idx);
-        int rc = kdb_launch_row_norms(v, idx->d_norms, first_id, n, idx->stream);
+        uint32_t *d_max = idx->desc.precision == KDB_PREC_F32 ? idx->d_work + 12 : nullptr;
+        if (d_max) KDB_HIP(hipMemsetAsync(d_max, 0, 4, idx->stream));
+        int rc = kdb_launch_row_norms(v, idx->d_norms, first_id, n, d_max, idx->stream);
         if (rc) return rc;
+        if (d_max) KDB_HIP(hipMemcpyAsync(&max_bits, d_max, 4, hipMemcpyDeviceToHost, idx->stream));
     }
     KDB_HIP(hipStreamSynchronize(idx->stream)); // host rows are consumed before returning (cgo rule)
+    if (max_bits) {
+        float m;
+        memcpy(&m, &max_bits, 4);
+        if (m > idx->max_norm2) idx->max_norm2 = m;
+    }
     return KDB_OK;
 }
 
@@ -1053,6 +1066,7 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
         r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
     } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
         r.n_dist = c[0] * (uint64_t)idx->ring_B[slot]; // rows scanned (after filter / deletes) x queries
+        r.n_hops = c[1];                               // f16-ranked scan: queries settled by the exact pass
         r.bytes = c[0] * row_bytes + (uint64_t)idx->ring_B[slot] * row_bytes;
     } else if (kind == 3) {
         r.n_dist = (uint64_t)idx->ring_B[slot] * idx->ring_C[slot];

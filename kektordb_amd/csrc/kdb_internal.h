@@ -57,6 +57,7 @@ struct kdb_index {
     uint8_t *d_levels = nullptr;
     uint32_t *d_deleted = nullptr;
     size_t up_slots = 0, up_slots_cap = 0;
+    float max_norm2 = 0.f; // largest ||x||^2 among the float32 rows uploaded so far (error band of the f16-ranked scan)
     // host copies of the per-node level and first upper slot (incremental refresh validates and places lists with them)
     std::vector<uint8_t> h_levels;
     std::vector<uint32_t> h_up_idx;
@@ -130,7 +131,7 @@ int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm,
                         const uint32_t *d_ids, uint32_t C, float *d_out, hipStream_t s);
 int kdb_launch_adj_scatter(uint32_t *d_dst, uint32_t deg, uint32_t n, const uint32_t *d_slots, const uint32_t *d_src, hipStream_t s);
 int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *d_out, hipStream_t s);
-int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, hipStream_t s);
+int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, uint32_t *d_max_bits, hipStream_t s);
 // flat_scan.hip
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,

@@ -394,7 +394,7 @@ __global__ void first_allowed_kernel(const uint32_t *allow, uint32_t words, uint
 }
 
 // ||x||^2 per row in the wave order (used by the L2 flat scan for ranking only)
-__global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32_t n) {
+__global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32_t n, uint32_t *max_bits) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
     const uint32_t r = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (uint32_t)g;
@@ -426,6 +426,12 @@ __global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32
     }
     float p = kdb_reduce16((a0 + a1) + (a2 + a3));
     if (act && t == 0) norms[id] = p;
+    if (max_bits) { // largest ||x||^2 of the upload (non-negative floats order like their bit patterns): one atomic per wave
+        float m = act ? p : 0.f;
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (lane == 0) atomicMax(max_bits, __float_as_uint(m));
+    }
 }
 
 template <typename K>
@@ -469,11 +475,11 @@ int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *
     return KDB_OK;
 }
 
-int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, hipStream_t s) {
+int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint32_t n, uint32_t *d_max_bits, hipStream_t s) {
     if (n == 0) return KDB_OK;
     const uint32_t rows_per_block = 16; // 4 waves x 4 rows
     hipLaunchKernelGGL(row_norms_kernel, dim3((n + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, v, d_norms,
-                       first, n);
+                       first, n, d_max_bits);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }

@@ -1,6 +1,6 @@
 """Generates tests/golden/quantised_flat_v1.npz: committed expectations for the quantised search paths (float16 /
 euclidean, int8 / cosine) and for the exact flat scan in every precision, produced by the restatement oracle in
-the GPU accumulation orders (wave order for searches and re-scored scans, MFMA order for the f32 cosine scan)
+the GPU accumulation order (wave order: searches, and the finalists every scan re-scores)
 AFTER it has passed the reference's known-answer tests.  Pins the oracle on CPU and gives the GPU tests a target
 that does not depend on the oracle's build-time behaviour.
 
@@ -63,8 +63,8 @@ def main():
                 ids[b, :len(i)], dist[b, :len(i)], cnt[b], ctr[b] = i, d, len(i), c
             key = f"{tag}_search_{'allow' if filt else 'all'}"
             out[key + "_ids"], out[key + "_dist"], out[key + "_cnt"], out[key + "_ctr"] = ids, dist, cnt, ctr
-        # exact scan: the f32 cosine scan reports MFMA-order dots, everything else is re-scored in the wave order
-        idx.set_arith(O.ARITH_HIP_MFMA if (prec == O.F32 and metric == O.COSINE) else O.ARITH_HIP_WAVE)
+        # exact scan: every precision re-scores its finalists in the wave order of the graph search
+        idx.set_arith(O.ARITH_HIP_WAVE)
         for filt in (False, True):
             ids = np.zeros((len(Q), k), np.uint32); dist = np.full((len(Q), k), np.inf); cnt = np.zeros(len(Q), np.int32)
             for b, q in enumerate(Q):
