@@ -1276,7 +1276,7 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
 
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
-                         float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
+                         float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s) {
     if (k == 0 || k > 128) {
         kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
         return KDB_ERR_INVALID;
@@ -1293,7 +1293,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                          (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
     // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly
-    const bool rank16 = !small && v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE && !getenv("KDB_FLAT_EXACT_ONLY");
+    // (only when the library normalised the queries itself and the rows are far from the f16 range limit)
+    const bool rank16 = !small && v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE && queries_normalised &&
+                        idx->max_norm2 > 0.f && idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
     //      waits for the device: the number of rows to scan stays in HBM and every kernel derives the stripe

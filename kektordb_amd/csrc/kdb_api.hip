@@ -854,7 +854,8 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
     float *d_qnorm = nullptr;
     int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
-    rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, d_first, d_out_ids, d_out_dist, d_out_count, s);
+    rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, d_first, d_out_ids, d_out_dist, d_out_count,
+                              (flags & KDB_SEARCH_PREPARED) ? 0 : 1, s);
     if (rc) return rc;
     return KDB_OK;
 }

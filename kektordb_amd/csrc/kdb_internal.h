@@ -135,7 +135,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 // flat_scan.hip
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
-                         float *d_out_dist, uint32_t *d_out_count, hipStream_t s);
+                         float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s);
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
                                 uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,
