@@ -895,6 +895,31 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     }
     __syncthreads();
     const uint32_t n = ctl[0];
+    float q_s2 = 0.f; // ||q||^2 (band of the f16-ranked L2 scan)
+    if (BAND && METRIC == KDB_METRIC_L2) {
+        // a query with components near the f16 range cannot be ranked in f16 at all: the exact pass answers it
+        float s2 = 0.f, mx = 0.f;
+        for (uint32_t i = (uint32_t)tid; i < v.dim; i += 256) {
+            const float y = queries[(size_t)q * v.ld + i];
+            s2 = __builtin_fmaf(y, y, s2);
+            mx = fmaxf(mx, fabsf(y));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            s2 += __shfl_xor(s2, o, 64);
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        }
+        float *rf = reinterpret_cast<float *>(red);
+        if ((tid & 63) == 0) { rf[tid >> 6] = s2; rf[4 + (tid >> 6)] = mx; }
+        __syncthreads();
+        q_s2 = (rf[0] + rf[1]) + (rf[2] + rf[3]);
+        mx = fmaxf(fmaxf(rf[4], rf[5]), fmaxf(rf[6], rf[7]));
+        __syncthreads();
+        if (!(mx < 3.0e4f) || !(q_s2 < 1.0e30f)) {
+            if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = qo;
+            return;
+        }
+    }
     // Every scan ranks on a key that is approximate or summed in another order (MFMA order, ||x||^2 - 2 q.x, -dot/||x||,
     // f16 products) and RE-SCORES its finalists in the order of the graph search, so a (query, row) pair has the same
     // distance bits whichever kernel produced it.  want = how many finalists the selection below isolates.
@@ -974,7 +999,11 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         // f16-ranked scores carry an error <= eps: every true top-k row has an approximate key within band = 2*eps of
         // the k-th best approximate key.  All of those are re-scored -- provided the lists still hold them all: a
         // stripe that kept kl entries and whose worst kept key is inside the band may have dropped some.
-        const unsigned long long Tb = fs_pack(fs_unpack_key(T) + p.band, 0xffffffffu);
+        // cosine: keys are -dot of unit queries.  L2: keys are ||x||^2 - 2 q.x -- twice the dot error, which scales with
+        // ||q|| (queries are not normalised), plus the worst-case f32 summation error of the exact distance
+        const float band = METRIC == KDB_METRIC_L2 ? 2.0f * p.band * (sqrtf(q_s2) * 1.0001f) + 6.0e-5f * (fabsf(fs_unpack_key(T)) + q_s2)
+                                                   : p.band;
+        const unsigned long long Tb = fs_pack(fs_unpack_key(T) + band, 0xffffffffu);
         uint32_t c = 0, sat = 0;
         for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += ent[i] <= Tb ? 1u : 0u;
         for (uint32_t sidx = (uint32_t)tid; sidx < n_stripes; sidx += 256)
@@ -1294,7 +1323,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
     // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly
     // (only when the library normalised the queries itself and the rows are far from the f16 range limit)
-    const bool rank16 = !small && v.precision == KDB_PREC_F32 && v.metric == KDB_METRIC_COSINE && queries_normalised &&
+    const bool rank16 = !small && v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
                         idx->max_norm2 > 0.f && idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
@@ -1382,7 +1411,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
     else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
-    else if (rank16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>);
+    else if (rank16 && v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>);
+    else if (rank16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, FS_PREC_F32R>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
@@ -1400,12 +1430,13 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         // eps bounds |q.x (wave order) - sum f16(q)f16(x) (MFMA order)| for rows and queries of norm <= 1: f16 rounding
         // of both factors (2^-10 and its square), f32 summation in either order (dim * 2^-23); band = 2 * eps
         // rows of norm R widen it by R (queries are normalised by the preparation step)
-        const float rmax = idx->max_norm2 > 1.0f ? sqrtf(idx->max_norm2) : 1.0f;
-        p.band = 2.0f * (9.9e-4f + (float)v.dim * 2.4e-7f) * rmax * 1.001f;
+        const float rmax = v.metric == KDB_METRIC_COSINE ? (idx->max_norm2 > 1.0f ? sqrtf(idx->max_norm2) : 1.0f) : sqrtf(idx->max_norm2);
+        p.band = 2.0f * (9.9e-4f + (float)v.dim * 2.4e-7f) * rmax * 1.001f; // cosine: the band; L2: per unit of ||q|| (x2 in the kernel)
         p.fb_count = d_fbcount;
         p.fb_list = d_fblist;
         KDB_HIP(hipMemsetAsync(d_fbcount, 0, 4, s));
-        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p, d_q);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p, d_q);
+        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 1>, p, d_q);
         if (rc) return rc;
         KDB_HIP(hipGetLastError());
         // the exact pass over the queries the band could not settle (usually none: every launch below returns at
@@ -1418,11 +1449,19 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p2.ctr = nullptr;
         p2.fb_count = nullptr;
         p2.fb_list = nullptr;
-        auto kx = flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>;
-        KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
-        KDB_HIP(hipGetLastError());
-        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
+        if (v.metric == KDB_METRIC_COSINE) {
+            auto kx = flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>;
+            KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
+            KDB_HIP(hipGetLastError());
+            rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
+        } else {
+            auto kx = flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>;
+            KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
+            KDB_HIP(hipGetLastError());
+            rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2, d_fbq);
+        }
         // statistics: how many queries the exact pass settled (kdb_counters.n_hops of a flat-scan launch)
         KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbcount, 4, hipMemcpyDeviceToDevice, s));
     } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>, p, d_q);

@@ -657,6 +657,47 @@ def test_flat_scan_groups_int8(oracle, hip):
             assert_same_results_tol(ids[b, :c], dist[b, :c].astype(np.float64), want_i, want_d)
 
 
+@pytest.mark.parametrize("case", ["near_duplicates", "dense_block", "plain", "huge_query"])
+def test_flat_scan_f16_ranked_band_l2(oracle, hip, case):
+    """the same f16-ranked band for squared L2 on unnormalised rows: the band scales with ||q|| and the largest row
+    norm; near-duplicate rows overflow it, a dense block of ids saturates one stripe, a query with components beyond
+    the f16 range is answered by the exact pass; answers are the oracle's bit for bit."""
+    O = oracle
+    rng = np.random.default_rng(23)
+    n, dim, k, B = 6000, 96, 10, 140
+    X = (rng.standard_normal((n, dim)) * 2.0).astype(np.float32)
+    centre = (rng.standard_normal(dim) * 2.0).astype(np.float32)
+    if case == "near_duplicates":
+        X = centre[None, :] + 1e-3 * rng.standard_normal((n, dim)).astype(np.float32)
+    elif case == "dense_block":
+        X[2000:2200] = centre[None, :] + 2e-3 * rng.standard_normal((200, dim)).astype(np.float32)
+    Q = (centre[None, :] + 0.3 * rng.standard_normal((B, dim))).astype(np.float32)
+    if case == "huge_query":
+        Q[:5] *= 2.0e4
+    orc = O.OracleIndex(dim, 0, O.F32, 8, 20, seed=3)
+    orc.add_many(X)
+    idx = hip.HipIndex(dim, 0, 0, 8, 20, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.set_count(n)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    settled_exactly = idx.launch_stats(1)[0]["n_hops"]
+    if case == "near_duplicates":
+        assert settled_exactly == B
+    elif case == "dense_block":
+        assert settled_exactly > 0
+    elif case == "huge_query":
+        assert settled_exactly >= 5
+    else:
+        assert settled_exactly < B // 4    # ordinary data: the band settles (nearly) everything
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k)
+        c = int(cnt[b])
+        assert c == len(oi) == k
+        assert np.array_equal(ids[b, :c], oi), (case, b, ids[b, :c], oi)
+        assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (case, b)
+
+
 @pytest.mark.parametrize("case", ["near_duplicates", "one_dense_stripe", "unnormalised_rows"])
 def test_flat_scan_f16_ranked_band_is_exact(oracle, hip, case):
     """float32 cosine scans of more than 64 queries rank on the f16 MFMA inside an error band and settle what the
