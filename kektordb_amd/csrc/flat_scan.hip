@@ -1,20 +1,22 @@
 // flat_scan.hip -- exact brute-force scan for gfx950 (the filtered path of north_star; reference
 // semantics: BruteForceIndex.SearchWithScores, pkg/core/vector_index.go:104-140).
 //
-// Shape: scores[query][row] = Q . X^T is a true GEMM (every row is shared by all B queries), so it
-// runs on the f32-input matrix cores: v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fmaf chain).
-// A 256-thread workgroup owns a (128 rows x 128 queries) tile, 4 waves in a 2x2 grid, each wave a
-// 64x64 sub-tile (4x4 MFMA tiles, 64 accumulator VGPRs).  Operands are staged through LDS in
-// 128-byte full-line pieces (row stride 160 B => conflict-free ds_read_b128 fragment reads), the next
-// K-slab is prefetched into registers while the current one is multiplied.
-// The score tile never leaves the chip: a threshold filter (current k-th best per query) feeds an LDS
-// queue that the query's owner thread drains into its running top-k list.  One workgroup walks a
-// stripe of rows; per-stripe lists are merged by a second kernel (bitonic sort in LDS) which also
-// re-scores L2 finalists exactly.
-//
-// Accumulation order per (query,row): for s (16-element K block), for j<4, for g<4: k = 16s+4g+j
-// (oracle: orc_dot_f32_hipmfma).  blockIdx -> (stripe, query tile) is XCD-aware: the query tiles of
-// one stripe run on the same XCD so the stripe's rows are fetched from HBM once and shared in L2.
+// scores[query][row] = Q . X^T is a true GEMM (every row is shared by all B queries), so it runs on the matrix
+// cores.  Every scan has the same three parts:
+//   rank     a score tile per (128 rows x 128 queries) workgroup -- 4 waves 2x2, 64x64 per wave, operands staged
+//            through LDS in 128-byte pieces (row stride 160 B: conflict-free ds_read_b128 fragments), next slab
+//            prefetched into registers -- or, for <= 64 queries, 16 whole queries in LDS and rows streamed from HBM
+//            straight into MFMA operand registers (flat_scan_small_kernel).  The MFMA depends on the rows:
+//            f32 MFMA (exact k-ordered fmaf chain, k = 16s+4g+j), f16 MFMA on raw halfs, i8 MFMA (exact i32 dots),
+//            and for float32 rows of batches > 64 the f16 MFMA on rows converted while staging (FS_PREC_F32R).
+//   select   the score tile never leaves the chip: a per-query threshold filters scores into per-query LDS queues,
+//            owner lanes keep the stripe's best kl = k+16 (LDS lists, or buffers compacted by whole waves).
+//   settle   flat_merge_kernel gathers the stripe lists of a query, isolates the finalists (radix select) and
+//            RE-SCORES them in the accumulation order of the graph search (wave order), so a (query, row) pair has
+//            one distance bit pattern whichever kernel produced it.  The f16-ranked float32 scan re-scores every
+//            entry inside a rigorous error band and hands queries it cannot settle to an exact second pass.
+// blockIdx -> (stripe, query tile) is XCD-aware: the query tiles of one stripe run on the same XCD so the stripe's
+// rows are fetched from HBM once and shared in L2.
 #include "kdb_device.cuh"
 #include <math.h>
 #include <stdlib.h>
