@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all hardware threads")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) or gloo (test rigs: several ranks on one GPU)")
+    ap.add_argument("--direct", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL all-gather + merge even with one rank (plumbing check on a 1-GPU box)")
     a = ap.parse_args()
@@ -148,7 +149,10 @@ def main():
     gt = gt_ids.cpu().numpy().view(np.uint32)
 
     def run_step(ef):
-        sh.search_dev(Q, k, ef, out_ids, out_dist, out_cnt)
+        if a.direct:  # measurement variant: the library's own stream, no ShardedSearch in between
+            idx.search_batch_dev(Q, k, ef, out_ids, out_dist, out_cnt)
+        else:
+            sh.search_dev(Q, k, ef, out_ids, out_dist, out_cnt)
 
     # ---- ef: smallest candidate reaching the recall bar on the timed query set
     sweep = {}
