@@ -1,10 +1,10 @@
 """Graph quality: the GPU batched builder vs the oracle's sequential Add (reference semantics) on the same vectors,
 both searched by the same HIP kernel; recall@10 against the exact scan."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import kektordb_amd as K
-from oracle import oracle as O   # measurement script (scripts/ is not the product path)
+from oracle import oracle as O   # checker-side tool (lives under tests/: only tests may use the oracle)
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=50000); ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--law", default="clustered"); ap.add_argument("--efs", default="10,20,40,64,100")
