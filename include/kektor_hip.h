@@ -194,7 +194,11 @@ KDB_API int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint32_
 KDB_API int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device);
 
 /* Exact scan over every non-deleted (and allowed) row.  An EMPTY allow list means "no filter"
- * (vector_index.go:130).  k <= 128.                                                               */
+ * (vector_index.go:130).  k <= 128.  The answer is the exact top-k under the index's own distance (total order:
+ * distance, then id); reported distances are computed in the accumulation order of kdb_search_batch, so a (query,
+ * row) pair has the same distance bits from either entry point.  Internally the matrix cores rank (f32 / f16 / i8
+ * MFMA; float32 rows of large batches on the f16 MFMA inside a rigorous error band) and the finalists are re-scored;
+ * queries the band cannot settle are answered by the exact kernel in the same call.                          */
 KDB_API int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k,
                         const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
                         uint32_t *out_count);
