@@ -50,6 +50,7 @@ struct FsParams {
     const uint32_t *g_base;   // [G] where group g's ids start in scan_ids
     const uint32_t *g_of_query; // [B]
     // f16-ranked float32 scan: error band of the approximate scores, queries that could not be settled inside it
+    const uint16_t *q16;      // the prepared queries as halfs [>= n_qtiles*128][ld] (converted once per call)
     float band;               // 2*eps (keys are -dot)
     uint32_t *fb_count;       // number of queries sent to the exact pass
     uint32_t *fb_list;        // their indices
@@ -287,19 +288,16 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                     continue;
                 }
                 if (PREC == FS_PREC_F32R) { // 8 floats of the row and of the query -> 8 halfs each (RNE)
-                    f16x8 hr = {0, 0, 0, 0, 0, 0, 0, 0}, hq = {0, 0, 0, 0, 0, 0, 0, 0};
+                    f16x8 hr = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (in) {
                         const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col);
                         const float4 x0 = rp[0], x1 = rp[1];
                         hr = (f16x8){(_Float16)x0.x, (_Float16)x0.y, (_Float16)x0.z, (_Float16)x0.w,
                                      (_Float16)x1.x, (_Float16)x1.y, (_Float16)x1.z, (_Float16)x1.w};
-                        const float4 *qp = reinterpret_cast<const float4 *>(queries + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col);
-                        const float4 y0 = qp[0], y1 = qp[1];
-                        hq = (f16x8){(_Float16)y0.x, (_Float16)y0.y, (_Float16)y0.z, (_Float16)y0.w,
-                                     (_Float16)y1.x, (_Float16)y1.y, (_Float16)y1.z, (_Float16)y1.w};
                     }
                     ra[i] = __builtin_bit_cast(float4, hr);
-                    rb[i] = __builtin_bit_cast(float4, hq);
+                    rb[i] = in ? *reinterpret_cast<const float4 *>(p.q16 + (size_t)(q0 + (uint32_t)(s_r + 32 * i)) * v.ld + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
                     continue;
                 }
                 if (PREC == KDB_PREC_F16) { // 8 raw halfs of the row; the query (f32 values that are exact halfs) packed alike
@@ -1081,6 +1079,18 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (tid == 0) out_count[qo] = nout;
 }
 
+// f16-ranked scan: the prepared queries as halfs, once per call (every workgroup used to convert them per row tile)
+__global__ void queries_to_f16_kernel(const float *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 y = *reinterpret_cast<const float4 *>(src + i);
+    const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+    uint2 o;
+    o.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    o.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+    *reinterpret_cast<uint2 *>(dst + i) = o;
+}
+
 // exact pass of the f16-ranked scan: the prepared vectors of the unsettled queries, made contiguous
 __global__ void gather_queries_kernel(const float *__restrict__ src, uint32_t ld, const uint32_t *list, const uint32_t *count,
                                       float *__restrict__ dst) {
@@ -1391,6 +1401,13 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                        (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 32;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
+    if (rank16) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
+        const size_t nq_elems = (size_t)n_qtiles * FS_TQ * v.ld;
+        hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq_elems / 4 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
+        KDB_HIP(hipGetLastError());
+        p.q16 = reinterpret_cast<const uint16_t *>(d_fbq);
+    }
     p.ctr = kdb_stats_begin(idx, 2, B, 0);
     unsigned long long *stat_slot = p.ctr;
     KDB_HIP(hipMemsetAsync(stat_slot, 0, 32, s));
