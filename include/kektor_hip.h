@@ -86,8 +86,12 @@ typedef struct {
     uint32_t ef_construction; /* 0 -> 200 */
     uint32_t capacity;   /* largest internal id the index may hold */
     int32_t device_id;   /* HIP device ordinal */
-    uint32_t reserved;
+    uint32_t reserved;   /* flags: KDB_INDEX_NO_F16_SHADOW */
 } kdb_index_desc;
+/* float32 indexes keep a second copy of the rows as halfs (+50 % row memory): the exact scan RANKS on it (half the
+ * HBM bytes for small batches, the f16 MFMA for large ones) inside a rigorous error band and settles on the float32
+ * rows, so answers are unchanged.  Set this bit to do without the copy.                                        */
+#define KDB_INDEX_NO_F16_SHADOW 1u
 
 /* Per-level CSR adjacency.  offsets[l] has count+2 entries: node i's neighbours at level l are
  * neighbors[l][offsets[l][i] .. offsets[l][i+1]) (empty when levels[i] < l).  Lists keep the

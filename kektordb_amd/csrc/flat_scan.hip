@@ -50,6 +50,7 @@ struct FsParams {
     const uint32_t *g_base;   // [G] where group g's ids start in scan_ids
     const uint32_t *g_of_query; // [B]
     // f16-ranked float32 scan: error band of the approximate scores, queries that could not be settled inside it
+    const uint16_t *rows16;   // float32 index: the rows as halfs (ranking copy), or null
     const uint16_t *q16;      // the prepared queries as halfs [>= n_qtiles*128][ld] (converted once per call)
     float band;               // 2*eps (keys are -dot)
     uint32_t *fb_count;       // number of queries sent to the exact pass
@@ -289,7 +290,9 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
                 }
                 if (PREC == FS_PREC_F32R) { // 8 floats of the row and of the query -> 8 halfs each (RNE)
                     f16x8 hr = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (in) {
+                    if (in && p.rows16) { // the ranking copy: no conversion, half the bytes
+                        hr = __builtin_bit_cast(f16x8, *reinterpret_cast<const float4 *>(p.rows16 + (size_t)a_id[i] * v.ld + col));
+                    } else if (in) {
                         const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)a_id[i] * v.ld + col);
                         const float4 x0 = rp[0], x1 = rp[1];
                         hr = (f16x8){(_Float16)x0.x, (_Float16)x0.y, (_Float16)x0.z, (_Float16)x0.w,
@@ -1079,6 +1082,18 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     if (tid == 0) out_count[qo] = nout;
 }
 
+// ranking copy of float32 rows: ld halfs per row (pad columns included), RNE
+__global__ void rows_to_f16_kernel(const float *__restrict__ rows, uint16_t *__restrict__ rows16, size_t first_elem, size_t n_elems) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n_elems) return;
+    const float4 y = *reinterpret_cast<const float4 *>(rows + first_elem + i);
+    const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+    uint2 o;
+    o.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    o.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+    *reinterpret_cast<uint2 *>(rows16 + first_elem + i) = o;
+}
+
 // f16-ranked scan: the prepared queries as halfs, once per call (every workgroup used to convert them per row tile)
 __global__ void queries_to_f16_kernel(const float *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1315,6 +1330,15 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
     return KDB_OK;
 }
 
+int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s) {
+    if (n == 0) return KDB_OK;
+    const size_t n_elems = (size_t)n * ld, first_elem = (size_t)first * ld;
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, s, d_rows, d_rows16, first_elem,
+                       n_elems);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
                          float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s) {
@@ -1407,6 +1431,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                            reinterpret_cast<const float *>(d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
         KDB_HIP(hipGetLastError());
         p.q16 = reinterpret_cast<const uint16_t *>(d_fbq);
+        p.rows16 = idx->d_rows16;
     }
     p.ctr = kdb_stats_begin(idx, 2, B, 0);
     unsigned long long *stat_slot = p.ctr;

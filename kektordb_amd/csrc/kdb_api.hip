@@ -229,6 +229,10 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     idx->ev1 = idx->ring_ev1[0];
     KDB_TRY(hipMalloc(&idx->d_rows, n1 * idx->ld * idx->elem));
     KDB_TRY(hipMemsetAsync(idx->d_rows, 0, (size_t)idx->ld * idx->elem, idx->stream)); // row 0
+    if (idx->desc.precision == KDB_PREC_F32 && !(idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW)) {
+        KDB_TRY(hipMalloc(&idx->d_rows16, n1 * idx->ld * 2));
+        KDB_TRY(hipMemsetAsync(idx->d_rows16, 0, (size_t)idx->ld * 2, idx->stream));
+    }
     KDB_TRY(hipMalloc(&idx->d_norms, n1 * 4));
     KDB_TRY(hipMemsetAsync(idx->d_norms, 0, n1 * 4, idx->stream));
     KDB_TRY(hipMalloc(&idx->d_adj0, n1 * idx->deg0 * 4));
@@ -256,7 +260,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
                     idx->d_deleted, idx->d_visited, idx->d_scratch, idx->d_work,  idx->d_ctr,    idx->d_qbuf,
-                    idx->d_iobuf, idx->d_build, idx->d_retry};
+                    idx->d_iobuf, idx->d_build, idx->d_retry, idx->d_rows16};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
@@ -282,6 +286,10 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
     KDB_HIP(hipMemcpy2DAsync(dst, lb, rows, rb, rb, n, kind, idx->stream));
     // ||x||^2 per row: ranking key of the L2 flat scan; for float32 rows also the largest one (error band of the
     // f16-ranked cosine scan: the reference normalises cosine rows at insert, the mirror does not assume it)
+    if (idx->d_rows16) { // ranking copy of the new rows
+        int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, first_id, n, idx->stream);
+        if (rc) return rc;
+    }
     const bool want_norms = idx->desc.precision != KDB_PREC_I8 &&
                             (idx->desc.metric == KDB_METRIC_L2 || idx->desc.precision == KDB_PREC_F32);
     uint32_t max_bits = 0;

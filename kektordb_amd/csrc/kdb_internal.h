@@ -57,6 +57,7 @@ struct kdb_index {
     uint8_t *d_levels = nullptr;
     uint32_t *d_deleted = nullptr;
     size_t up_slots = 0, up_slots_cap = 0;
+    uint16_t *d_rows16 = nullptr; // float32 indexes: the rows once more as halfs (ranking copy of the exact scan: half the bytes)
     float max_norm2 = 0.f; // largest ||x||^2 among the float32 rows uploaded so far (error band of the f16-ranked scan)
     // host copies of the per-node level and first upper slot (incremental refresh validates and places lists with them)
     std::vector<uint8_t> h_levels;
@@ -136,6 +137,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
                          float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s);
+int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s);
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
                                 uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,
