@@ -559,7 +559,9 @@ __host__ __device__ inline uint32_t fss_qstride(uint32_t ld) { return ld + ((40u
 
 template <int PREC>
 __host__ __device__ inline size_t fss_q_bytes(uint32_t ld) {
-    return PREC == KDB_PREC_I8 ? (((size_t)FSS_TQ * (ld + 16u) + 255u) & ~(size_t)255u) : (size_t)FSS_TQ * fss_qstride(ld) * 4u;
+    return PREC == KDB_PREC_I8   ? (((size_t)FSS_TQ * (ld + 16u) + 255u) & ~(size_t)255u)
+           : PREC == FS_PREC_F32R ? (((size_t)FSS_TQ * (ld * 2u + 16u) + 255u) & ~(size_t)255u)
+                                  : (size_t)FSS_TQ * fss_qstride(ld) * 4u;
 }
 
 template <int METRIC, int PREC>
@@ -568,7 +570,11 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // queries in LDS: [16][S] floats (f32, f16 widened), or [16][S8] bytes (int8, stride ld+16: conflict-free b128 reads)
     const uint32_t S = fss_qstride(v.ld);
-    const uint32_t S8 = v.ld + 16u;
+    // raw-bytes mode (int8 rows; the half-precision ranking copy of float32 rows): a row is rowb bytes, one step = 64 of
+    // them per row (64 int8 / 32 f16 components), queries sit in LDS in the same encoding with stride rowb + 16
+    constexpr bool RAW = PREC == KDB_PREC_I8 || PREC == FS_PREC_F32R;
+    const uint32_t rowb = PREC == FS_PREC_F32R ? v.ld * 2u : v.ld;
+    const uint32_t S8 = rowb + 16u;
     float *qs = reinterpret_cast<float *>(smem);
     unsigned char *qs8 = smem;
     float *b_key = reinterpret_cast<float *>(smem + fss_q_bytes<PREC>(v.ld));  // [16][cap_s]
@@ -587,7 +593,12 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     // this tile's queries and scan list: the batch's, or its group's (grouped scan)
     const uint32_t *scan_ids = p.scan_ids;
     uint32_t q0 = qt * FSS_TQ;
-    uint32_t nq = p.B - q0 < (uint32_t)FSS_TQ ? p.B - q0 : (uint32_t)FSS_TQ;
+    uint32_t nq = 0;
+    if (!p.g_tile) {
+        const uint32_t Beff = p.b_dev ? *p.b_dev : p.B; // exact pass of the ranked scan: only the unsettled queries
+        if (q0 >= Beff) return;
+        nq = Beff - q0 < (uint32_t)FSS_TQ ? Beff - q0 : (uint32_t)FSS_TQ;
+    }
     FsGeom geo;
     if (p.g_tile) {
         const uint32_t grp = p.g_tile[qt * 3u];
@@ -604,7 +615,19 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     uint32_t row_end = row_begin + geo.rows_per_stripe;
     if (row_end > geo.n_scan) row_end = geo.n_scan;
 
-    if (PREC == KDB_PREC_I8) { // prepared int8 queries: ld bytes per row
+    if (PREC == FS_PREC_F32R) { // prepared float32 queries -> halfs (RNE), 8 at a time
+        for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 3); i += 256) {
+            const uint32_t n = i / (v.ld >> 3), c = i % (v.ld >> 3);
+            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < nq) {
+                const float4 *qp = reinterpret_cast<const float4 *>(queries + (size_t)(q0 + n) * v.ld + c * 8u);
+                const float4 y0 = qp[0], y1 = qp[1];
+                h = (f16x8){(_Float16)y0.x, (_Float16)y0.y, (_Float16)y0.z, (_Float16)y0.w,
+                            (_Float16)y1.x, (_Float16)y1.y, (_Float16)y1.z, (_Float16)y1.w};
+            }
+            *reinterpret_cast<float4 *>(qs8 + n * S8 + c * 16u) = __builtin_bit_cast(float4, h);
+        }
+    } else if (PREC == KDB_PREC_I8) { // prepared int8 queries: ld bytes per row
         const unsigned char *q8 = reinterpret_cast<const unsigned char *>(queries);
         for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 4); i += 256) {
             const uint32_t n = i / (v.ld >> 4), c = i % (v.ld >> 4);
@@ -629,9 +652,10 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows);
-    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(v.rows);
+    const unsigned char *rows8 = PREC == FS_PREC_F32R ? reinterpret_cast<const unsigned char *>(p.rows16)
+                                                      : reinterpret_cast<const unsigned char *>(v.rows);
     // one step = one 16-byte load per lane: 16 k-values of a f32/f16 row, 64 of an int8 row
-    const uint32_t nsteps = PREC == KDB_PREC_I8 ? (v.ld + 63u) >> 6 : v.ld >> 4;
+    const uint32_t nsteps = RAW ? (rowb + 63u) >> 6 : v.ld >> 4;
     // a tile is cut into an EVEN number of register chunks (<= FSS_CH steps each), so that every tile starts
     // in buffer A and the per-tile side loads below have a fixed place in the pipeline
     const uint32_t nch = 2u * ((nsteps + 2u * FSS_CH - 1u) / (2u * FSS_CH));
@@ -656,11 +680,11 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
                 const uint32_t step = ch * cs + (uint32_t)u;
                 const uint32_t col = step * 16u + (uint32_t)fg * 4u;
                 if ((uint32_t)u < cs && step < nsteps) {
-                    if (PREC == KDB_PREC_I8) { // bytes as they are; the last step of a row may be partial
+                    if (RAW) { // bytes as they are; the last step of a row may be partial
                         const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
-                        dst[a][u] = cb < v.ld ? *reinterpret_cast<const float4 *>(rows8 + (size_t)ld_id[a] * v.ld + cb)
+                        dst[a][u] = cb < rowb ? *reinterpret_cast<const float4 *>(rows8 + (size_t)ld_id[a] * rowb + cb)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                    } else if (PREC == KDB_PREC_F16) {
+                    } else if (PREC == KDB_PREC_F16) { // halfs, widened exactly onto the f32 MFMA
                         const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)ld_id[a] * v.ld + col);
                         dst[a][u] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
                                                 (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
@@ -679,15 +703,20 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
         for (int u = 0; u < FSS_CH; u++) {
             const uint32_t step = ch * cs + (uint32_t)u;
             if ((uint32_t)u >= cs || step >= nsteps) break;
-            if (PREC == KDB_PREC_I8) { // exact i32 dots: one 16x16x64 MFMA per 16-row group and step
+            if (RAW) { // one MFMA per 16-row group and 64-byte step: exact i32 dots (int8), f16 products summed in f32
                 const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
-                const float4 q16 = cb < v.ld ? *reinterpret_cast<const float4 *>(qs8 + (uint32_t)fi * S8 + cb)
+                const float4 q16 = cb < rowb ? *reinterpret_cast<const float4 *>(qs8 + (uint32_t)fi * S8 + cb)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int a = 0; a < 2; a++)
-                    acc[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                                                          __builtin_bit_cast(i32x4, src[a][u]), __builtin_bit_cast(i32x4, q16),
-                                                          __builtin_bit_cast(i32x4, acc[a]), 0, 0, 0));
+                for (int a = 0; a < 2; a++) {
+                    if (PREC == KDB_PREC_I8)
+                        acc[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                                              __builtin_bit_cast(i32x4, src[a][u]), __builtin_bit_cast(i32x4, q16),
+                                                              __builtin_bit_cast(i32x4, acc[a]), 0, 0, 0));
+                    else
+                        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[a][u]), __builtin_bit_cast(f16x8, q16),
+                                                                        acc[a], 0, 0, 0);
+                }
                 continue;
             }
             const float4 qf = *reinterpret_cast<const float4 *>(qs + (uint32_t)fi * S + step * 16u + (uint32_t)fg * 4u);
@@ -1359,7 +1388,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
     // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly
     // (only when the library normalised the queries itself and the rows are far from the f16 range limit)
-    const bool rank16 = !small && v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
+    // (small batches rank on the half-precision copy of the rows, when the index keeps one: half the HBM bytes)
+    const bool rank16 = (!small || idx->d_rows16) && v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
                         idx->max_norm2 > 0.f && idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
@@ -1425,7 +1455,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                        (size_t)FS_TQ * FS_LDS_KL * 8 + (size_t)FS_TQ * 8 + 32;
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
-    if (rank16) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
+    if (rank16 && small) p.rows16 = idx->d_rows16;
+    if (rank16 && !small) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
         const size_t nq_elems = (size_t)n_qtiles * FS_TQ * v.ld;
         hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq_elems / 4 + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<const float *>(d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
@@ -1442,13 +1473,17 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
         return KDB_OK;
     };
-    auto launch_small = [&](auto kern) -> int {
-        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-        hipLaunchKernelGGL(kern, dim3(stripes8 * n_q16), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_q), p, n_q16,
-                           cap_s);
+    auto launch_small_on = [&](auto kern, const FsParams &pp, const void *qv, size_t lds_k) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
+        hipLaunchKernelGGL(kern, dim3(stripes8 * n_q16), dim3(256), lds_k, s, v, reinterpret_cast<const float *>(qv), pp, n_q16, cap_s);
         return KDB_OK;
     };
-    if (small) {
+    auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, d_q, lds_s); };
+    if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, d_q, lds_r);
+        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p, d_q, lds_r);
+    } else if (small) {
         if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
         else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
         else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
@@ -1493,19 +1528,24 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p2.ctr = nullptr;
         p2.fb_count = nullptr;
         p2.fb_list = nullptr;
-        if (v.metric == KDB_METRIC_COSINE) {
+        if (small) {
+            if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, p2, d_fbq, lds_s);
+            else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, d_fbq, lds_s);
+            if (rc) return rc;
+            KDB_HIP(hipGetLastError());
+        } else if (v.metric == KDB_METRIC_COSINE) {
             auto kx = flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>;
             KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
             KDB_HIP(hipGetLastError());
-            rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
         } else {
             auto kx = flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>;
             KDB_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
             KDB_HIP(hipGetLastError());
-            rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2, d_fbq);
         }
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
+        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2, d_fbq);
         // statistics: how many queries the exact pass settled (kdb_counters.n_hops of a flat-scan launch)
         KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbcount, 4, hipMemcpyDeviceToDevice, s));
     } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>, p, d_q);
