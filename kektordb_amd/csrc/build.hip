@@ -139,11 +139,6 @@ struct PruneLds {
     uint32_t *misc;    // [8]: 0 n_sel, 1 n_disc
 };
 
-__device__ __forceinline__ size_t prune_lds_bytes() {
-    return (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
-           (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
-}
-
 __device__ __forceinline__ void prune_carve(unsigned char *smem, PruneLds &p) {
     size_t off = 0;
     p.rows = reinterpret_cast<float *>(smem + off);

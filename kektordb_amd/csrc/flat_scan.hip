@@ -1277,12 +1277,6 @@ group_fill_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words
     }
 }
 
-__global__ void any_bit_kernel(const uint32_t *bits, uint32_t words, uint32_t *out) {
-    bool f = false;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) f |= bits[i] != 0u;
-    if (__ballot(f) && kdb_lane() == 0) atomicOr(out, 1u);
-}
-
 // Shard merge: G lists of <=k per query -> top-k. One 64-thread block per query.
 // negate = 1 when larger raw values are nearer (dot products of the f32 cosine path).
 // Shard g's ids/distances start at g*stride_e and its counts at g*stride_c (32-bit words): separate [G][B][k]

@@ -86,7 +86,7 @@ KdbView kdb_make_view(const kdb_index *idx) {
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
     if (idx->scratch_bytes >= bytes) return KDB_OK;
     if (idx->d_scratch) {
-        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_scratch));
         idx->d_scratch = nullptr;
         idx->scratch_bytes = 0;
@@ -100,7 +100,7 @@ int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
 int kdb_ensure_visited(kdb_index *idx, uint32_t slots) {
     if (idx->vis_slots >= slots) return KDB_OK;
     if (idx->d_visited) {
-        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_visited));
         idx->d_visited = nullptr;
         idx->vis_slots = 0;
@@ -126,23 +126,23 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
     return idx->d_ctr + (size_t)slot * 4; // [0] n_dist / rows scanned, [1] n_hops, [2] work counter of the launch
 }
 
-int kdb_ensure_retry(kdb_index *idx, uint32_t n) {
-    if (idx->retry_cap >= n) return KDB_OK;
-    if (idx->d_retry) {
-        KDB_HIP(hipStreamSynchronize(idx->stream));
-        KDB_HIP(hipFree(idx->d_retry));
-        idx->d_retry = nullptr;
-        idx->retry_cap = 0;
+int kdb_ensure_group_entries(kdb_index *idx, uint32_t n) {
+    if (idx->gentry_cap >= n) return KDB_OK;
+    if (idx->d_gentry) {
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
+        KDB_HIP(hipFree(idx->d_gentry));
+        idx->d_gentry = nullptr;
+        idx->gentry_cap = 0;
     }
-    KDB_HIP(hipMalloc(&idx->d_retry, ((size_t)n + n / 4 + 64) * 4));
-    idx->retry_cap = n + n / 4 + 64;
+    KDB_HIP(hipMalloc(&idx->d_gentry, ((size_t)n + n / 4 + 64) * 4));
+    idx->gentry_cap = n + n / 4 + 64;
     return KDB_OK;
 }
 
 static int ensure_qbuf(kdb_index *idx, size_t bytes) {
     if (idx->qbuf_bytes >= bytes) return KDB_OK;
     if (idx->d_qbuf) {
-        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_qbuf));
         idx->d_qbuf = nullptr;
         idx->qbuf_bytes = 0;
@@ -155,7 +155,7 @@ static int ensure_qbuf(kdb_index *idx, size_t bytes) {
 static int ensure_iobuf(kdb_index *idx, size_t bytes) {
     if (idx->iobuf_bytes >= bytes) return KDB_OK;
     if (idx->d_iobuf) {
-        KDB_HIP(hipStreamSynchronize(idx->stream));
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_iobuf));
         idx->d_iobuf = nullptr;
         idx->iobuf_bytes = 0;
@@ -260,7 +260,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
                     idx->d_deleted, idx->d_visited, idx->d_scratch, idx->d_work,  idx->d_ctr,    idx->d_qbuf,
-                    idx->d_iobuf, idx->d_build, idx->d_retry, idx->d_rows16};
+                    idx->d_iobuf, idx->d_build, idx->d_gentry, idx->d_rows16};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
@@ -696,21 +696,21 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
     const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
     KdbMultiAllow ma;
     if (ml && ml->G) { // one entry point per list, chosen on the device: no host round trip for any of the G lists
-        int rc = kdb_ensure_retry(idx, ml->G);
+        int rc = kdb_ensure_group_entries(idx, ml->G);
         if (rc) return rc;
-        rc = kdb_launch_group_entries(v, d_allow, ml->G, (uint32_t)(ml->words64 * 2), entry, idx->d_retry, s);
+        rc = kdb_launch_group_entries(v, d_allow, ml->G, (uint32_t)(ml->words64 * 2), entry, idx->d_gentry, s);
         if (rc) return rc;
         ma.of_query = ml->d_of_query;
-        ma.group_entry = idx->d_retry;
+        ma.group_entry = idx->d_gentry;
         ma.words32 = (uint32_t)(ml->words64 * 2);
     } else if (d_allow) { // Smart Entry Point Selection (hnsw_index.go:437-447), decided on the device: an empty bitmap,
         // or one whose smallest id names no vector while the entry point is not allowed, yields no results
         const uint32_t words32 = 2u * ((idx->count >> 6) + 1u);
-        int rc = kdb_ensure_retry(idx, 1);
+        int rc = kdb_ensure_group_entries(idx, 1);
         if (rc) return rc;
-        rc = kdb_launch_group_entries(v, d_allow, 1, words32, entry, idx->d_retry, s);
+        rc = kdb_launch_group_entries(v, d_allow, 1, words32, entry, idx->d_gentry, s);
         if (rc) return rc;
-        ma.group_entry = idx->d_retry; // of_query stays null: every query uses list 0
+        ma.group_entry = idx->d_gentry; // of_query stays null: every query uses list 0
         ma.words32 = words32;
     }
     // float32 / float16 indexes: the search kernel prepares each query itself while it loads it into LDS (normalise for

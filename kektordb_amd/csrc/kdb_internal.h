@@ -77,8 +77,8 @@ struct kdb_index {
     size_t qbuf_bytes = 0;
     void *d_iobuf = nullptr;        // staging for the host-pointer entry points
     size_t iobuf_bytes = 0;
-    uint32_t *d_retry = nullptr;    // queries whose LDS visited set overflowed (re-run with the HBM bitset)
-    uint32_t retry_cap = 0;
+    uint32_t *d_gentry = nullptr;    // entry point per allow list of a search batch (hnsw_index.go:437-447), chosen on the device
+    uint32_t gentry_cap = 0;
     void *d_build = nullptr;        // graph-construction workspace
     size_t build_bytes = 0;
     int last_kind = 0;              // 1 search, 2 flat scan, 3 distance tile
@@ -114,7 +114,7 @@ void kdb_set_error(const char *fmt, ...);
 KdbView kdb_make_view(const kdb_index *idx);
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes);
 int kdb_ensure_visited(kdb_index *idx, uint32_t slots);
-int kdb_ensure_retry(kdb_index *idx, uint32_t n);
+int kdb_ensure_group_entries(kdb_index *idx, uint32_t n);
 // start a new statistics slot: selects ring events (idx->ev0/ev1) and returns the slot's counter words
 unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32_t C);
 
