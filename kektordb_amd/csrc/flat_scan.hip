@@ -58,6 +58,10 @@ struct FsParams {
     // exact pass over those queries: how many there are (device), where their results go
     const uint32_t *b_dev;
     const uint32_t *q_map;
+    // grouped scan, ranked: unsettled queries are marked in place (their group's id list is needed again)
+    uint32_t *q_flag, *tile_flag;   // band merge writes: query / its 16-query tile needs the exact pass
+    const uint32_t *q_tile;         // [B] tile of every query
+    const uint32_t *q_sel, *tile_sel; // exact pass reads: only marked queries / tiles are processed
     uint32_t lists_query_major; // per-stripe lists: 0 = [tile][entry][128 queries] (tile kernel), 1 = [query][entry] (small kernel)
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
@@ -601,6 +605,7 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     }
     FsGeom geo;
     if (p.g_tile) {
+        if (p.tile_sel && !p.tile_sel[qt]) return; // exact pass: only tiles that hold an unsettled query
         const uint32_t grp = p.g_tile[qt * 3u];
         q0 = p.g_tile[qt * 3u + 1u];
         nq = p.g_tile[qt * 3u + 2u];
@@ -871,6 +876,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     const uint32_t q = blockIdx.x;
     const int tid = (int)threadIdx.x;
     if (p.b_dev && q >= *p.b_dev) return;               // exact pass over the unsettled queries only
+    if (p.q_sel && !p.q_sel[q]) return;                 // (grouped scan: marked in place)
     const uint32_t qo = p.q_map ? p.q_map[q] : q;       // where this query's answer goes
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
@@ -948,7 +954,11 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         mx = fmaxf(fmaxf(rf[4], rf[5]), fmaxf(rf[6], rf[7]));
         __syncthreads();
         if (!(mx < 3.0e4f) || !(q_s2 < 1.0e30f)) {
-            if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = qo;
+            if (tid == 0) {
+                const uint32_t pos = atomicAdd(p.fb_count, 1u);
+                if (p.q_flag) { p.q_flag[q] = 1u; p.tile_flag[p.q_tile[q]] = 1u; }
+                else p.fb_list[pos] = qo;
+            }
             return;
         }
     }
@@ -1045,7 +1055,11 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const uint32_t n_sat = fs_block_sum(sat, red, tid, 1);
         __syncthreads();
         if (n_band > 256u || n_sat) { // not settled here: the exact pass answers this query
-            if (tid == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = qo;
+            if (tid == 0) {
+                const uint32_t pos = atomicAdd(p.fb_count, 1u);
+                if (p.q_flag) { p.q_flag[q] = 1u; p.tile_flag[p.q_tile[q]] = 1u; }
+                else p.fb_list[pos] = qo;
+            }
             return;
         }
         T = Tb;
@@ -1557,7 +1571,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
                                 uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,
-                                uint32_t *d_out_count, hipStream_t s) {
+                                uint32_t *d_out_count, int queries_normalised, hipStream_t s) {
     if (k == 0 || k > 128) {
         kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
         return KDB_ERR_INVALID;
@@ -1572,7 +1586,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         return KDB_ERR_UNSUPPORTED;
     }
     // 16-query tiles of every group + the group of every query (host: the caller's grouping is host knowledge)
-    std::vector<uint32_t> tiles, qgrp((size_t)B, 0u);
+    std::vector<uint32_t> tiles, qgrp((size_t)B, 0u), qtile((size_t)B, 0u);
     for (uint32_t g = 0; g < G; g++) {
         const uint32_t a = group_offsets[g], b = group_offsets[g + 1];
         if (b < a || b > B) {
@@ -1581,6 +1595,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         }
         for (uint32_t q = a; q < b; q++) qgrp[q] = g;
         for (uint32_t q = a; q < b; q += FSS_TQ) {
+            for (uint32_t qq = q; qq < b && qq < q + FSS_TQ; qq++) qtile[qq] = (uint32_t)(tiles.size() / 3);
             tiles.push_back(g);
             tiles.push_back(q);
             tiles.push_back(b - q < (uint32_t)FSS_TQ ? b - q : (uint32_t)FSS_TQ);
@@ -1636,7 +1651,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     if (total > (uint64_t)G * v.count) total = (uint64_t)G * v.count;
     const size_t ids_bytes = al((size_t)total * 4 + 1024);
     const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
-    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) + al((size_t)B * 4) + part_bytes + 4096;
+    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 3 + 256 + part_bytes + 4096;
     rc = kdb_ensure_scratch(idx, need);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
@@ -1646,12 +1661,24 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     uint32_t *d_gcur = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4));
     uint32_t *d_tiles = reinterpret_cast<uint32_t *>(base + ids_bytes + 3 * al((size_t)G * 4));
     uint32_t *d_qgrp = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_tiles) + al(tiles.size() * 4));
-    unsigned char *part = reinterpret_cast<unsigned char *>(d_qgrp) + al((size_t)B * 4);
+    uint32_t *d_qtile = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qgrp) + al((size_t)B * 4));
+    uint32_t *d_qflag = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qtile) + al((size_t)B * 4));
+    uint32_t *d_tflag = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qflag) + al((size_t)B * 4));
+    uint32_t *d_fbc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_tflag) + al(tiles.size() * 4));
+    unsigned char *part = reinterpret_cast<unsigned char *>(d_fbc) + 256;
+    // float32 indexes with a half-precision row copy rank on it inside the error band (see kdb_launch_flat_scan); the
+    // exact pass re-runs only the tiles that hold an unsettled query, with their group's id list
+    const bool rank16 = v.precision == KDB_PREC_F32 && idx->d_rows16 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
+                        idx->max_norm2 > 0.f && idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
 
     FsParams p{};
     p.ctr = kdb_stats_begin(idx, 2, B, 0);
+    unsigned long long *stat_slot = p.ctr;
+    KDB_HIP(hipMemsetAsync(stat_slot, 0, 32, s));
     KDB_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, s));
     KDB_HIP(hipMemcpyAsync(d_qgrp, qgrp.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_qtile, qtile.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemsetAsync(d_qflag, 0, al((size_t)B * 4) + al(tiles.size() * 4) + 256, s)); // q_flag, tile_flag, count
     KDB_HIP(hipMemsetAsync(d_gn, 0, (size_t)G * 4, s));
     hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gn);
     hipLaunchKernelGGL(group_prefix_kernel, dim3(1), dim3(256), 0, s, d_gn, G, d_gbase, d_gcur, p.ctr);
@@ -1679,12 +1706,18 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.ctr = nullptr; // written by group_prefix_kernel
     const uint32_t stripes8 = (want + 7) / 8 * 8;
     KDB_HIP(hipEventRecord(idx->ev0, s));
-    auto launch_small = [&](auto kern) -> int {
-        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-        hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_q), p, T, cap_s);
+    auto launch_small_on = [&](auto kern, const FsParams &pp, size_t lds_k) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
+        hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_k, s, v, reinterpret_cast<const float *>(d_q), pp, T, cap_s);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
+    auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, lds_s); };
+    if (rank16) {
+        p.rows16 = idx->d_rows16;
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, lds_r);
+        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p, lds_r);
+    } else if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
     else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
@@ -1693,13 +1726,39 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = want * kl;
     const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
-    auto launch_merge = [&](auto kern) -> int {
+    auto launch_merge_on = [&](auto kern, const FsParams &pp) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, p, k, nmax, d_out_ids,
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, pp, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
-    if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>);
+    auto launch_merge = [&](auto kern) -> int { return launch_merge_on(kern, p); };
+    if (rank16) {
+        const float rmax = v.metric == KDB_METRIC_COSINE ? (idx->max_norm2 > 1.0f ? sqrtf(idx->max_norm2) : 1.0f) : sqrtf(idx->max_norm2);
+        p.band = 2.0f * (9.9e-4f + (float)v.dim * 2.4e-7f) * rmax * 1.001f;
+        p.fb_count = d_fbc;
+        p.q_flag = d_qflag;
+        p.tile_flag = d_tflag;
+        p.q_tile = d_qtile;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p);
+        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 1>, p);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        FsParams p2 = p; // exact pass: the marked tiles, the marked queries
+        p2.rows16 = nullptr;
+        p2.fb_count = nullptr;
+        p2.q_flag = nullptr;
+        p2.tile_flag = nullptr;
+        p2.q_sel = d_qflag;
+        p2.tile_sel = d_tflag;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, p2, lds_s);
+        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, lds_s);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2);
+        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2);
+        if (stat_slot) KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbc, 4, hipMemcpyDeviceToDevice, s));
+    } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>);
     else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, 0>);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>);
     else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>);

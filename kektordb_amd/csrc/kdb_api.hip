@@ -898,7 +898,8 @@ extern "C" int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, 
     if (rc) return rc;
     return kdb_launch_flat_scan_groups(idx, v, d_q, d_qnorm, B, k, G, group_offsets,
                                        reinterpret_cast<const uint32_t *>(d_allow_lists), (uint32_t)(words_per_list * 2),
-                                       max_total_allowed, d_out_ids, d_out_dist, d_out_count, s);
+                                       max_total_allowed, d_out_ids, d_out_dist, d_out_count,
+                                       (flags & KDB_SEARCH_PREPARED) ? 0 : 1, s);
 }
 
 extern "C" int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k,

@@ -141,7 +141,7 @@ int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld,
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
                                 uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,
-                                uint32_t *d_out_count, hipStream_t s);
+                                uint32_t *d_out_count, int queries_normalised, hipStream_t s);
 int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
                           const float *d_in_dist, const uint32_t *d_in_count, size_t stride_e, size_t stride_c,
                           const uint32_t *d_id_base, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
