@@ -54,7 +54,9 @@ def _ready(stream):
 
 class HipIndex:
     def __init__(self, dim: int, metric: int = COSINE, precision: int = F32, m: int = 16,
-                 ef_construction: int = 200, capacity: int = 1 << 20, device_id: int = 0):
+                 ef_construction: int = 200, capacity: int = 1 << 20, device_id: int = 0, f16_shadow: bool = True):
+        """f16_shadow: float32 indexes keep a half-precision RANKING copy of the rows for the exact scan (+50 % row
+        memory, answers unchanged); False sets KDB_INDEX_NO_F16_SHADOW."""
         self.L = _lib.load()
         self.dim, self.metric, self.precision = int(dim), int(metric), int(precision)
         self.m = m if m > 0 else 16
@@ -63,7 +65,7 @@ class HipIndex:
         self.device_id = device_id
         self.needs_refine = False
         desc = _lib.IndexDesc(self.dim, self.metric, self.precision, self.m, self.ef_construction, self.capacity,
-                              device_id, 0)
+                              device_id, 0 if f16_shadow else 1)
         h = C.c_void_p()
         check(self.L.kdb_index_create(C.byref(desc), C.byref(h)), "kdb_index_create")
         self.h = h

@@ -757,3 +757,24 @@ def test_flat_scan_f16_ranked_band_is_exact(oracle, hip, case, B):
         assert c == len(oi) == k
         assert np.array_equal(ids[b, :c], oi), (case, b, ids[b, :c], oi)
         assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (case, b)
+
+
+def test_flat_scan_without_ranking_copy(oracle, hip):
+    """KDB_INDEX_NO_F16_SHADOW: no half-precision copy of the rows; small batches take the exact kernel, large ones
+    convert rows while staging -- same answers"""
+    O = oracle
+    n, dim, k = 3000, 80, 10
+    X = make_corpus(n, dim, "normal", seed=95)
+    orc = O.OracleIndex(dim, 1, O.F32, 8, 20, seed=3)
+    orc.add_many(X)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    idx = hip.HipIndex(dim, 1, 0, 8, 20, capacity=n + 8, f16_shadow=False)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.set_count(n)
+    for B in (7, 140):
+        Q = make_corpus(B, dim, "normal", seed=96 + B)
+        ids, dist, cnt = idx.flat_scan_batch(Q, k)
+        for b in range(B):
+            oi, od = orc.flat_scan(Q[b], k)
+            assert np.array_equal(ids[b, :int(cnt[b])], oi)
+            assert np.array_equal(raw_to_score(idx, dist[b, :int(cnt[b])]), od)
