@@ -2,16 +2,18 @@
 //
 // Follows pkg/core/hnsw/hnsw_index.go:369-468 (searchInternal) and :2351-2611
 // (searchLayerUnlocked) of the reference, re-designed for CDNA4:
-//   * the reference's two binary heaps (hnsw_heap.go) become ONE distance-sorted beam array in LDS;
-//     pop-min = first un-expanded entry, result set = the array itself.  With distinct distances
-//     this yields exactly the reference's traversal (same expansions, same n_dist / n_hops, same
-//     results); equal distances are ordered by id instead of by heap history;
-//   * each hop evaluates the <=32 neighbour rows as a tile: 4 rows per pass, 16 lanes per row,
-//     16-byte coalesced loads straight to VGPRs (rows are streamed once, never staged), the query
+//   * the reference's two binary heaps (hnsw_heap.go) become ONE distance-sorted beam array, in registers (one entry per
+//     lane and slot) for ef <= 366, in LDS beyond; pop-min = first un-expanded entry, result set = the array itself.
+//     With distinct distances this yields exactly the reference's traversal (same expansions, same n_dist / n_hops,
+//     same results); equal distances are ordered by id instead of by heap history;
+//   * each hop evaluates the <=32 neighbour rows as a tile: 16 lanes per row, up to 12 rows (three per 16-lane group)
+//     per HBM round trip, 16-byte coalesced loads straight to VGPRs (rows are streamed once, never staged), the query
 //     stays in LDS, a DPP row reduction finishes each distance;
-//   * visited = a per-wave bitset in HBM (atomicOr test-and-set), cleared by the wave itself;
-//     upper layers un-mark what they marked instead of clearing;
-//   * queries are pulled from an atomic work counter by persistent waves.
+//   * visited = an exact hash set of node ids in LDS (ds_cmpst), migrating to a per-wave bitset in HBM only if it
+//     fills; large ef uses the bitset (atomicOr test-and-set, upper layers un-mark what they marked);
+//   * the query is prepared inside the kernel (normalise in the reference's order, f16 round trip) straight from the
+//     caller's buffer; queries are pulled from an atomic work counter by persistent waves;
+//   * one allow list per batch or one per query; its entry point (hnsw_index.go:437-447) is chosen on the device.
 #include "kdb_search_core.cuh"
 #include <stdio.h>
 #include <stdlib.h>
