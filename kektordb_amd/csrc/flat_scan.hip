@@ -62,6 +62,10 @@ struct FsParams {
     uint32_t *q_flag, *tile_flag;   // band merge writes: query / its 16-query tile needs the exact pass
     const uint32_t *q_tile;         // [B] tile of every query
     const uint32_t *q_sel, *tile_sel; // exact pass reads: only marked queries / tiles are processed
+    // last resort of the exact scans: queries whose finalists the rounding band could not isolate are re-scanned with
+    // keys in the final (wave) order by flat_rescue_kernel
+    uint32_t *rs_count, *rs_list;
+    float rmax;               // largest row norm (float32 rows), rounding band of the cosine scan
     uint32_t lists_query_major; // per-stripe lists: 0 = [tile][entry][128 queries] (tile kernel), 1 = [query][entry] (small kernel)
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
@@ -861,7 +865,14 @@ __device__ __forceinline__ uint32_t fs_block_sum(uint32_t v, uint32_t *red /*[8]
     return slot[0] + slot[1] + slot[2] + slot[3];
 }
 
-template <int METRIC, int PREC, int BAND>
+// MODE: how the finalists are isolated from the approximate keys of the stripe lists
+//   FM_KL     the kl = k+16 best keys (int8: integer dots are exact, keys differ from the final distance by one rounding)
+//   FM_BAND16 f16-ranked keys: everything inside the f16 error band of the k-th key; unsettled -> exact pass
+//   FM_ROUND  f32-accumulated keys (MFMA order, ||x||^2 - 2 q.x): everything inside the ROUNDING band of the k-th key;
+//             unsettled (more than 256 in the band, or a full stripe list reaching into it) -> rescue pass
+//   FM_EXACT  lists written by the rescue pass: keys are already the final distances
+constexpr int FM_KL = 0, FM_BAND16 = 1, FM_EXACT = 2, FM_ROUND = 3;
+template <int METRIC, int PREC, int MODE>
 __global__ void __launch_bounds__(256)
 flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__restrict__ qnorm, FsParams p, uint32_t k,
                   uint32_t nmax, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
@@ -873,10 +884,16 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     uint32_t *ctl = red + 8;                                                // [4]: total, nfin
     uint32_t *hist = ctl + 4;                                               // [256] radix-select bins
     float *qlds = reinterpret_cast<float *>(hist + 256);                    // [ld]
-    const uint32_t q = blockIdx.x;
+    constexpr bool BAND = MODE == FM_BAND16 || MODE == FM_ROUND;
+    uint32_t q = blockIdx.x;
     const int tid = (int)threadIdx.x;
-    if (p.b_dev && q >= *p.b_dev) return;               // exact pass over the unsettled queries only
-    if (p.q_sel && !p.q_sel[q]) return;                 // (grouped scan: marked in place)
+    if (MODE == FM_EXACT) { // the queries the rounding band could not settle
+        if (q >= *p.rs_count) return;
+        q = p.rs_list[q];
+    } else {
+        if (p.b_dev && q >= *p.b_dev) return;           // exact pass over the unsettled queries only
+        if (p.q_sel && !p.q_sel[q]) return;             // (grouped scan: marked in place)
+    }
     const uint32_t qo = p.q_map ? p.q_map[q] : q;       // where this query's answer goes
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
@@ -933,8 +950,8 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     }
     __syncthreads();
     const uint32_t n = ctl[0];
-    float q_s2 = 0.f; // ||q||^2 (band of the f16-ranked L2 scan)
-    if (BAND && METRIC == KDB_METRIC_L2) {
+    float q_s2 = 0.f; // ||q||^2 (the bands scale with it)
+    if ((MODE == FM_BAND16 && METRIC == KDB_METRIC_L2) || MODE == FM_ROUND) {
         // a query with components near the f16 range cannot be ranked in f16 at all: the exact pass answers it
         float s2 = 0.f, mx = 0.f;
         for (uint32_t i = (uint32_t)tid; i < v.dim; i += 256) {
@@ -953,7 +970,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         q_s2 = (rf[0] + rf[1]) + (rf[2] + rf[3]);
         mx = fmaxf(fmaxf(rf[4], rf[5]), fmaxf(rf[6], rf[7]));
         __syncthreads();
-        if (!(mx < 3.0e4f) || !(q_s2 < 1.0e30f)) {
+        if (MODE == FM_BAND16 && (!(mx < 3.0e4f) || !(q_s2 < 1.0e30f))) {
             if (tid == 0) {
                 const uint32_t pos = atomicAdd(p.fb_count, 1u);
                 if (p.q_flag) { p.q_flag[q] = 1u; p.tile_flag[p.q_tile[q]] = 1u; }
@@ -965,7 +982,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     // Every scan ranks on a key that is approximate or summed in another order (MFMA order, ||x||^2 - 2 q.x, -dot/||x||,
     // f16 products) and RE-SCORES its finalists in the order of the graph search, so a (query, row) pair has the same
     // distance bits whichever kernel produced it.  want = how many finalists the selection below isolates.
-    uint32_t want = BAND ? k : p.kl;
+    uint32_t want = MODE == FM_KL ? p.kl : k;
     if (want > 256u) want = 256u;
     unsigned long long T = ~0ull;
     if (n > want && n <= 256u) { // few survivors: rank by counting, one pass instead of a 32-step search
@@ -1043,8 +1060,25 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         // stripe that kept kl entries and whose worst kept key is inside the band may have dropped some.
         // cosine: keys are -dot of unit queries.  L2: keys are ||x||^2 - 2 q.x -- twice the dot error, which scales with
         // ||q|| (queries are not normalised), plus the worst-case f32 summation error of the exact distance
-        const float band = METRIC == KDB_METRIC_L2 ? 2.0f * p.band * (sqrtf(q_s2) * 1.0001f) + 6.0e-5f * (fabsf(fs_unpack_key(T)) + q_s2)
-                                                   : p.band;
+        float band;
+        if (MODE == FM_BAND16) {
+            band = METRIC == KDB_METRIC_L2 ? 2.0f * p.band * (sqrtf(q_s2) * 1.0001f) + 6.0e-5f * (fabsf(fs_unpack_key(T)) + q_s2) : p.band;
+        } else {
+            // FM_ROUND: key and final distance are the same real number summed in two orders.  gam bounds the relative
+            // error of a dim-term f32 sum in ANY order (dim * 2^-24, a few roundings more for the norm, the -2 q.x
+            // fma and the final subtraction).  cosine: both are q.x, each off by <= gam*||q||*||x||.  L2: the key is
+            // ||x||^2 - 2 q.x (error <= gam*(||x||^2 + 2||q||*||x||)), the final value sums (q-x)^2 (error <= gam*t);
+            // for the rows that matter t <= t_k, so ||x|| <= ||q|| + sqrt(t_k) and no bound on the row norms is needed.
+            // delta = the larger side; every true top-k row has a key within 2*delta of the k-th key.
+            const float gam = (float)(v.dim + 16u) * 5.97e-8f * 1.05f;
+            if (METRIC == KDB_METRIC_COSINE) {
+                band = 4.0f * gam * sqrtf(q_s2) * p.rmax;
+            } else {
+                float tk = fs_unpack_key(T) + q_s2;
+                tk = tk > 0.f ? tk : 0.f;
+                band = 2.0f * gam * (3.0f * q_s2 + 4.0f * sqrtf(q_s2 * tk) + 3.0f * tk) * 1.05f;
+            }
+        }
         const unsigned long long Tb = fs_pack(fs_unpack_key(T) + band, 0xffffffffu);
         uint32_t c = 0, sat = 0;
         for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += ent[i] <= Tb ? 1u : 0u;
@@ -1054,11 +1088,15 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const uint32_t n_band = fs_block_sum(c, red, tid, 0);
         const uint32_t n_sat = fs_block_sum(sat, red, tid, 1);
         __syncthreads();
-        if (n_band > 256u || n_sat) { // not settled here: the exact pass answers this query
+        if (n_band > 256u || n_sat) { // not settled here: the exact pass (rounding band: the rescue pass) answers this query
             if (tid == 0) {
-                const uint32_t pos = atomicAdd(p.fb_count, 1u);
-                if (p.q_flag) { p.q_flag[q] = 1u; p.tile_flag[p.q_tile[q]] = 1u; }
-                else p.fb_list[pos] = qo;
+                if (MODE == FM_ROUND) {
+                    p.rs_list[atomicAdd(p.rs_count, 1u)] = q;
+                } else {
+                    const uint32_t pos = atomicAdd(p.fb_count, 1u);
+                    if (p.q_flag) { p.q_flag[q] = 1u; p.tile_flag[p.q_tile[q]] = 1u; }
+                    else p.fb_list[pos] = qo;
+                }
             }
             return;
         }
@@ -1123,6 +1161,110 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         out_dist[(size_t)qo * k + i] = INFINITY;
     }
     if (tid == 0) out_count[qo] = nout;
+}
+
+// Rescue pass (rare): the stripes of the queries in rs_list are scanned again with keys computed in the FINAL order
+// (the wave order of the graph search, same device functions as the re-score above), so the stripe lists hold each
+// stripe's true best kl and the FM_EXACT merge needs no band.  One workgroup per (query, stripe) work item, taken in
+// a grid-stride loop so that the launch costs nothing when the list is empty; a wave scores 4 rows per step
+// (16 lanes per row), appends what beats its threshold to its own LDS buffer and compacts it when it fills; the four
+// buffers are folded into one at the end.  HBM-bound re-read of the stripe's rows: ~3 GB for one query at 1M x 768.
+constexpr uint32_t FSR_BUF = 320; // entries per wave buffer (fs_compact_wave handles up to 320)
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qlds = reinterpret_cast<float *>(smem);                               // [ld]
+    float *bkey = qlds + v.ld;                                                   // [4][FSR_BUF]
+    uint32_t *bid = reinterpret_cast<uint32_t *>(bkey + 4 * FSR_BUF);            // [4][FSR_BUF]
+    uint32_t *wcnt = bid + 4 * FSR_BUF;                                          // [4]
+    const uint32_t n_rs = *p.rs_count;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, t = lane & 15;
+    const uint32_t qstride = p.n_qtiles * FS_TQ;
+    for (uint32_t item = blockIdx.x; item < n_rs * p.want; item += gridDim.x) {
+        const uint32_t q = p.rs_list[item / p.want], sidx = item % p.want;
+        const uint32_t *scan_ids = p.scan_ids;
+        FsGeom geo;
+        if (p.g_of_query) {
+            const uint32_t grp = p.g_of_query[q];
+            scan_ids = p.scan_ids + p.g_base[grp];
+            geo = fs_resolve_n(p, p.g_nscan[grp]);
+        } else {
+            geo = fs_resolve(p);
+        }
+        if (sidx >= geo.n_stripes) continue; // uniform over the workgroup
+        const uint32_t row_begin = sidx * geo.rows_per_stripe;
+        const uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
+        __syncthreads(); // the previous item's buffers are no longer read
+        for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256)
+            reinterpret_cast<float4 *>(qlds)[i] = reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld)[i];
+        __syncthreads();
+        float *mk = bkey + wave * FSR_BUF;
+        uint32_t *mi = bid + wave * FSR_BUF;
+        uint32_t cnt = 0;
+        unsigned long long thr = ~0ull;
+        for (uint32_t base = row_begin + (uint32_t)wave * 4u; base < row_end; base += 16u) {
+            const uint32_t r = base + (uint32_t)g;
+            const bool act = r < row_end;
+            const uint32_t id = act ? (scan_ids ? scan_ids[r] : r + 1u) : 0u;
+            float part;
+            if (PREC == KDB_PREC_F16) {
+                part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            } else if (METRIC == KDB_METRIC_COSINE) { // key = -dot
+                part = -kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_COSINE>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            } else {
+                part = kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            }
+            const unsigned long long e = fs_pack(part, id);
+            bool pass = act && t == 0 && e < thr;
+            unsigned long long m = __ballot(pass);
+            if (!m) continue;
+            if (cnt + 4u > FSR_BUF) {
+                thr = fs_compact_wave<1>(mk, mi, cnt, p.kl);
+                cnt = p.kl;
+                pass = pass && e <= thr;
+                m = __ballot(pass);
+            }
+            if (pass) {
+                const uint32_t pos = cnt + kdb_mbcnt(m);
+                mk[pos] = part;
+                mi[pos] = id;
+            }
+            cnt += (uint32_t)__builtin_popcountll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        }
+        if (cnt > p.kl) {
+            (void)fs_compact_wave<1>(mk, mi, cnt, p.kl);
+            cnt = p.kl;
+        }
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        if (wave == 0) { // fold the other waves' lists into this one (<= 2 kl <= 288 entries at a time)
+            for (int w = 1; w < 4; w++) {
+                const uint32_t c = wcnt[w];
+                for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
+                    mk[cnt + i] = bkey[w * FSR_BUF + i];
+                    mi[cnt + i] = bid[w * FSR_BUF + i];
+                }
+                cnt += c;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                if (cnt > p.kl) {
+                    (void)fs_compact_wave<1>(mk, mi, cnt, p.kl);
+                    cnt = p.kl;
+                }
+            }
+            const size_t lb = p.lists_query_major ? ((size_t)sidx * qstride + q) * p.cap
+                                                  : ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ);
+            const size_t est = p.lists_query_major ? 1 : (size_t)FS_TQ;
+            for (uint32_t i = (uint32_t)lane; i < cnt; i += 64) {
+                p.part_key[lb + i * est] = mk[i];
+                p.part_id[lb + i * est] = mi[i];
+            }
+            if (lane == 0) p.part_cnt[(size_t)sidx * qstride + q] = cnt;
+        }
+    }
 }
 
 // ranking copy of float32 rows: ld halfs per row (pad columns included), RNE
@@ -1427,7 +1569,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
     const size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
     const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
-    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + part_bytes + 4096);
+    const size_t rsl_bytes = ((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255; // queries handed to the rescue pass
+    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes + part_bytes + 4096);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
@@ -1435,7 +1578,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     float *d_fbq = reinterpret_cast<float *>(base + ids_bytes + 256);
     uint32_t *d_fblist = reinterpret_cast<uint32_t *>(base + ids_bytes + 256 + fbq_bytes);
     uint32_t *d_fbcount = d_nscan + 4; // inside the 256-byte header
-    unsigned char *part = base + ids_bytes + 256 + fbq_bytes + fbl_bytes;
+    uint32_t *d_rscount = d_nscan + 8;
+    uint32_t *d_rslist = reinterpret_cast<uint32_t *>(base + ids_bytes + 256 + fbq_bytes + fbl_bytes);
+    unsigned char *part = base + ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes;
     if (need_ids) {
         KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
         hipLaunchKernelGGL(compact_ids_kernel, dim3(((v.count >> 5) + 256) / 256), dim3(256), 0, s, v.deleted, d_allow, d_first_allowed,
@@ -1457,6 +1602,10 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * cap * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * cap * 8);
     p.lists_query_major = small ? 1u : 0u;
+    p.rs_count = d_rscount;
+    p.rs_list = d_rslist;
+    p.rmax = idx->max_norm2 > 0.f ? sqrtf(idx->max_norm2) : 1.0f;
+    if (v.precision != KDB_PREC_I8) KDB_HIP(hipMemsetAsync(d_rscount, 0, 4, s));
     const uint32_t n_stripes = want; // upper bound: workgroups of stripes past the resolved count return at once
 
     const size_t lds = (size_t)(FS_TR + FS_TQ) * FS_LDS_STRIDE * 4 + FS_TQ * 12 + (size_t)FS_TQ * FS_QPER * 8 +
@@ -1513,6 +1662,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                            d_out_dist, d_out_count);
         return KDB_OK;
     };
+    // exact scans isolate their finalists inside the rounding band (FM_ROUND); what that cannot settle -- a cluster of
+    // near-duplicates larger than a stripe list or than the 256 re-score slots -- is re-scanned in the final summation
+    // order.  Both launches return at once when the list is empty (the usual case).
+    const size_t rlds = (size_t)v.ld * 4 + 4 * FSR_BUF * 8 + 64;
+    auto rescue = [&](auto scan_k, auto merge_k, const FsParams &pp, const void *qv) -> int {
+        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(qv), pp);
+        KDB_HIP(hipGetLastError());
+        return launch_merge(merge_k, pp, qv);
+    };
     if (rank16) {
         // eps bounds |q.x (wave order) - sum f16(q)f16(x) (MFMA order)| for rows and queries of norm <= 1: f16 rounding
         // of both factors (2^-10 and its square), f32 summation in either order (dim * 2^-23); band = 2 * eps
@@ -1522,8 +1680,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_count = d_fbcount;
         p.fb_list = d_fblist;
         KDB_HIP(hipMemsetAsync(d_fbcount, 0, 4, s));
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p, d_q);
-        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 1>, p, d_q);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_BAND16>, p, d_q);
+        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_BAND16>, p, d_q);
         if (rc) return rc;
         KDB_HIP(hipGetLastError());
         // the exact pass over the queries the band could not settle (usually none: every launch below returns at
@@ -1552,16 +1710,38 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
             hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_fbq), p2);
             KDB_HIP(hipGetLastError());
         }
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2, d_fbq);
-        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2, d_fbq);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>, p2, d_fbq);
+        else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_ROUND>, p2, d_fbq);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        if (v.metric == KDB_METRIC_COSINE)
+            rc = rescue(flat_rescue_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_EXACT>, p2, d_fbq);
+        else rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_EXACT>, p2, d_fbq);
         // statistics: how many queries the exact pass settled (kdb_counters.n_hops of a flat-scan launch)
         KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbcount, 4, hipMemcpyDeviceToDevice, s));
-    } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>, p, d_q);
-    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, 0>, p, d_q);
-    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p, d_q);
-    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p, d_q);
+    } else if (v.precision == KDB_PREC_I8) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, FM_KL>, p, d_q);
+    } else if (v.precision == KDB_PREC_F16) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, FM_ROUND>, p, d_q);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F16>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, FM_EXACT>, p, d_q);
+    } else if (v.metric == KDB_METRIC_COSINE) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>, p, d_q);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_EXACT>, p, d_q);
+    } else {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_ROUND>, p, d_q);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_EXACT>, p, d_q);
+    }
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
+    // statistics: queries answered by the rescue pass (high word of kdb_counters.n_hops of a flat-scan launch)
+    if (v.precision != KDB_PREC_I8)
+        KDB_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t *>(stat_slot + 1) + 1, d_rscount, 4, hipMemcpyDeviceToDevice, s));
     return KDB_OK;
 }
 
@@ -1651,7 +1831,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     if (total > (uint64_t)G * v.count) total = (uint64_t)G * v.count;
     const size_t ids_bytes = al((size_t)total * 4 + 1024);
     const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
-    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 3 + 256 + part_bytes + 4096;
+    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + part_bytes + 4096;
     rc = kdb_ensure_scratch(idx, need);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
@@ -1665,7 +1845,9 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     uint32_t *d_qflag = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qtile) + al((size_t)B * 4));
     uint32_t *d_tflag = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qflag) + al((size_t)B * 4));
     uint32_t *d_fbc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_tflag) + al(tiles.size() * 4));
-    unsigned char *part = reinterpret_cast<unsigned char *>(d_fbc) + 256;
+    uint32_t *d_rsc = d_fbc + 4; // queries handed to the rescue pass: count (inside the 256-byte block), list
+    uint32_t *d_rsl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_fbc) + 256);
+    unsigned char *part = reinterpret_cast<unsigned char *>(d_rsl) + al((size_t)B * 4);
     // float32 indexes with a half-precision row copy rank on it inside the error band (see kdb_launch_flat_scan); the
     // exact pass re-runs only the tiles that hold an unsettled query, with their group's id list
     const bool rank16 = v.precision == KDB_PREC_F32 && idx->d_rows16 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
@@ -1699,6 +1881,9 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.part_id = reinterpret_cast<uint32_t *>(part + n_part * kl * 4);
     p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part * kl * 8);
     p.lists_query_major = 1u;
+    p.rs_count = d_rsc;
+    p.rs_list = d_rsl;
+    p.rmax = idx->max_norm2 > 0.f ? sqrtf(idx->max_norm2) : 1.0f;
     p.g_tile = d_tiles;
     p.g_nscan = d_gn;
     p.g_base = d_gbase;
@@ -1733,6 +1918,12 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         return KDB_OK;
     };
     auto launch_merge = [&](auto kern) -> int { return launch_merge_on(kern, p); };
+    const size_t rlds = (size_t)v.ld * 4 + 4 * FSR_BUF * 8 + 64;
+    auto rescue = [&](auto scan_k, auto merge_k, const FsParams &pp) -> int { // see kdb_launch_flat_scan
+        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(d_q), pp);
+        KDB_HIP(hipGetLastError());
+        return launch_merge_on(merge_k, pp);
+    };
     if (rank16) {
         const float rmax = v.metric == KDB_METRIC_COSINE ? (idx->max_norm2 > 1.0f ? sqrtf(idx->max_norm2) : 1.0f) : sqrtf(idx->max_norm2);
         p.band = 2.0f * (9.9e-4f + (float)v.dim * 2.4e-7f) * rmax * 1.001f;
@@ -1740,8 +1931,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         p.q_flag = d_qflag;
         p.tile_flag = d_tflag;
         p.q_tile = d_qtile;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 1>, p);
-        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 1>, p);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_BAND16>, p);
+        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_BAND16>, p);
         if (rc) return rc;
         KDB_HIP(hipGetLastError());
         FsParams p2 = p; // exact pass: the marked tiles, the marked queries
@@ -1755,14 +1946,35 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, lds_s);
         if (rc) return rc;
         KDB_HIP(hipGetLastError());
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>, p2);
-        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>, p2);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>, p2);
+        else rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_ROUND>, p2);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        if (v.metric == KDB_METRIC_COSINE)
+            rc = rescue(flat_rescue_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_EXACT>, p2);
+        else rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_EXACT>, p2);
         if (stat_slot) KDB_HIP(hipMemcpyAsync(stat_slot + 1, d_fbc, 4, hipMemcpyDeviceToDevice, s));
-    } else if (v.precision == KDB_PREC_I8) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, 0>);
-    else if (v.precision == KDB_PREC_F16) rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, 0>);
-    else if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, 0>);
-    else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, 0>);
+    } else if (v.precision == KDB_PREC_I8) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, FM_KL>);
+    } else if (v.precision == KDB_PREC_F16) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, FM_ROUND>);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F16>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F16, FM_EXACT>, p);
+    } else if (v.metric == KDB_METRIC_COSINE) {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_EXACT>, p);
+    } else {
+        rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_ROUND>);
+        if (rc) return rc;
+        KDB_HIP(hipGetLastError());
+        rc = rescue(flat_rescue_kernel<KDB_METRIC_L2, KDB_PREC_F32>, flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_EXACT>, p);
+    }
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
+    if (stat_slot && v.precision != KDB_PREC_I8)
+        KDB_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t *>(stat_slot + 1) + 1, d_rsc, 4, hipMemcpyDeviceToDevice, s));
     return KDB_OK;
 }

@@ -38,6 +38,13 @@ def raw_to_score(idx, raw):
     return np.array([idx.score(r) for r in raw], dtype=np.float64)
 
 
+def flat_stats(idx):
+    """(queries settled by the exact pass, queries settled by the rescue pass) of the last flat-scan launch:
+    the low / high word of kdb_counters.n_hops"""
+    h = idx.launch_stats(1)[0]["n_hops"]
+    return h & 0xffffffff, h >> 32
+
+
 def assert_same_results_tol(ids_a, d_a, ids_b, d_b):
     """same ids, distances within tolerance; swaps/differences allowed only between near-ties"""
     n = min(len(ids_a), len(ids_b))
@@ -578,7 +585,7 @@ def test_flat_scan_groups(oracle, hip, metric, corpus):
         idx.flat_scan_groups_dev(dQ, k, off, dL, oi, od, oc, max_total_allowed=bound)
         idx.sync()
         if corpus == "near_duplicates":
-            assert idx.launch_stats(1)[0]["n_hops"] > 0   # queries settled by the exact pass
+            assert flat_stats(idx)[0] > 0   # queries settled by the exact pass
         ids, dist, cnt = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy()
         for g in range(len(sizes)):
             for b in range(int(off[g]), int(off[g + 1])):
@@ -687,7 +694,7 @@ def test_flat_scan_f16_ranked_band_l2(oracle, hip, case, B):
     idx.set_count(n)
     orc.set_arith(O.ARITH_HIP_WAVE)
     ids, dist, cnt = idx.flat_scan_batch(Q, k)
-    settled_exactly = idx.launch_stats(1)[0]["n_hops"]
+    settled_exactly = flat_stats(idx)[0]
     if case == "near_duplicates":
         assert settled_exactly == B
     elif case == "dense_block":
@@ -746,7 +753,7 @@ def test_flat_scan_f16_ranked_band_is_exact(oracle, hip, case, B):
     idx.set_count(n)
     orc.set_arith(O.ARITH_HIP_WAVE)
     ids, dist, cnt = idx.flat_scan_batch(Q, k)
-    settled_exactly = idx.launch_stats(1)[0]["n_hops"]
+    settled_exactly = flat_stats(idx)[0]
     if case == "near_duplicates":
         assert settled_exactly == B        # every band overflows
     elif case == "one_dense_stripe":
@@ -778,3 +785,66 @@ def test_flat_scan_without_ranking_copy(oracle, hip):
             oi, od = orc.flat_scan(Q[b], k)
             assert np.array_equal(ids[b, :int(cnt[b])], oi)
             assert np.array_equal(raw_to_score(idx, dist[b, :int(cnt[b])]), od)
+
+
+@pytest.mark.parametrize("B", [3, 70])
+@pytest.mark.parametrize("case", ["f32_l2", "f32_cosine", "f16_l2", "f32_l2_filtered", "f32_l2_wide"])
+def test_flat_scan_rounding_band_rescue(oracle, hip, case, B):
+    """Rows that differ by less than the rounding error of the ranking key (||x||^2 - 2 q.x in MFMA order vs the
+    final wave-order sum): a block of near-duplicates longer than a stripe list (or than the 256 re-score slots) next
+    to the queries.  The rounding band sees that its finalists are not isolated and the rescue pass re-scans those
+    queries in the final summation order; answers are the oracle's bit for bit.  (Found by tests/tools/fuzz_flat.py.)"""
+    import torch
+    from kektordb_amd.index import dense_bitset
+    O = oracle
+    rng = np.random.default_rng(41)
+    n, dim, k = 3000, 768, 5
+    prec = O.F16 if case == "f16_l2" else O.F32
+    metric = 1 if case == "f32_cosine" else 0
+    scale = 0.5 if prec == O.F16 else 3.0
+    X = (rng.standard_normal((n, dim)) * scale).astype(np.float32)
+    width = 400 if case == "f32_l2_wide" else 60
+    X[600:600 + width] = X[600] + (2e-3 if prec == O.F16 else 1e-4) * rng.standard_normal((width, dim)).astype(np.float32)
+    Q = (X[600][None, :] + 0.1 * scale * rng.standard_normal((B, dim))).astype(np.float32)
+    orc = O.OracleIndex(dim, metric, prec, 8, 16, seed=3)
+    orc.add_many(X)
+    for d in (610, 633):
+        orc.mark_deleted(d)
+    idx = hip.HipIndex(dim, metric, prec, 8, 16, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_graph_obj(orc.export_graph())
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    allow = None
+    if case == "f32_l2_filtered":
+        a = np.nonzero(rng.random(n + 1) < 0.7)[0]
+        allow = dense_bitset(a[a >= 1], n)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k, allow_bits=allow)
+    assert flat_stats(idx)[1] > 0, "the rescue pass did not run"
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k, allow=allow)
+        c = int(cnt[b])
+        assert c == len(oi) == k
+        assert np.array_equal(ids[b, :c], oi), (case, b, ids[b, :c], oi)
+        assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (case, b)
+    # the grouped scan takes the same route
+    if B >= 2:
+        lists = []
+        for sel in (0.8, 0.5):
+            a = np.nonzero(rng.random(n + 1) < sel)[0]
+            lists.append(dense_bitset(a[a >= 1], n))
+        L = np.stack(lists)
+        off = np.array([0, B // 2, B], dtype=np.uint32)
+        dev = torch.device("cuda:0")
+        oi_ = torch.zeros((B, k), dtype=torch.int32, device=dev)
+        od_ = torch.zeros((B, k), dtype=torch.float32, device=dev)
+        oc_ = torch.zeros((B,), dtype=torch.int32, device=dev)
+        idx.flat_scan_groups_dev(torch.from_numpy(Q).to(dev), k, off, torch.from_numpy(L.view(np.int64)).to(dev), oi_, od_, oc_)
+        idx.sync()
+        assert flat_stats(idx)[1] > 0
+        gi, gd, gc = oi_.cpu().numpy().view(np.uint32), od_.cpu().numpy(), oc_.cpu().numpy()
+        for b in range(B):
+            oi, od = orc.flat_scan(Q[b], k, allow=L[0 if b < B // 2 else 1])
+            c = int(gc[b])
+            assert c == len(oi)
+            assert np.array_equal(gi[b, :c], oi), (case, "grouped", b)
+            assert np.array_equal(raw_to_score(idx, gd[b, :c]), od), (case, "grouped", b)
