@@ -109,7 +109,9 @@ typedef struct {
 
 typedef struct {
     uint64_t n_dist;       /* distance evaluations of the last search call             */
-    uint64_t n_hops;       /* expanded candidates of the last search call              */
+    uint64_t n_hops;       /* expanded candidates of the last search call; flat scan:  *
+                            * low word = queries settled by the exact pass of the      *
+                            * f16-ranked scan, high word = by the rescue pass           */
     uint64_t bytes;        /* algorithmic bytes of the last call   */
     double last_kernel_ms; /* HIP-event duration of the dominant kernel of the last call */
 } kdb_counters;

@@ -13,8 +13,10 @@
 //            owner lanes keep the stripe's best kl = k+16 (LDS lists, or buffers compacted by whole waves).
 //   settle   flat_merge_kernel gathers the stripe lists of a query, isolates the finalists (radix select) and
 //            RE-SCORES them in the accumulation order of the graph search (wave order), so a (query, row) pair has
-//            one distance bit pattern whichever kernel produced it.  The f16-ranked float32 scan re-scores every
-//            entry inside a rigorous error band and hands queries it cannot settle to an exact second pass.
+//            one distance bit pattern whichever kernel produced it.  Finalists = every entry inside a rigorous
+//            error band of the k-th key: the f16 error band of the f16-ranked float32 scan (unsettled queries go to
+//            an exact second pass), the f32 ROUNDING band of the exact scans (unsettled queries -- clusters of
+//            near-duplicates -- are re-scanned in the final summation order by flat_rescue_kernel).
 // blockIdx -> (stripe, query tile) is XCD-aware: the query tiles of one stripe run on the same XCD so the stripe's
 // rows are fetched from HBM once and shared in L2.
 #include "kdb_device.cuh"
