@@ -114,6 +114,9 @@ typedef struct {
                             * f16-ranked scan, high word = by the rescue pass           */
     uint64_t bytes;        /* algorithmic bytes of the last call   */
     double last_kernel_ms; /* HIP-event duration of the dominant kernel of the last call */
+    uint64_t n_dropped;    /* graph search: pending traversal-only candidates (deleted    *
+                            * nodes) discarded because more than 2048 were waiting; 0 =   *
+                            * the walk was the reference's, step for step                 */
 } kdb_counters;
 
 typedef struct {

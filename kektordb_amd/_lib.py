@@ -45,7 +45,7 @@ class GraphView(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("n_dist", C.c_uint64), ("n_hops", C.c_uint64), ("bytes", C.c_uint64),
-                ("last_kernel_ms", C.c_double)]
+                ("last_kernel_ms", C.c_double), ("n_dropped", C.c_uint64)]
 
 
 class BuildParams(C.Structure):

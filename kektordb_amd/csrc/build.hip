@@ -75,6 +75,9 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     s.beam_d = nullptr;
     s.beam_id = nullptr;
     s.beam_cap = 0;
+    s.nr_d = nullptr; // construction never meets a deleted node or a filter
+    s.nr_id = nullptr;
+    s.nr_cap = 0;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
@@ -105,7 +108,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         __threadfence_block();
         wave_lds_fence();
         RegBeam<BS> b;
-        QCtr ctr{0, 0};
+        QCtr ctr{0, 0, 0};
         uint32_t ep = v.entry;
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;

@@ -1060,12 +1060,12 @@ extern "C" int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B,
 }
 
 static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     float ms = 0.f;
     if (hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
         hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess)
         ms = 0.f;
-    KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 4, 16, hipMemcpyDeviceToHost));
+    KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 4, 32, hipMemcpyDeviceToHost));
     kdb_counters r{};
     r.last_kernel_ms = ms;
     const uint64_t row_bytes = (uint64_t)idx->desc.dim * idx->elem;
@@ -1073,6 +1073,7 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     if (kind == 1) { // n_dist*(dim*elem) + n_hops*(deg_cap*4) + n_dist*4
         r.n_dist = c[0];
         r.n_hops = c[1];
+        r.n_dropped = c[3];
         r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
     } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
         r.n_dist = c[0] * (uint64_t)idx->ring_B[slot]; // rows scanned (after filter / deletes) x queries

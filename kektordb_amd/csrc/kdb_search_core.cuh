@@ -2,11 +2,13 @@
 // See search.hip for the design notes; reference: pkg/core/hnsw/hnsw_index.go:2351-2611.
 //
 // The reference's candidate min-heap + result max-heap (hnsw_heap.go) are ONE distance-sorted beam:
-// pop-min = first un-expanded entry, results = the non-traversal-only entries.  Two storages with the
-// same interface:
+// pop-min = first un-expanded entry, results = the entries.  Candidates that never enter the result heap
+// (soft-deleted nodes, a non-allowed entry point) wait in a small unsorted side list in LDS (NrList) and are
+// popped in the same (distance, id) order; the list is empty unless the index holds deleted nodes.
+// Two beam storages with the same interface:
 //   RegBeam<S>  entry i lives in lane i&63, register slot i>>6 (64*S entries).  Position search is a
 //               ballot + scalar popcount, the shift is a DPP wave_shr, reads are v_readlane: no LDS
-//               round trips on the hop's critical path.  Used for ef <= 366.
+//               round trips on the hop's critical path.  Used for ef <= 382.
 //   LdsBeam     arrays in LDS, any ef that fits LDS.
 #pragma once
 #include "kdb_device.cuh"
@@ -34,6 +36,9 @@ struct WaveLds {
     float *nb_d;       // [64]
     uint32_t *marks;   // [KDB_UP_MARK_CAP]
     uint32_t beam_cap; // entries in beam_d / beam_id
+    float *nr_d;       // [nr_cap] traversal-only candidates (NrList)
+    uint32_t *nr_id;   // [nr_cap]
+    uint32_t nr_cap;
 };
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
@@ -192,15 +197,13 @@ struct RegBeam {
     static constexpr uint32_t CAP = 64u * S;
     float d[S];
     uint32_t id[S]; // id | flags
-    uint32_t count, n_res, n_nr, scan_from, nr_max;
+    uint32_t count, n_res, scan_from;
     float worst;
 
     __device__ __forceinline__ void bind(const WaveLds &) {}
-    __device__ __forceinline__ void reset(uint32_t ef) {
-        count = n_res = n_nr = scan_from = 0;
+    __device__ __forceinline__ void reset(uint32_t) {
+        count = n_res = scan_from = 0;
         worst = INFINITY;
-        const int slack = (int)CAP - (int)ef - 2; // traversal-only (deleted / non-allowed entry) entries kept
-        nr_max = slack > 63 ? 63u : (slack < 0 ? 0u : (uint32_t)slack);
 #pragma unroll
         for (int s = 0; s < S; s++) {
             d[s] = INFINITY;
@@ -233,19 +236,6 @@ struct RegBeam {
             const bool f = i >= scan_from && i < count && !(id[s] & KDB_F_EXPANDED);
             const unsigned long long m = __ballot(f);
             if (m) return (int)(64u * s + (uint32_t)__builtin_ctzll(m));
-        }
-        return -1;
-    }
-    // index of the last entry whose (flags & mask) == want; -1 if none
-    __device__ __forceinline__ int last_with(uint32_t mask, uint32_t want) const {
-        const uint32_t lane = (uint32_t)kdb_lane();
-#pragma unroll
-        for (int s = S - 1; s >= 0; s--) {
-            if (64u * s >= count) continue;
-            const uint32_t i = 64u * s + lane;
-            const bool f = i < count && ((id[s] & mask) == want);
-            const unsigned long long m = __ballot(f);
-            if (m) return (int)(64u * s + 63u - (uint32_t)__builtin_clzll(m));
         }
         return -1;
     }
@@ -287,51 +277,11 @@ struct RegBeam {
         count++;
         if (pos < scan_from) scan_from = pos;
     }
-    // remove entry j (shift the tail left by one)
-    __device__ __forceinline__ void remove(uint32_t j) {
-        const uint32_t lane = (uint32_t)kdb_lane();
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            if (64u * (s + 1) <= j || 64u * s >= count) continue;
-            const uint32_t i = 64u * s + lane;
-            float nd = shl1_f(d[s]);
-            uint32_t ni = shl1_u(id[s]);
-            if (s + 1 < S) {
-                const float cd = readlane_f(d[s + 1 < S ? s + 1 : s], 0);
-                const uint32_t ci = readlane_u(id[s + 1 < S ? s + 1 : s], 0);
-                if (lane == 63) {
-                    nd = cd;
-                    ni = ci;
-                }
-            }
-            if (i >= j) {
-                d[s] = nd;
-                id[s] = ni;
-            }
-        }
-        count--;
-        if (scan_from > j) scan_from--;
-    }
-    // invariants: n_res <= ef; when n_res == ef the last entry is a result (the worst);
-    // at most nr_max traversal-only entries
+    // every entry is a result: n_res == count <= ef after trimming, the last entry is the worst
     __device__ __forceinline__ void trim(uint32_t ef) {
-        if (n_res > ef) {
-            const int j = n_nr == 0 ? (int)count - 1 : last_with(KDB_F_NORESULT, 0u);
-            n_nr -= (count - 1 - (uint32_t)j); // farther traversal-only entries go with it
-            count = (uint32_t)j;
+        if (n_res > ef) { // heap_pop(results): the farthest result leaves
+            count--;
             n_res--;
-        }
-        if (n_res >= ef && n_nr != 0) {
-            const int j = last_with(KDB_F_NORESULT, 0u);
-            if (j >= 0) {
-                n_nr -= (count - 1 - (uint32_t)j);
-                count = (uint32_t)j + 1;
-            }
-        }
-        while (n_nr > nr_max) { // pathological: many deleted nodes nearer than the worst result
-            const int j = last_with(KDB_F_NORESULT, KDB_F_NORESULT);
-            remove((uint32_t)j);
-            n_nr--;
         }
         if (n_res >= ef && count > 0) {
             float dd;
@@ -348,13 +298,13 @@ struct RegBeam {
         for (int s = 0; s < S; s++) {
             if (64u * s >= count) continue;
             const uint32_t i = 64u * s + lane;
-            const bool f = i < count && !(id[s] & KDB_F_NORESULT);
+            const bool f = i < count;
             const unsigned long long m = __ballot(f);
             if (m) return (int)(64u * s + (uint32_t)__builtin_ctzll(m));
         }
         return -1;
     }
-    // results (non traversal-only entries, ascending), first k -> out arrays; returns the number written
+    // results (ascending), first k -> out arrays; returns the number written
     __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate) const {
         const uint32_t lane = (uint32_t)kdb_lane();
         uint32_t nout = 0;
@@ -362,7 +312,7 @@ struct RegBeam {
         for (int s = 0; s < S; s++) {
             if (64u * s >= count || nout >= k) continue;
             const uint32_t i = 64u * s + lane;
-            const bool f = i < count && !(id[s] & KDB_F_NORESULT);
+            const bool f = i < count;
             const unsigned long long m = __ballot(f);
             const uint32_t p = nout + kdb_mbcnt(m);
             if (f && p < k) {
@@ -382,7 +332,7 @@ struct LdsBeam {
     float *bd;
     uint32_t *bi;
     uint32_t cap;
-    uint32_t count, n_res, n_nr, scan_from, nr_max;
+    uint32_t count, n_res, scan_from;
     float worst;
 
     __device__ __forceinline__ void bind(const WaveLds &s) {
@@ -390,10 +340,9 @@ struct LdsBeam {
         bi = s.beam_id;
         cap = s.beam_cap;
     }
-    __device__ __forceinline__ void reset(uint32_t ef) {
-        count = n_res = n_nr = scan_from = 0;
+    __device__ __forceinline__ void reset(uint32_t) {
+        count = n_res = scan_from = 0;
         worst = INFINITY;
-        nr_max = cap > ef + 2 ? cap - ef - 2 : 0; // traversal-only entries kept (the launcher sizes cap ~ 2*ef)
     }
     __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const {
         dd = unif(bd[idx]);
@@ -409,15 +358,6 @@ struct LdsBeam {
             const bool f = i < count && !(bi[i] & KDB_F_EXPANDED);
             const unsigned long long m = __ballot(f);
             if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
-        }
-        return -1;
-    }
-    __device__ __forceinline__ int last_with(uint32_t mask, uint32_t want) const {
-        for (int base = (int)count - 1; base >= 0; base -= 64) {
-            const int i = base - kdb_lane();
-            const bool f = i >= 0 && ((bi[i] & mask) == want);
-            const unsigned long long m = __ballot(f);
-            if (m) return base - __builtin_ctzll(m);
         }
         return -1;
     }
@@ -459,51 +399,17 @@ struct LdsBeam {
         count++;
         if (pos < scan_from) scan_from = pos;
     }
-    __device__ __forceinline__ void remove(uint32_t j) {
-        for (uint32_t lo = j; lo + 1 < count; lo += 64) {
-            const uint32_t i = lo + (uint32_t)kdb_lane();
-            const bool act = i + 1 < count;
-            float e = 0.f;
-            uint32_t x = 0;
-            if (act) {
-                e = bd[i + 1];
-                x = bi[i + 1];
-            }
-            wave_lds_fence();
-            if (act) {
-                bd[i] = e;
-                bi[i] = x;
-            }
-            wave_lds_fence();
-        }
-        count--;
-        if (scan_from > j) scan_from--;
-    }
     __device__ __forceinline__ void trim(uint32_t ef) {
         if (n_res > ef) {
-            const int j = n_nr == 0 ? (int)count - 1 : last_with(KDB_F_NORESULT, 0u);
-            n_nr -= (count - 1 - (uint32_t)j);
-            count = (uint32_t)j;
+            count--;
             n_res--;
-        }
-        if (n_res >= ef && n_nr != 0) {
-            const int j = last_with(KDB_F_NORESULT, 0u);
-            if (j >= 0) {
-                n_nr -= (count - 1 - (uint32_t)j);
-                count = (uint32_t)j + 1;
-            }
-        }
-        while (n_nr > nr_max) {
-            const int j = last_with(KDB_F_NORESULT, KDB_F_NORESULT);
-            remove((uint32_t)j);
-            n_nr--;
         }
         worst = (n_res >= ef && count > 0) ? unif(bd[count - 1]) : INFINITY;
     }
     __device__ __forceinline__ int first_result() const {
         for (uint32_t base = 0; base < count; base += 64) {
             const uint32_t i = base + (uint32_t)kdb_lane();
-            const bool f = i < count && !(bi[i] & KDB_F_NORESULT);
+            const bool f = i < count;
             const unsigned long long m = __ballot(f);
             if (m) return (int)(base + (uint32_t)__builtin_ctzll(m));
         }
@@ -513,7 +419,7 @@ struct LdsBeam {
         uint32_t nout = 0;
         for (uint32_t base = 0; base < count && nout < k; base += 64) {
             const uint32_t i = base + (uint32_t)kdb_lane();
-            const bool f = i < count && !(bi[i] & KDB_F_NORESULT);
+            const bool f = i < count;
             const unsigned long long m = __ballot(f);
             const uint32_t p = nout + kdb_mbcnt(m);
             if (f && p < k) {
@@ -642,8 +548,109 @@ struct VisHash { // hybrid: LDS hash set that migrates into the wave's HBM bitse
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Traversal-only candidates: soft-deleted nodes and a non-allowed entry point are pushed on the reference's candidate
+// heap but never on its result heap (:2480-2489, :2583-2590).  They wait here, unsorted, and are popped in the same
+// (distance, id) order as beam entries.  Exact as long as the list has room: when it fills, entries that can never
+// be expanded (farther than the worst of a full result set -- worst only shrinks) are discarded first; only if more
+// than nr_cap candidates are still pending is the farthest one dropped, and that is counted (kdb_counters.n_dropped).
+// ------------------------------------------------------------------------------------------------
+struct NrList {
+    float *d;
+    uint32_t *id;
+    uint32_t cap, count, dropped;
+    __device__ __forceinline__ void bind(const WaveLds &s) {
+        d = s.nr_d;
+        id = s.nr_id;
+        cap = s.nr_cap;
+        count = 0;
+        dropped = 0;
+    }
+    static __device__ __forceinline__ unsigned long long pack(float key, uint32_t idv) {
+        uint32_t u = __float_as_uint(key);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving
+        return ((unsigned long long)u << 32) | idv;
+    }
+    // position of the extreme (distance, id) pair (smallest, or largest when MAX); count > 0
+    template <bool MAX>
+    __device__ __forceinline__ uint32_t extreme(float &dd, uint32_t &idv) const {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        unsigned long long best = MAX ? 0ull : ~0ull;
+        uint32_t pos = 0;
+        for (uint32_t i = lane; i < count; i += 64) {
+            const unsigned long long e = pack(d[i], id[i]);
+            if (MAX ? e >= best : e <= best) {
+                best = e;
+                pos = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(best >> 32), o, 64);
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(best & 0xffffffffu), o, 64);
+            const uint32_t op = (uint32_t)__shfl_xor((int)pos, o, 64);
+            const unsigned long long e = ((unsigned long long)hi << 32) | lo;
+            if (MAX ? e > best : e < best) {
+                best = e;
+                pos = op;
+            }
+        }
+        pos = uni(pos);
+        dd = unif(d[pos]);
+        idv = uni(id[pos]);
+        return pos;
+    }
+    __device__ __forceinline__ void remove(uint32_t pos) { // order does not matter: the last entry fills the hole
+        if (kdb_lane() == 0) {
+            d[pos] = d[count - 1];
+            id[pos] = id[count - 1];
+        }
+        count--;
+        wave_lds_fence();
+    }
+    // worst / full: the result set's current worst distance and whether it holds ef entries
+    __device__ __forceinline__ void push(float dd, uint32_t idv, float worst, bool full) {
+        if (count == cap) {
+            if (full) { // discard what can never be expanded any more
+                const uint32_t lane = (uint32_t)kdb_lane();
+                uint32_t w = 0;
+                for (uint32_t base = 0; base < count; base += 64) {
+                    const uint32_t i = base + lane;
+                    float e = 0.f;
+                    uint32_t x = 0;
+                    const bool keep = i < count && (e = d[i], x = id[i], !(e > worst));
+                    const unsigned long long m = __ballot(keep);
+                    wave_lds_fence();
+                    if (keep) {
+                        d[w + kdb_mbcnt(m)] = e;
+                        id[w + kdb_mbcnt(m)] = x;
+                    }
+                    w += (uint32_t)__builtin_popcountll(m);
+                    wave_lds_fence();
+                }
+                count = w;
+            }
+            if (count == cap) { // still full: the farthest pending candidate goes (not the reference's walk any more)
+                dropped++;
+                if (cap == 0) return;
+                float md;
+                uint32_t mid;
+                const uint32_t mp = extreme<true>(md, mid);
+                if (!(dd < md || (dd == md && idv < mid))) return;
+                remove(mp);
+            }
+        }
+        if (kdb_lane() == 0) {
+            d[count] = dd;
+            id[count] = idv;
+        }
+        count++;
+        wave_lds_fence();
+    }
+};
+
 struct QCtr {
-    uint32_t n_dist, n_hops;
+    uint32_t n_dist, n_hops, n_dropped;
 };
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
@@ -652,6 +659,8 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr) {
     const int lane = kdb_lane();
     b.reset(ef);
+    NrList nr;
+    nr.bind(s);
     vis.begin_layer(level > 0);
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     if (lane == 0) s.nb_id[0] = ep;
@@ -660,23 +669,47 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
     ctr.n_dist++;
     {
         (void)vis.test_and_set(ep, lane == 0);
-        bool nr = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
-        if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) nr = true;
-        b.insert(unif(s.nb_d[0]), ep | (nr ? KDB_F_NORESULT : 0u));
-        if (nr) b.n_nr++; else b.n_res++;
-        b.trim(ef);
+        bool no_result = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
+        if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) no_result = true;
+        if (no_result) {
+            nr.push(unif(s.nb_d[0]), ep, INFINITY, false);
+        } else {
+            b.insert(unif(s.nb_d[0]), ep);
+            b.n_res++;
+            b.trim(ef);
+        }
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
     for (;;) {
+        // heap_pop(candidates): the nearest un-expanded beam entry or the nearest traversal-only candidate
         const int idx = b.next();
-        if (idx < 0) break;
-        float cur_d;
-        uint32_t cur_f;
-        b.get((uint32_t)idx, cur_d, cur_f);
-        const uint32_t cur = cur_f & KDB_ID_MASK;
-        if (b.n_res >= ef && cur_d > b.worst) break; // :2501-2506 (never true after trimming; kept for clarity)
-        b.mark_expanded((uint32_t)idx);
-        b.scan_from = (uint32_t)idx + 1;
+        float cur_d = INFINITY;
+        uint32_t cur = 0;
+        if (idx >= 0) {
+            uint32_t cur_f;
+            b.get((uint32_t)idx, cur_d, cur_f);
+            cur = cur_f & KDB_ID_MASK;
+        }
+        bool from_nr = false;
+        uint32_t nr_pos = 0;
+        if (nr.count) { // wave-uniform; only indexes with deleted nodes (or a filtered-out entry point) get here
+            float nd;
+            uint32_t nid;
+            nr_pos = nr.extreme<false>(nd, nid);
+            if (idx < 0 || nd < cur_d || (nd == cur_d && nid < cur)) {
+                from_nr = true;
+                cur_d = nd;
+                cur = nid;
+            }
+        }
+        if (idx < 0 && !from_nr) break;
+        if (b.n_res >= ef && cur_d > b.worst) break; // :2501-2506 (only a traversal-only candidate can be this far)
+        if (from_nr) {
+            nr.remove(nr_pos);
+        } else {
+            b.mark_expanded((uint32_t)idx);
+            b.scan_from = (uint32_t)idx + 1;
+        }
         if (level > 0 && (int)v.levels[cur] < level) continue; // :2524-2527 node lacks this level
         ctr.n_hops++;
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
@@ -706,12 +739,16 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
             const float d = readlane_f(my_d, j);
             if (!(b.n_res < ef || d < b.worst)) continue;
             const uint32_t id = readlane_u(my_id, j);
-            const bool nr = readlane_u((uint32_t)my_nr, j) != 0;
-            b.insert(d, id | (nr ? KDB_F_NORESULT : 0u));
-            if (nr) b.n_nr++; else b.n_res++;
-            b.trim(ef);
+            if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
+                nr.push(d, id, b.worst, b.n_res >= ef);
+            } else {
+                b.insert(d, id);
+                b.n_res++;
+                b.trim(ef);
+            }
         }
     }
+    ctr.n_dropped += nr.dropped;
     vis.end_layer();
 }
 
@@ -722,9 +759,9 @@ __host__ __device__ inline uint32_t kdb_vis_hash_size(uint32_t ef) {
     return 0;
 }
 
-// beam slots needed for ef (>= 16 traversal-only entries of slack); 0 = use the LDS beam
+// beam slots needed for ef (ef results + the one inserted before trimming); 0 = use the LDS beam
 __host__ __device__ inline int kdb_beam_slots(uint32_t ef) {
-    const uint32_t need = ef + 2 + 16;
+    const uint32_t need = ef + 2;
     if (need <= 128) return 2;
     if (need <= 256) return 4;
     if (need <= 384) return 6;

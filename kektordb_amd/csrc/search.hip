@@ -3,9 +3,10 @@
 // Follows pkg/core/hnsw/hnsw_index.go:369-468 (searchInternal) and :2351-2611
 // (searchLayerUnlocked) of the reference, re-designed for CDNA4:
 //   * the reference's two binary heaps (hnsw_heap.go) become ONE distance-sorted beam array, in registers (one entry per
-//     lane and slot) for ef <= 366, in LDS beyond; pop-min = first un-expanded entry, result set = the array itself.
+//     lane and slot) for ef <= 382, in LDS beyond; pop-min = first un-expanded entry, result set = the array itself.
 //     With distinct distances this yields exactly the reference's traversal (same expansions, same n_dist / n_hops,
-//     same results); equal distances are ordered by id instead of by heap history;
+//     same results); equal distances are ordered by id instead of by heap history.  Candidates that never become
+//     results (soft-deleted nodes, a filtered-out entry point) wait in an unsorted LDS side list (NrList);
 //   * each hop evaluates the <=32 neighbour rows as a tile: 16 lanes per row, up to 12 rows (three per 16-lane group)
 //     per HBM round trip, 16-byte coalesced loads straight to VGPRs (rows are streamed once, never staged), the query
 //     stays in LDS, a DPP row reduction finishes each distance;
@@ -50,7 +51,7 @@ template <int PREC, int METRIC, int NCH, int BS, int VIS>
 __global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
-                   uint32_t beam_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
+                   uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
                    unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
                    uint32_t *tr_ndist, uint32_t *tr_nhops) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,11 +67,16 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
+    s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
+    off += (size_t)nr_cap * 4;
+    s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += (size_t)nr_cap * 4;
+    s.nr_cap = nr_cap;
     s.marks = reinterpret_cast<uint32_t *>(smem + off); // VIS=0: un-mark list; VIS=1: the hash table
     s.beam_cap = beam_cap;
 
     const int lane = kdb_lane();
-    unsigned long long tot_dist = 0, tot_hops = 0;
+    unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
     typename BeamSel<BS>::type b;
     b.bind(s);
     typename VisSel<VIS>::type vis;
@@ -145,7 +151,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         __threadfence_block();
         wave_lds_fence();
 
-        QCtr ctr{0, 0};
+        QCtr ctr{0, 0, 0};
         // the query's allow list and entry point: one list for the whole batch, or its own (heterogeneous batch)
         const uint32_t *q_allow = allow;
         uint32_t ep = entry;
@@ -173,7 +179,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         uint32_t nout = 0;
         if (!failed) {
             search_layer<PREC, METRIC, NCH>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
-            // results = non traversal-only entries, ascending (:2596-2610), first k
+            // results, ascending (:2596-2610), first k
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
                                    PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
         }
@@ -188,11 +194,13 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
+        tot_dropped += ctr.n_dropped;
         wave_lds_fence();
     }
     if (lane == 0 && gctr) {
         atomicAdd(&gctr[0], tot_dist);
         atomicAdd(&gctr[1], tot_hops);
+        if (tot_dropped) atomicAdd(&gctr[3], tot_dropped);
     }
 }
 
@@ -212,6 +220,9 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.beam_d = nullptr;
     s.beam_id = nullptr;
     s.marks = nullptr;
+    s.nr_d = nullptr;
+    s.nr_id = nullptr;
+    s.nr_cap = 0;
     const int lane = kdb_lane();
     const uint32_t chunks = (C + 31) / 32;
     const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -492,10 +503,13 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
                             float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                             hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef; // ef = max(efSearch, k) (:2377-2380)
-    // LDS beam (BS == 0): room for ef results plus as many traversal-only (deleted) entries
-    const uint32_t beam_cap = ((2 * eff + 66) + 63) / 64 * 64;
+    const uint32_t beam_cap = ((eff + 2) + 63) / 64 * 64; // LDS beam (BS == 0)
+    // traversal-only candidates (NrList): a walk can never hold more of them than the index has deleted nodes (+ the
+    // entry point when a filter excludes it), so up to 2047 deleted nodes the list cannot overflow; beyond that it
+    // holds the 2048 nearest pending ones and counts what it had to drop (kdb_counters.n_dropped)
+    const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8;
+    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8 + (size_t)nr_cap * 8;
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
     const uint32_t hsize = (BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
@@ -517,7 +531,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, vis_size,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));

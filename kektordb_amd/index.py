@@ -274,13 +274,13 @@ class HipIndex:
         c = _lib.Counters()
         check(self.L.kdb_get_counters(self.h, C.byref(c)), "get_counters")
         return {"n_dist": int(c.n_dist), "n_hops": int(c.n_hops), "bytes": int(c.bytes),
-                "kernel_ms": float(c.last_kernel_ms)}
+                "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped)}
 
     def launch_stats(self, last_n: int):
         arr = (_lib.Counters * last_n)()
         check(self.L.kdb_get_launch_stats(self.h, last_n, arr), "get_launch_stats")
         return [{"n_dist": int(c.n_dist), "n_hops": int(c.n_hops), "bytes": int(c.bytes),
-                 "kernel_ms": float(c.last_kernel_ms)} for c in arr]
+                 "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped)} for c in arr]
 
     def sync(self):
         check(self.L.kdb_index_sync(self.h), "sync")

@@ -437,6 +437,38 @@ def test_search_beam_and_visited_variants(oracle, hip, ef):
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
+@pytest.mark.parametrize("frac", [0.5, 0.9])
+@pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1)])
+def test_search_mostly_deleted_index(oracle, hip, metric, prec, frac):
+    """Soft-deleted nodes stay on the candidate heap and are traversed but never returned (hnsw_index.go:2583-2590).
+    With half or nine tenths of the index deleted, hundreds of such candidates wait at once: they live in an unsorted
+    side list next to the beam (NrList) and pop in (distance, id) order with the beam's entries.  ids, distance bits
+    and the per-query n_dist / n_hops are the oracle's, nothing was dropped.  (tests/tools/fuzz_search.py found the
+    previous 63-entry bound.)"""
+    O = oracle
+    n, dim = 3000, 48
+    X = make_corpus(n, dim, "normal", seed=33)
+    rng = np.random.default_rng(34)
+    deleted = (rng.choice(n, size=int(n * frac), replace=False) + 1).tolist()
+    orc, idx = build_pair(O, hip, X, metric, precision=prec, m=8, efc=40, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(20, dim, "normal", seed=35)
+    from kektordb_amd.index import dense_bitset
+    allowed = np.nonzero(rng.random(n + 1) < 0.6)[0]
+    ab = dense_bitset(allowed[allowed >= 1], n)
+    for k, ef, allow in ((10, 64, None), (1, 111, None), (50, 300, None), (10, 64, ab), (10, 600, ab)):
+        ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, allow_bits=allow, trace=True)
+        assert idx.launch_stats(1)[0]["n_dropped"] == 0
+        for b in range(Q.shape[0]):
+            oi, od, (ond, onh) = orc.search(Q[b], k, allow=allow, ef=ef, counters=True)
+            c = int(cnt[b])
+            assert c == len(oi), (k, ef, b)
+            assert np.array_equal(ids[b, :c], oi), (k, ef, b)
+            assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (k, ef, b)
+            assert (int(nd[b]), int(nh[b])) == (ond, onh), (k, ef, b)
+            assert not (set(ids[b, :c].tolist()) & set(deleted))
+
+
 def test_concurrent_search_delete_and_scan(oracle, hip):
     """Several caller threads on ONE handle (cgo calls arrive on any OS thread; the reference stresses the same with
     TestConcurrencyChaos / TestDeleteWhileSearching, hnsw_stress_test.go:110-114): searches, exact scans and soft

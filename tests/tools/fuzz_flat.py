@@ -1,6 +1,6 @@
 """Randomised parity sweep of the exact scan against the oracle (checker-side tool: uses oracle/).  Random shapes,
 metrics, precisions, batch sizes (small-batch, tile and grouped kernels), filters, deletions, near-duplicate blocks.
-    python tests/tools/fuzz_flat.py [n_cases] [seed] [only_case]"""
+    python tests/tools/fuzz_flat.py [n_cases] [seed] [only_case|-] [wide]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,8 @@ import kektordb_amd as K
 from kektordb_amd.index import dense_bitset
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-only = int(sys.argv[3]) if len(sys.argv) > 3 else None  # replay one case of a sweep, with details
+only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+wide = len(sys.argv) > 4 and sys.argv[4] == "wide"  # replay one case of a sweep, with details
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 def i8_ids_ok(got, want, want_d):
@@ -21,12 +22,17 @@ def i8_ids_ok(got, want, want_d):
 for case in range(n_cases):
     prec = int(rng.choice([O.F32, O.F32, O.F32, O.F16, O.I8]))
     metric = 0 if prec == O.F16 else 1 if prec == O.I8 else int(rng.integers(0, 2))
-    n = int(rng.choice([300, 900, 2500, 7000])); dim = int(rng.choice([16, 40, 100, 128, 260, 768]))
-    k = int(rng.choice([1, 5, 10, 37, 100])); B = int(rng.choice([1, 3, 16, 17, 60, 65, 130, 300]))
-    X = rng.standard_normal((n, dim)).astype(np.float32) * float(rng.choice([0.2, 1.0, 3.0]))
-    if rng.random() < 0.3:  # a block of near duplicates
+    if wide:  # corner shapes: tiny / odd widths, one-row and many-stripe corpora, the largest k, extreme magnitudes
+        n = int(rng.choice([1, 5, 130, 2500, 30000])); dim = int(rng.choice([1, 3, 7, 33, 128, 1000]))
+        k = int(rng.choice([1, 10, 128])); B = int(rng.choice([1, 16, 65, 400]))
+        X = rng.standard_normal((n, dim)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 50.0, 1e3]))
+    else:
+        n = int(rng.choice([300, 900, 2500, 7000])); dim = int(rng.choice([16, 40, 100, 128, 260, 768]))
+        k = int(rng.choice([1, 5, 10, 37, 100])); B = int(rng.choice([1, 3, 16, 17, 60, 65, 130, 300]))
+        X = rng.standard_normal((n, dim)).astype(np.float32) * float(rng.choice([0.2, 1.0, 3.0]))
+    if n > 60 and rng.random() < 0.3:  # a block of near duplicates
         a = int(rng.integers(0, n - 50)); X[a:a + 50] = X[a] + 1e-4 * rng.standard_normal((50, dim)).astype(np.float32)
-    dele = rng.choice(n, size=int(rng.integers(0, 20)), replace=False) + 1
+    dele = rng.choice(n, size=int(rng.integers(0, min(20, n))), replace=False) + 1
     Q = (X[rng.integers(0, n, B)] + 0.1 * rng.standard_normal((B, dim))).astype(np.float32)
     allow = None
     if rng.random() < 0.5:

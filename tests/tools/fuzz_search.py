@@ -1,7 +1,7 @@
 """Randomised parity sweep of the graph search against the oracle (checker-side tool: uses oracle/): random shapes,
 metrics, precisions, k, ef (register / LDS beams, LDS hash / HBM bitset), allow lists (one per batch, one per query),
 deletions; ids, distance bits and per-query n_dist / n_hops must match.
-    python tests/tools/fuzz_search.py [n_cases] [seed] [only_case]"""
+    python tests/tools/fuzz_search.py [n_cases] [seed] [only_case|-] [wide]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,17 +11,23 @@ import kektordb_amd as K
 from kektordb_amd.index import dense_bitset
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(n_cases):
     prec = int(rng.choice([O.F32, O.F32, O.F32, O.F16, O.I8]))
     metric = 0 if prec == O.F16 else 1 if prec == O.I8 else int(rng.integers(0, 2))
-    n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 384, 768]))
-    k = int(rng.choice([1, 10, 50])); ef = int(rng.choice([0, 5, 40, 120, 300, 500])); B = int(rng.choice([1, 7, 40]))
+    if wide:  # corner shapes: tiny / odd widths, tiny graphs, k > n, very large ef, most of the nodes deleted
+        n = int(rng.choice([1, 2, 9, 300, 3000])); dim = int(rng.choice([1, 3, 7, 33, 128, 1000]))
+        k = int(rng.choice([1, 10, 200])); ef = int(rng.choice([0, 1, 64, 110, 111, 400, 2000])); B = int(rng.choice([1, 5, 70]))
+    else:
+        n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 384, 768]))
+        k = int(rng.choice([1, 10, 50])); ef = int(rng.choice([0, 5, 40, 120, 300, 500])); B = int(rng.choice([1, 7, 40]))
     X = rng.random((n, dim), dtype=np.float32) if rng.random() < 0.5 else rng.standard_normal((n, dim)).astype(np.float32)
     m_, seed_ = int(rng.choice([4, 8, 16])), int(rng.integers(1, 99))
-    dele = rng.choice(n, size=int(rng.integers(0, 30)), replace=False) + 1
+    n_del = int(rng.integers(0, min(30, n))) if not wide else int(n * float(rng.choice([0.0, 0.1, 0.5, 0.9])))
+    dele = rng.choice(n, size=n_del, replace=False) + 1
     Q = (X[rng.integers(0, n, B)] + 0.05 * rng.standard_normal((B, dim))).astype(np.float32)
     mode = int(rng.integers(0, 3))  # 0 no filter, 1 one list, 2 one list per query
     lists = [dense_bitset((lambda a: a[a >= 1])(np.nonzero(rng.random(n + 1) < s)[0]), n) for s in (0.6, 0.15, 0.02)]
@@ -73,7 +79,7 @@ for case in range(n_cases):
         ok &= bool(good)
         if only is not None and not good:
             print("  q", b, "got", ids[b, :c], got_d, None if nd is None else (int(nd[b]), int(nh[b])), "want", wi, wd, (ond, onh))
-    print(f"case {case}: prec={prec} metric={metric} n={n} dim={dim} m={orc.m} k={k} ef={ef} B={B} mode={mode} tie-queries={ties} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: ndel={n_del} prec={prec} metric={metric} n={n} dim={dim} m={orc.m} k={k} ef={ef} B={B} mode={mode} tie-queries={ties} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
     del idx
 print("mismatching cases:", bad)
