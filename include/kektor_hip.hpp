@@ -5,13 +5,20 @@
 //   SearchWithScores(query, k, allowList, efSearch) -> []SearchResult   (hnsw_index.go:343-366,
 //                                                                        core.VectorIndex, vector_index.go:35)
 //   Delete(ids), Close(), Metric(), Precision()
-// plus the batch entry points the shim's micro-batcher calls.  Errors of the search path are swallowed
+// plus the batch entry points the shim's micro-batcher calls, and that micro-batcher itself (MicroBatcher).  Errors of the search path are swallowed
 // to an empty result exactly like the reference (":356-359 slog.Error + empty slice"); everything else
 // throws kektor::Error carrying kdb_last_error().
 #pragma once
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "kektor_hip.h"
@@ -127,6 +134,13 @@ class Index {
         return out;
     }
     kdb_index *handle() const { return h_; }
+    uint32_t Dim() const { return dim_; }
+    uint32_t Count() const { // nodeCounter of the mirror
+        uint32_t count = 0, entry = 0;
+        int32_t maxLevel = -1;
+        if (!h_ || kdb_index_graph_info(h_, &count, &entry, &maxLevel)) return 0;
+        return count;
+    }
 
   private:
     // the reference's f64 epilogue: float64(sum) (distance_go.go:67) / 1.0 - float64(dot) (:127)
@@ -140,6 +154,123 @@ class Index {
     kdb_index *h_ = nullptr;
     uint32_t dim_, metric_, precision_;
     bool needsRefine_ = false;
+};
+
+// MicroBatcher -- turns concurrent one-query callers into GPU batches (the compiled counterpart of
+// the Go shim's hipBatcher, integration/go/hnsw_hip.go).  SearchWithScores keeps the contract of
+// hnsw.Index.SearchWithScores (hnsw_index.go:343-366): it blocks until the caller's answer is ready and returns an
+// empty slice on any error, on a stopped batcher and for a non-nil empty allow list.
+//   * callers that share (k, efSearch, allow-list object) share a group; the first caller of a group is its leader:
+//     it waits `window` for company (or until `maxBatch` callers joined), runs ONE kdb_search_batch for the group and
+//     hands every caller its slice -- no service thread, no timer thread;
+//   * a filter that allows less than `flatScanSelectivity` of the ids takes the exact scan: the reference's filtered
+//     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there.
+class MicroBatcher {
+  public:
+    struct Options {
+        uint32_t maxBatch = 8192;                     // queries per GPU call
+        std::chrono::microseconds window{150};        // how long a group's first caller waits for company
+        double flatScanSelectivity = 0.05;
+    };
+    struct Stats {
+        uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
+    };
+    explicit MicroBatcher(Index &idx) : idx_(idx) {}
+    MicroBatcher(Index &idx, const Options &o) : idx_(idx), opt_(o) {}
+    ~MicroBatcher() { Stop(); }
+    MicroBatcher(const MicroBatcher &) = delete;
+    MicroBatcher &operator=(const MicroBatcher &) = delete;
+
+    // pending callers and every later call get []
+    void Stop() {
+        std::lock_guard<std::mutex> lk(mu_);
+        closed_ = true;
+        for (auto &kv : groups_) kv.second->cv.notify_all();
+    }
+    Stats stats() const {
+        std::lock_guard<std::mutex> lk(mu_);
+        return stats_;
+    }
+
+    std::vector<SearchResult> SearchWithScores(const std::vector<float> &query, int k, const AllowList *allowList, int efSearch) {
+        if (k <= 0 || query.size() != idx_.Dim()) return {};
+        std::unique_lock<std::mutex> lk(mu_);
+        if (closed_) return {};
+        stats_.calls++;
+        const Key key{k, efSearch, allowList};
+        std::shared_ptr<Group> g;
+        auto it = groups_.find(key);
+        const bool leader = it == groups_.end();
+        if (leader) {
+            g = std::make_shared<Group>();
+            groups_[key] = g;
+        } else {
+            g = it->second;
+        }
+        const size_t me = g->queries.size();
+        g->queries.push_back(query.data());
+        if (g->queries.size() >= opt_.maxBatch) { // full: later callers start the next group
+            groups_.erase(key);
+            g->sealed = true;
+            g->cv.notify_all();
+        }
+        if (!leader) {
+            g->cv.wait(lk, [&] { return g->done; });
+            return me < g->results.size() ? std::move(g->results[me]) : std::vector<SearchResult>();
+        }
+        g->cv.wait_for(lk, opt_.window, [&] { return g->sealed || closed_; });
+        if (!g->sealed) {
+            auto cur = groups_.find(key);
+            if (cur != groups_.end() && cur->second == g) groups_.erase(cur);
+            g->sealed = true;
+        }
+        const bool stopped = closed_;
+        const uint32_t B = (uint32_t)g->queries.size(); // nobody can join a sealed group
+        lk.unlock();
+        std::vector<std::vector<SearchResult>> out;
+        bool flat = false;
+        if (!stopped) {
+            const uint32_t dim = idx_.Dim();
+            std::vector<float> Q((size_t)B * dim);
+            for (uint32_t b = 0; b < B; b++) std::memcpy(Q.data() + (size_t)b * dim, g->queries[b], (size_t)dim * 4);
+            if (allowList) {
+                uint64_t allowed = 0;
+                for (uint64_t w : allowList->words) allowed += (uint64_t)__builtin_popcountll(w);
+                const uint32_t count = idx_.Count();
+                flat = allowed > 0 && count > 0 && (double)allowed < opt_.flatScanSelectivity * (double)count;
+            }
+            try {
+                out = flat ? idx_.FlatScanBatch(Q.data(), B, k, allowList) : idx_.SearchBatch(Q.data(), B, k, allowList, efSearch);
+            } catch (const Error &) { // ":356-359": log and return []
+                out.clear();
+            }
+        }
+        lk.lock();
+        stats_.batches++;
+        if (flat) stats_.flatBatches++;
+        if (B > stats_.largest) stats_.largest = B;
+        g->results = std::move(out);
+        g->results.resize(B);
+        g->done = true;
+        std::vector<SearchResult> mine = std::move(g->results[me]);
+        g->cv.notify_all();
+        return mine;
+    }
+
+  private:
+    using Key = std::tuple<int, int, const AllowList *>;
+    struct Group {
+        std::vector<const float *> queries; // callers' buffers: they are blocked in SearchWithScores until done
+        std::vector<std::vector<SearchResult>> results;
+        bool sealed = false, done = false;
+        std::condition_variable cv;
+    };
+    Index &idx_;
+    Options opt_;
+    mutable std::mutex mu_;
+    std::map<Key, std::shared_ptr<Group>> groups_;
+    bool closed_ = false;
+    Stats stats_;
 };
 
 } // namespace hnsw

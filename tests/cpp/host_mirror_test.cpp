@@ -1,9 +1,11 @@
 // Exercises include/kektor_hip.hpp the way the reference's own tests exercise hnsw.Index
 // (pkg/client/client_test.go:171-236: a stored vector ranks itself first at efSearch 12 and 100;
 //  hnsw_stress_test.go:110-114: len(results) <= k).  Exit code 0 = pass, 77 = no GPU (skipped).
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "kektor_hip.hpp"
@@ -53,6 +55,43 @@ int main() {
     // exact scan agrees with the graph search on the self match
     auto fs = idx.FlatScanBatch(X.data() + dim, 1, 3, nullptr);
     if (fs[0].empty() || fs[0][0].DocID != 2 || fs[0][0].Score != 0.0) bad++;
+    // micro-batcher: 32 threads x 40 one-query calls (hnsw_stress_test.go's concurrent readers); every answer equals
+    // the direct one-query call, callers were coalesced into far fewer GPU calls, a selective filter took the exact scan
+    {
+        kektor::hnsw::MicroBatcher::Options o;
+        o.window = std::chrono::microseconds(2000);
+        o.maxBatch = 64;
+        kektor::hnsw::MicroBatcher mb(idx, o);
+        kektor::AllowList few(n); // 2 % of the ids: below the routing threshold
+        for (uint32_t id = 50; id <= n; id += 50) few.Add(id);
+        std::atomic<int> wrong{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 32; t++)
+            th.emplace_back([&, t] {
+                for (int it = 0; it < 40; it++) {
+                    const uint32_t i = (uint32_t)((t * 40 + it) % 500) + 1; // row i (id i+1)
+                    std::vector<float> qq(X.begin() + (size_t)i * dim, X.begin() + (size_t)(i + 1) * dim);
+                    const kektor::AllowList *al = (it % 4 == 1) ? &allow : (it % 4 == 3) ? &few : nullptr;
+                    const int ef = (it % 2) ? 50 : 12;
+                    auto got = mb.SearchWithScores(qq, (int)k, al, ef);
+                    auto want = al == &few ? idx.FlatScanBatch(qq.data(), 1, (int)k, al)[0] : idx.SearchWithScores(qq, (int)k, al, ef);
+                    if (got.size() != want.size()) { wrong++; continue; }
+                    for (size_t j = 0; j < got.size(); j++)
+                        if (got[j].DocID != want[j].DocID || got[j].Score != want[j].Score) wrong++;
+                }
+            });
+        for (auto &x : th) x.join();
+        const auto st = mb.stats();
+        if (wrong.load()) bad += wrong.load();
+        if (st.calls != 32 * 40 || st.batches >= st.calls / 2 || st.largest < 2 || st.flatBatches == 0) {
+            std::printf("batcher stats: calls %llu batches %llu largest %llu flat %llu\n", (unsigned long long)st.calls,
+                        (unsigned long long)st.batches, (unsigned long long)st.largest, (unsigned long long)st.flatBatches);
+            bad++;
+        }
+        if (!mb.SearchWithScores(std::vector<float>(3, 0.f), 5, nullptr, 10).empty()) bad++; // wrong width -> []
+        mb.Stop();
+        if (!mb.SearchWithScores(q, 5, nullptr, 10).empty()) bad++; // stopped batcher -> []
+    }
     idx.Close();
     if (!idx.SearchWithScores(q, 10, nullptr, 50).empty()) bad++; // closed index returns []
     std::printf(bad ? "FAIL %d\n" : "ok\n", bad);

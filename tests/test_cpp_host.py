@@ -16,7 +16,7 @@ def build_exe(tmp_path):
     libdir = os.path.dirname(kektordb_amd.LIB_PATH)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"), "-L", libdir, "-lkektor_hip",
-           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     return exe
