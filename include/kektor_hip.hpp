@@ -161,8 +161,9 @@ class Index {
 // hnsw.Index.SearchWithScores (hnsw_index.go:343-366): it blocks until the caller's answer is ready and returns an
 // empty slice on any error, on a stopped batcher and for a non-nil empty allow list.
 //   * callers that share (k, efSearch, allow-list object) share a group; the first caller of a group is its leader:
-//     it waits `window` for company (or until `maxBatch` callers joined), runs ONE kdb_search_batch for the group and
-//     hands every caller its slice -- no service thread, no timer thread;
+//     it waits `window` for company (or until `maxBatch` callers joined), then for its turn on the device -- the group
+//     stays open while the previous group's call runs, so batches grow with the load -- runs ONE kdb_search_batch for
+//     the group and hands every caller its slice; no service thread, no timer thread;
 //   * a filter that allows less than `flatScanSelectivity` of the ids takes the exact scan: the reference's filtered
 //     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there.
 class MicroBatcher {
@@ -219,6 +220,11 @@ class MicroBatcher {
             return me < g->results.size() ? std::move(g->results[me]) : std::vector<SearchResult>();
         }
         g->cv.wait_for(lk, opt_.window, [&] { return g->sealed || closed_; });
+        // one GPU call at a time: while the previous group's call runs, this group stays open and keeps growing
+        // (batch size adapts to the load: everything that arrived during one call goes into the next)
+        lk.unlock();
+        std::unique_lock<std::mutex> turn(exec_mu_);
+        lk.lock();
         if (!g->sealed) {
             auto cur = groups_.find(key);
             if (cur != groups_.end() && cur->second == g) groups_.erase(cur);
@@ -268,6 +274,7 @@ class MicroBatcher {
     Index &idx_;
     Options opt_;
     mutable std::mutex mu_;
+    std::mutex exec_mu_; // taken before mu_, never while holding it
     std::map<Key, std::shared_ptr<Group>> groups_;
     bool closed_ = false;
     Stats stats_;
