@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef with recall@k >= --recall")
     ap.add_argument("--recall", type=float, default=0.95)
     ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--build-batch", type=int, default=16384, help="nodes inserted per round of the GPU builder")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all hardware threads")
     ap.add_argument("--no-cpu", action="store_true")
@@ -131,7 +132,7 @@ def main():
     idx.upload_rows(X, 1)
     del X
     t0 = time.time()
-    idx.build(n, batch=16384, ef_construction=a.efc, seed=1 + rank)     # GPU batched construction
+    idx.build(n, batch=a.build_batch, ef_construction=a.efc, seed=1 + rank)     # GPU batched construction
     t_build = time.time() - t0
     sh = ShardedSearch(K.COSINE, K.F32, id_base=rank * n, hip_index=idx, force_exchange=a.force_exchange)
     log(f"[bench] rank {rank}: corpus {t_gen:.1f}s, GPU graph build {t_build:.1f}s")
@@ -158,7 +159,7 @@ def main():
     sweep = {}
     ef = a.ef
     if ef == 0:
-        for cand in (24, 32, 40, 48, 64, 80, 96, 128, 160, 200, 256, 384, 512, 768, 1024, 2048):
+        for cand in (24, 32, 40, 48, 52, 56, 60, 64, 80, 96, 128, 160, 200, 256, 384, 512, 768, 1024, 2048):
             run_step(cand)
             torch.cuda.synchronize()
             r = recall_at_k(out_ids.cpu().numpy().view(np.uint32), gt, k)
