@@ -144,6 +144,53 @@ __device__ __forceinline__ void kdb_row_partialR_f32(const float *const (&rows)[
     for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
 }
 
+// R rows at once for ANY width (ld floats = npieces 16-byte pieces, known only at run time): the rows are walked in
+// blocks of U pieces per lane, R*U loads in flight per block; per row the accumulation order is that of
+// kdb_row_partial_f32 (lane t: pieces t, t+16, ... in order; a lane past the end of a ragged last block sits out).
+// Row widths without an unrolled instantiation used to take one row per group and 4 pieces per round trip: 256-d
+// 1.75x, 512-d 2.4x slower than their unrolled variants.
+template <int METRIC, int R, int U>
+__device__ __forceinline__ void kdb_row_partialR_f32_dyn(const float *const (&rows)[R], const float *q, uint32_t npieces, int t,
+                                                         float (&p)[R]) {
+    const float4 *q4 = reinterpret_cast<const float4 *>(q);
+    float a[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r][0] = a[r][1] = a[r][2] = a[r][3] = 0.f;
+    for (uint32_t c0 = (uint32_t)t; c0 < npieces + (uint32_t)t; c0 += 16u * U) { // same trip count for every lane
+        float4 x[R][U];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + 16u * (uint32_t)u;
+                x[r][u] = c < npieces ? reinterpret_cast<const float4 *>(rows[r])[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = c0 + 16u * (uint32_t)u;
+            if (c >= npieces) continue;
+            const float4 y = q4[c];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (METRIC == KDB_METRIC_L2) {
+                    const float d0 = y.x - x[r][u].x, d1 = y.y - x[r][u].y, d2 = y.z - x[r][u].z, d3 = y.w - x[r][u].w;
+                    a[r][0] = __builtin_fmaf(d0, d0, a[r][0]);
+                    a[r][1] = __builtin_fmaf(d1, d1, a[r][1]);
+                    a[r][2] = __builtin_fmaf(d2, d2, a[r][2]);
+                    a[r][3] = __builtin_fmaf(d3, d3, a[r][3]);
+                } else {
+                    a[r][0] = __builtin_fmaf(y.x, x[r][u].x, a[r][0]);
+                    a[r][1] = __builtin_fmaf(y.y, x[r][u].y, a[r][1]);
+                    a[r][2] = __builtin_fmaf(y.z, x[r][u].z, a[r][2]);
+                    a[r][3] = __builtin_fmaf(y.w, x[r][u].w, a[r][3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
+}
+
 template <int METRIC, int NCH = 0>
 __device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ row, const float *q, uint32_t ld,
                                                      int t) {

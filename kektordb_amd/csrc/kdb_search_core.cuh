@@ -165,6 +165,30 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         wave_lds_fence();
         return;
     }
+    if constexpr (PREC == KDB_PREC_F32 && NCH == 0) { // any other width: 8 rows per pass, 8 pieces per lane and trip
+        constexpr int R = 2, U = 8;
+        {
+            for (uint32_t base = 0; base < n; base += 4u * R) {
+                const float *rows[R];
+                uint32_t rr[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
+                    const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                    rows[r] = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
+                }
+                float p[R];
+                kdb_row_partialR_f32_dyn<METRIC, R, U>(rows, s.q, v.ld >> 2, t, p);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p[r]));
+                    if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                }
+            }
+            wave_lds_fence();
+            return;
+        }
+    }
     for (uint32_t base = 0; base < n; base += 4) {
         const uint32_t r = base + (uint32_t)g;
         const bool act = r < n;

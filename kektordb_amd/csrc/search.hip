@@ -48,7 +48,7 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
@@ -565,10 +565,17 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
                       hipStream_t s) {
 #define KDB_ARGS idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, ma, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
     if (v.precision == KDB_PREC_F32) { // common row widths get fully unrolled row loads (NCH = ld/64)
+        static const bool force_generic = getenv("KDB_SEARCH_GENERIC") != nullptr; // measurement knob
+        if (force_generic) {
+            if (v.metric == KDB_METRIC_L2) return launch_search_t<KDB_PREC_F32, KDB_METRIC_L2, 0>(KDB_ARGS);
+            return launch_search_t<KDB_PREC_F32, KDB_METRIC_COSINE, 0>(KDB_ARGS);
+        }
 #define KDB_F32(M)                                                                            \
     switch (v.ld) {                                                                           \
     case 128: return launch_search_t<KDB_PREC_F32, M, 2>(KDB_ARGS);                           \
+    case 256: return launch_search_t<KDB_PREC_F32, M, 4>(KDB_ARGS);                           \
     case 384: return launch_search_t<KDB_PREC_F32, M, 6>(KDB_ARGS);                           \
+    case 512: return launch_search_t<KDB_PREC_F32, M, 8>(KDB_ARGS);                           \
     case 768: return launch_search_t<KDB_PREC_F32, M, 12>(KDB_ARGS);                          \
     case 1024: return launch_search_t<KDB_PREC_F32, M, 16>(KDB_ARGS);                         \
     case 1536: return launch_search_t<KDB_PREC_F32, M, 24>(KDB_ARGS);                         \

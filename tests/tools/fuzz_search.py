@@ -22,7 +22,7 @@ for case in range(n_cases):
         n = int(rng.choice([1, 2, 9, 300, 3000])); dim = int(rng.choice([1, 3, 7, 33, 128, 1000]))
         k = int(rng.choice([1, 10, 200])); ef = int(rng.choice([0, 1, 64, 110, 111, 400, 2000])); B = int(rng.choice([1, 5, 70]))
     else:
-        n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 384, 768]))
+        n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 256, 384, 512, 768]))
         k = int(rng.choice([1, 10, 50])); ef = int(rng.choice([0, 5, 40, 120, 300, 500])); B = int(rng.choice([1, 7, 40]))
     X = rng.random((n, dim), dtype=np.float32) if rng.random() < 0.5 else rng.standard_normal((n, dim)).astype(np.float32)
     m_, seed_ = int(rng.choice([4, 8, 16])), int(rng.integers(1, 99))
