@@ -301,6 +301,78 @@ __device__ __forceinline__ void kdb_row_partialR_f16(const uint16_t *const (&row
     for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
 }
 
+// R f16 rows at once for any width (npieces = ld/8 16-byte pieces): blocks of U pieces per lane, R*U loads in flight;
+// per row the accumulation order of kdb_row_partial_f16.
+template <int R, int U>
+__device__ __forceinline__ void kdb_row_partialR_f16_dyn(const uint16_t *const (&rows)[R], const float *q, uint32_t npieces, int t,
+                                                         float (&p)[R]) {
+    float a[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r][0] = a[r][1] = a[r][2] = a[r][3] = 0.f;
+    for (uint32_t c0 = (uint32_t)t; c0 < npieces + (uint32_t)t; c0 += 16u * U) {
+        uint4 xb[R][U];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + 16u * (uint32_t)u;
+                xb[r][u] = c < npieces ? reinterpret_cast<const uint4 *>(rows[r])[c] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = c0 + 16u * (uint32_t)u;
+            if (c >= npieces) continue;
+            const float4 *q4 = reinterpret_cast<const float4 *>(q + 8 * c);
+            const float4 y0 = q4[0], y1 = q4[1];
+            const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned w[4] = {xb[r][u].x, xb[r][u].y, xb[r][u].z, xb[r][u].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned short hb = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+                    const float x = (float)__builtin_bit_cast(_Float16, hb);
+                    const float d = yy[j] - x;
+                    a[r][j & 3] = __builtin_fmaf(d, d, a[r][j & 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = (a[r][0] + a[r][1]) + (a[r][2] + a[r][3]);
+}
+
+// R int8 rows at once for any width (npieces = ld/16): exact i32 dots, order irrelevant.
+template <int R, int U>
+__device__ __forceinline__ void kdb_row_partialR_i8_dyn(const int8_t *const (&rows)[R], const int8_t *q, uint32_t npieces, int t,
+                                                        int (&p)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; r++) p[r] = 0;
+    for (uint32_t c0 = (uint32_t)t; c0 < npieces + (uint32_t)t; c0 += 16u * U) {
+        int4 x[R][U];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + 16u * (uint32_t)u;
+                x[r][u] = c < npieces ? reinterpret_cast<const int4 *>(rows[r])[c] : make_int4(0, 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = c0 + 16u * (uint32_t)u;
+            if (c >= npieces) continue;
+            const int4 y = reinterpret_cast<const int4 *>(q)[c];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                p[r] = __builtin_amdgcn_sdot4(x[r][u].x, y.x, p[r], false);
+                p[r] = __builtin_amdgcn_sdot4(x[r][u].y, y.y, p[r], false);
+                p[r] = __builtin_amdgcn_sdot4(x[r][u].z, y.z, p[r], false);
+                p[r] = __builtin_amdgcn_sdot4(x[r][u].w, y.w, p[r], false);
+            }
+        }
+    }
+}
+
 // R int8 rows at once with ld == 256*NCHI: R*NCHI 16-byte loads in flight, exact i32 dots.
 template <int NCHI, int R>
 __device__ __forceinline__ void kdb_row_partialR_i8(const int8_t *const (&rows)[R], const int8_t *q, int t, int (&p)[R]) {

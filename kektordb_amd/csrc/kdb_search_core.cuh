@@ -165,6 +165,51 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         wave_lds_fence();
         return;
     }
+    if constexpr (PREC == KDB_PREC_F16 && NCH == 0) { // any other width: 8 rows per pass, 4 pieces per lane and trip
+        constexpr int R = 2, U = 4;
+        for (uint32_t base = 0; base < n; base += 4u * R) {
+            const uint16_t *rows[R];
+            uint32_t rr[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
+                const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                rows[r] = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld;
+            }
+            float p[R];
+            kdb_row_partialR_f16_dyn<R, U>(rows, s.q, v.ld >> 3, t, p);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float key = kdb_reduce16(p[r]);
+                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+            }
+        }
+        wave_lds_fence();
+        return;
+    }
+    if constexpr (PREC == KDB_PREC_I8 && NCH == 0) {
+        constexpr int R = 2, U = 4;
+        for (uint32_t base = 0; base < n; base += 4u * R) {
+            const int8_t *rows[R];
+            uint32_t rr[R], ids[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
+                ids[r] = rr[r] < n ? s.nb_id[rr[r]] : 0u;
+                rows[r] = reinterpret_cast<const int8_t *>(v.rows) + (size_t)ids[r] * v.ld;
+            }
+            int p[R];
+            kdb_row_partialR_i8_dyn<R, U>(rows, reinterpret_cast<const int8_t *>(s.q), v.ld >> 4, t, p);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int dot = kdb_reduce16_i(p[r]);
+                const float key = kdb_i8_distance(dot, qnorm, v.norms[ids[r]]);
+                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+            }
+        }
+        wave_lds_fence();
+        return;
+    }
     if constexpr (PREC == KDB_PREC_F32 && NCH == 0) { // any other width: 8 rows per pass, 8 pieces per lane and trip
         constexpr int R = 2, U = 8;
         {
