@@ -76,8 +76,8 @@ template <int PREC, int METRIC, int NCH = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
-    if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 12 && KDB_F32_DUAL) { // 4*R rows per round trip
-        constexpr int R = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : KDB_F32_ROWS;
+    if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 16 && KDB_F32_DUAL) { // 4*R rows per round trip
+        constexpr int R = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : NCH <= 12 ? KDB_F32_ROWS : 2;
         for (uint32_t base = 0; base < n;) {
             const uint32_t left = n - base;
             if (left > 4u * (R - 1) || R == 1) { // wave-uniform: a full-width trip
