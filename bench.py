@@ -54,7 +54,10 @@ def traffic_from_profile(n, dim, ef, B):
     cannot be run from inside the timed process); only reported when the profiled workload is this one."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        if t["workload"] == f"{n}x{dim} clustered ef={ef} batch {B}":
+        w = f"{n}x{dim} clustered ef={ef} batch {B}"
+        if w in t.get("workloads", {}):
+            return t["workloads"][w]["hbm_bytes_per_launch"]
+        if t.get("workload") == w:
             return t["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -76,7 +79,9 @@ def main():
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="rows per GPU shard")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8192, help="queries per step")
+    ap.add_argument("--batch", type=int, default=32768,
+                    help="queries per step (one wave walks one query: a launch ends with waves idling for up to one query's "
+                         "duration, 11 %% of an 8192-query launch, 3 %% of a 32768-query one)")
     ap.add_argument("--corpus", default="clustered", choices=["clustered", "iid"])
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef with recall@k >= --recall")
     ap.add_argument("--recall", type=float, default=0.95)

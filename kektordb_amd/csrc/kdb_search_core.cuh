@@ -346,6 +346,10 @@ struct RegBeam {
         count++;
         if (pos < scan_from) scan_from = pos;
     }
+    __device__ __forceinline__ void drop_last() { // heap_pop(results): the farthest result leaves
+        count--;
+        n_res--;
+    }
     // every entry is a result: n_res == count <= ef after trimming, the last entry is the worst
     __device__ __forceinline__ void trim(uint32_t ef) {
         if (n_res > ef) { // heap_pop(results): the farthest result leaves
@@ -467,6 +471,10 @@ struct LdsBeam {
         wave_lds_fence();
         count++;
         if (pos < scan_from) scan_from = pos;
+    }
+    __device__ __forceinline__ void drop_last() {
+        count--;
+        n_res--;
     }
     __device__ __forceinline__ void trim(uint32_t ef) {
         if (n_res > ef) {
@@ -811,6 +819,10 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
             if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
                 nr.push(d, id, b.worst, b.n_res >= ef);
             } else {
+                // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
+                // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
+                // (ef <= 64 stays inside one register slot: ef=64 ran 10 % slower than ef=60 before)
+                if (b.n_res >= ef) b.drop_last();
                 b.insert(d, id);
                 b.n_res++;
                 b.trim(ef);
@@ -828,9 +840,9 @@ __host__ __device__ inline uint32_t kdb_vis_hash_size(uint32_t ef) {
     return 0;
 }
 
-// beam slots needed for ef (ef results + the one inserted before trimming); 0 = use the LDS beam
+// beam slots needed for ef (the beam never holds more than ef entries); 0 = use the LDS beam
 __host__ __device__ inline int kdb_beam_slots(uint32_t ef) {
-    const uint32_t need = ef + 2;
+    const uint32_t need = ef;
     if (need <= 128) return 2;
     if (need <= 256) return 4;
     if (need <= 384) return 6;

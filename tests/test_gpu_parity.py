@@ -880,3 +880,34 @@ def test_flat_scan_rounding_band_rescue(oracle, hip, case, B):
             assert c == len(oi)
             assert np.array_equal(gi[b, :c], oi), (case, "grouped", b)
             assert np.array_equal(raw_to_score(idx, gd[b, :c]), od), (case, "grouped", b)
+
+
+@pytest.mark.parametrize("prec,metric", [(0, 1), (0, 0), (2, 1)])
+def test_flat_scan_batch_larger_than_one_launch(oracle, hip, prec, metric):
+    """more than 8192 queries run as several 8192-query launches (one launch is one round of 512 workgroups; longer
+    query lists push the stripes' rows out of L2): same answers, every query answered, padding rows untouched"""
+    O = oracle
+    n, dim, k, B = 1500, 32, 7, 8192 + 300
+    X = make_corpus(n, dim, "normal", seed=51)
+    orc = O.OracleIndex(dim, metric, prec, 8, 16, seed=3)
+    if prec == O.I8:
+        Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+        orc.set_absmax(float(np.quantile(np.abs(Xn), 0.999)))
+    orc.add_many(X)
+    idx = hip.HipIndex(dim, metric, prec, 8, 16, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    if prec == O.I8:
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(B, dim, "normal", seed=52)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    assert np.all(cnt == k)
+    for b in list(range(0, B, 97)) + [8191, 8192, 8193, B - 1]:
+        oi, od = orc.flat_scan(Q[b], k)
+        if prec == O.I8:
+            assert_same_results_tol(ids[b, :k], raw_to_score(idx, dist[b, :k]), oi, od)
+        else:
+            assert np.array_equal(ids[b, :k], oi), b
+            assert np.array_equal(raw_to_score(idx, dist[b, :k]), od), b
