@@ -263,18 +263,21 @@ def main():
         except Exception as e:  # never lose the GPU line
             log(f"[bench] cpu_baseline failed: {e!r}")
             res["cpu_baseline"] = None
+    # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (stdout being a pipe)
+    # would otherwise be flushed at exit, after Python's own output -- every rank empties its buffers first
+    def flush_all():
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    flush_all()
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (stdout being a pipe)
-    # would otherwise be flushed at exit, after Python's own output
-    sys.stdout.flush()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_all()
     if rank == 0:
         print(json.dumps(res), flush=True)
 
