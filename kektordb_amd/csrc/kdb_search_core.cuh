@@ -8,7 +8,7 @@
 // Two beam storages with the same interface:
 //   RegBeam<S>  entry i lives in lane i&63, register slot i>>6 (64*S entries).  Position search is a
 //               ballot + scalar popcount, the shift is a DPP wave_shr, reads are v_readlane: no LDS
-//               round trips on the hop's critical path.  Used for ef <= 382.
+//               round trips on the hop's critical path.  Used for ef <= 384.
 //   LdsBeam     arrays in LDS, any ef that fits LDS.
 #pragma once
 #include "kdb_device.cuh"

@@ -3,7 +3,7 @@
 // Follows pkg/core/hnsw/hnsw_index.go:369-468 (searchInternal) and :2351-2611
 // (searchLayerUnlocked) of the reference, re-designed for CDNA4:
 //   * the reference's two binary heaps (hnsw_heap.go) become ONE distance-sorted beam array, in registers (one entry per
-//     lane and slot) for ef <= 382, in LDS beyond; pop-min = first un-expanded entry, result set = the array itself.
+//     lane and slot) for ef <= 384, in LDS beyond; pop-min = first un-expanded entry, result set = the array itself.
 //     With distinct distances this yields exactly the reference's traversal (same expansions, same n_dist / n_hops,
 //     same results); equal distances are ordered by id instead of by heap history.  Candidates that never become
 //     results (soft-deleted nodes, a filtered-out entry point) wait in an unsorted LDS side list (NrList);
