@@ -33,6 +33,7 @@ constexpr int FS_LDS_STRIDE = 40;   // floats per LDS row (160 B)
 constexpr int FS_QPER = 16;         // survivor slots per query per round (per-query mini queues in LDS)
 constexpr int FS_LDS_KL = 16;       // running top-k lists live in LDS up to this length, else in HBM scratch
 constexpr uint32_t FS_MAX_MERGE = 16384; // entries one merge workgroup gathers in LDS (128 KB)
+constexpr uint32_t FS_FIN = 1024;        // finalists one merge workgroup can re-score exactly (band modes)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -871,7 +872,7 @@ __device__ __forceinline__ uint32_t fs_block_sum(uint32_t v, uint32_t *red /*[8]
 //   FM_KL     the kl = k+16 best keys (int8: integer dots are exact, keys differ from the final distance by one rounding)
 //   FM_BAND16 f16-ranked keys: everything inside the f16 error band of the k-th key; unsettled -> exact pass
 //   FM_ROUND  f32-accumulated keys (MFMA order, ||x||^2 - 2 q.x): everything inside the ROUNDING band of the k-th key;
-//             unsettled (more than 256 in the band, or a full stripe list reaching into it) -> rescue pass
+//             unsettled (more than 1024 in the band, or a full stripe list reaching into it) -> rescue pass
 //   FM_EXACT  lists written by the rescue pass: keys are already the final distances
 constexpr int FM_KL = 0, FM_BAND16 = 1, FM_EXACT = 2, FM_ROUND = 3;
 template <int METRIC, int PREC, int MODE>
@@ -880,9 +881,9 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
                   uint32_t nmax, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [nmax]
-    float *fin_d = reinterpret_cast<float *>(ent + nmax);                   // [256]
-    uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + 256);           // [256]
-    uint32_t *red = fin_id + 256;                                           // [8]
+    float *fin_d = reinterpret_cast<float *>(ent + nmax);                   // [FS_FIN]
+    uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + FS_FIN);        // [FS_FIN]
+    uint32_t *red = fin_id + FS_FIN;                                        // [8]
     uint32_t *ctl = red + 8;                                                // [4]: total, nfin
     uint32_t *hist = ctl + 4;                                               // [256] radix-select bins
     float *qlds = reinterpret_cast<float *>(hist + 256);                    // [ld]
@@ -1090,7 +1091,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const uint32_t n_band = fs_block_sum(c, red, tid, 0);
         const uint32_t n_sat = fs_block_sum(sat, red, tid, 1);
         __syncthreads();
-        if (n_band > 256u || n_sat) { // not settled here: the exact pass (rounding band: the rescue pass) answers this query
+        if (n_band > FS_FIN || n_sat) { // not settled here: the exact pass (rounding band: the rescue pass) answers this query
             if (tid == 0) {
                 if (MODE == FM_ROUND) {
                     p.rs_list[atomicAdd(p.rs_count, 1u)] = q;
@@ -1110,7 +1111,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const unsigned long long e = ent[i];
         if (e <= T) {
             const uint32_t pos = atomicAdd(&ctl[1], 1u);
-            if (pos < 256u) {
+            if (pos < FS_FIN) {
                 fin_d[pos] = fs_unpack_key(e);
                 fin_id[pos] = (uint32_t)(e & 0xffffffffu);
             }
@@ -1148,9 +1149,9 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         }
         __syncthreads();
     }
-    if ((uint32_t)tid < nf) { // rank by counting over the total order (distance key, id)
-        const float d = fin_d[tid];
-        const uint32_t id = fin_id[tid];
+    for (uint32_t e = (uint32_t)tid; e < nf; e += 256) { // rank by counting over the total order (distance key, id)
+        const float d = fin_d[e];
+        const uint32_t id = fin_id[e];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
         if (rank < k) {
@@ -1672,7 +1673,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
+    const size_t mlds = (size_t)nmax * 8 + FS_FIN * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
     auto launch_merge = [&](auto kern, const FsParams &pp, const void *qv) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(qv), d_qnorm, pp, k, nmax, d_out_ids,
@@ -1680,7 +1681,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_OK;
     };
     // exact scans isolate their finalists inside the rounding band (FM_ROUND); what that cannot settle -- a cluster of
-    // near-duplicates larger than a stripe list or than the 256 re-score slots -- is re-scanned in the final summation
+    // near-duplicates larger than a stripe list or than the 1024 re-score slots -- is re-scanned in the final summation
     // order.  Both launches return at once when the list is empty (the usual case).
     const size_t rlds = (size_t)v.ld * 4 + 4 * FSR_BUF * 8 + 64;
     auto rescue = [&](auto scan_k, auto merge_k, const FsParams &pp, const void *qv) -> int {
@@ -1927,7 +1928,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
     const uint32_t nmax = want * kl;
-    const size_t mlds = (size_t)nmax * 8 + 256 * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
+    const size_t mlds = (size_t)nmax * 8 + FS_FIN * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
     auto launch_merge_on = [&](auto kern, const FsParams &pp) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(d_q), d_qnorm, pp, k, nmax, d_out_ids,

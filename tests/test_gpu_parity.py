@@ -823,7 +823,7 @@ def test_flat_scan_without_ranking_copy(oracle, hip):
 @pytest.mark.parametrize("case", ["f32_l2", "f32_cosine", "f16_l2", "f32_l2_filtered", "f32_l2_wide"])
 def test_flat_scan_rounding_band_rescue(oracle, hip, case, B):
     """Rows that differ by less than the rounding error of the ranking key (||x||^2 - 2 q.x in MFMA order vs the
-    final wave-order sum): a block of near-duplicates longer than a stripe list (or than the 256 re-score slots) next
+    final wave-order sum): a block of near-duplicates longer than a stripe list (or than the 1024 re-score slots) next
     to the queries.  The rounding band sees that its finalists are not isolated and the rescue pass re-scans those
     queries in the final summation order; answers are the oracle's bit for bit.  (Found by tests/tools/fuzz_flat.py.)"""
     import torch
