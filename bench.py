@@ -164,7 +164,7 @@ def main():
     sweep = {}
     ef = a.ef
     if ef == 0:
-        for cand in (24, 32, 40, 48, 52, 56, 60, 64, 80, 96, 128, 160, 200, 256, 384, 512, 768, 1024, 2048):
+        for cand in (24, 32, 40, 48, 52, 56, 58, 60, 62, 64, 80, 96, 128, 160, 200, 256, 384, 512, 768, 1024, 2048):
             run_step(cand)
             torch.cuda.synchronize()
             r = recall_at_k(out_ids.cpu().numpy().view(np.uint32), gt, k)
