@@ -166,7 +166,8 @@ class Index {
 //     the group and hands every caller its slice; no service thread, no timer thread;
 //   * a filter that allows less than `flatScanSelectivity` of the ids takes the exact scan: the reference's filtered
 //     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there.
-class MicroBatcher {
+template <class IndexT>
+class BasicMicroBatcher {
   public:
     struct Options {
         uint32_t maxBatch = 8192;                     // queries per GPU call
@@ -176,11 +177,11 @@ class MicroBatcher {
     struct Stats {
         uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
     };
-    explicit MicroBatcher(Index &idx) : idx_(idx) {}
-    MicroBatcher(Index &idx, const Options &o) : idx_(idx), opt_(o) {}
-    ~MicroBatcher() { Stop(); }
-    MicroBatcher(const MicroBatcher &) = delete;
-    MicroBatcher &operator=(const MicroBatcher &) = delete;
+    explicit BasicMicroBatcher(IndexT &idx) : idx_(idx) {}
+    BasicMicroBatcher(IndexT &idx, const Options &o) : idx_(idx), opt_(o) {}
+    ~BasicMicroBatcher() { Stop(); }
+    BasicMicroBatcher(const BasicMicroBatcher &) = delete;
+    BasicMicroBatcher &operator=(const BasicMicroBatcher &) = delete;
 
     // pending callers and every later call get []
     void Stop() {
@@ -219,7 +220,9 @@ class MicroBatcher {
             g->cv.wait(lk, [&] { return g->done; });
             return me < g->results.size() ? std::move(g->results[me]) : std::vector<SearchResult>();
         }
-        g->cv.wait_for(lk, opt_.window, [&] { return g->sealed || closed_; });
+        // (wait_until on the system clock = pthread_cond_timedwait, which thread sanitizers intercept; wait_for would use
+        // pthread_cond_clockwait, invisible to GCC 11's TSan)
+        g->cv.wait_until(lk, std::chrono::system_clock::now() + opt_.window, [&] { return g->sealed || closed_; });
         // one GPU call at a time: while the previous group's call runs, this group stays open and keeps growing
         // (batch size adapts to the load: everything that arrived during one call goes into the next)
         lk.unlock();
@@ -247,7 +250,7 @@ class MicroBatcher {
             }
             try {
                 out = flat ? idx_.FlatScanBatch(Q.data(), B, k, allowList) : idx_.SearchBatch(Q.data(), B, k, allowList, efSearch);
-            } catch (const Error &) { // ":356-359": log and return []
+            } catch (const std::exception &) { // ":356-359": log and return []
                 out.clear();
             }
         }
@@ -271,7 +274,7 @@ class MicroBatcher {
         bool sealed = false, done = false;
         std::condition_variable cv;
     };
-    Index &idx_;
+    IndexT &idx_;
     Options opt_;
     mutable std::mutex mu_;
     std::mutex exec_mu_; // taken before mu_, never while holding it
@@ -279,6 +282,9 @@ class MicroBatcher {
     bool closed_ = false;
     Stats stats_;
 };
+
+// IndexT needs Dim(), Count(), SearchBatch(), FlatScanBatch() with Index's signatures (a test double can stand in)
+using MicroBatcher = BasicMicroBatcher<Index>;
 
 } // namespace hnsw
 } // namespace kektor

@@ -35,3 +35,22 @@ def test_cpp_host_mirror_on_gpu(tmp_path):
     p = subprocess.run([build_exe(tmp_path)], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     assert "ok" in p.stdout
+
+
+def test_micro_batcher_logic_under_thread_sanitizer(tmp_path):
+    """the batcher's grouping / leader / turn-taking / Stop() logic on a test double, built with -fsanitize=thread
+    (the reference runs its concurrency tests under the race detector): no report, every caller gets
+    the answer computed from its own query, calls are coalesced"""
+    import kektordb_amd
+    kektordb_amd.build_library()
+    exe = str(tmp_path / "batcher_logic_test")
+    libdir = os.path.dirname(kektordb_amd.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "batcher_logic_test.cpp"), "-L", libdir, "-lkektor_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.stdout.startswith("ok"), r.stdout
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
