@@ -1545,8 +1545,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_OK;
     }
     const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
-    // every scan selects by a key that is approximate or summed in another order and re-scores its finalists in the
-    // order of the graph search: 16 extra candidates absorb the difference
+    // per-stripe list length: a stripe keeps its k+16 best by the ranking key; the merge kernel checks that no full
+    // list reaches into the error band of the k-th key (else the query goes to the exact / rescue pass)
     const uint32_t kl = k + 16 > 144 ? 144 : k + 16;
     // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
     const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
