@@ -1173,23 +1173,34 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
 // (16 lanes per row), appends what beats its threshold to its own LDS buffer and compacts it when it fills; the four
 // buffers are folded into one at the end.  HBM-bound re-read of the stripe's rows: ~3 GB for one query at 1M x 768.
 constexpr uint32_t FSR_BUF = 320; // entries per wave buffer (fs_compact_wave handles up to 320)
+constexpr uint32_t FSR_TQ = 8;    // rescued queries that share one pass over a stripe's rows (ungrouped scans)
+__host__ __device__ inline size_t fsr_lds_bytes(uint32_t ld, uint32_t tq) {
+    return (size_t)tq * ((size_t)ld * 4 + 4 * FSR_BUF * 8 + 4 * 4 + 4 * 8) + 64;
+}
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p) {
+flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t tq_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qlds = reinterpret_cast<float *>(smem);                               // [ld]
-    float *bkey = qlds + v.ld;                                                   // [4][FSR_BUF]
-    uint32_t *bid = reinterpret_cast<uint32_t *>(bkey + 4 * FSR_BUF);            // [4][FSR_BUF]
-    uint32_t *wcnt = bid + 4 * FSR_BUF;                                          // [4]
+    // [tq][ld] queries | [tq][4][FSR_BUF] keys | ids | [tq][4] thresholds (u64) | [tq][4] counts
+    float *qlds = reinterpret_cast<float *>(smem);
+    float *bkey = qlds + (size_t)tq_max * v.ld;
+    uint32_t *bid = reinterpret_cast<uint32_t *>(bkey + (size_t)tq_max * 4 * FSR_BUF);
+    unsigned long long *wthr = reinterpret_cast<unsigned long long *>(bid + (size_t)tq_max * 4 * FSR_BUF);
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wthr + (size_t)tq_max * 4);
     const uint32_t n_rs = *p.rs_count;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, t = lane & 15;
     const uint32_t qstride = p.n_qtiles * FS_TQ;
-    for (uint32_t item = blockIdx.x; item < n_rs * p.want; item += gridDim.x) {
-        const uint32_t q = p.rs_list[item / p.want], sidx = item % p.want;
+    // queries of one item share the stripe's rows (every re-read after the first hits in cache); a grouped scan gives
+    // every query its own id list and stripe geometry, so its items hold one query each
+    const uint32_t tq = p.g_of_query ? 1u : tq_max;
+    const uint32_t n_tiles = (n_rs + tq - 1) / tq;
+    for (uint32_t item = blockIdx.x; item < n_tiles * p.want; item += gridDim.x) {
+        const uint32_t r0 = (item / p.want) * tq, sidx = item % p.want;
+        const uint32_t nq = n_rs - r0 < tq ? n_rs - r0 : tq;
         const uint32_t *scan_ids = p.scan_ids;
         FsGeom geo;
         if (p.g_of_query) {
-            const uint32_t grp = p.g_of_query[q];
+            const uint32_t grp = p.g_of_query[p.rs_list[r0]];
             scan_ids = p.scan_ids + p.g_base[grp];
             geo = fs_resolve_n(p, p.g_nscan[grp]);
         } else {
@@ -1199,56 +1210,75 @@ flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p) {
         const uint32_t row_begin = sidx * geo.rows_per_stripe;
         const uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
         __syncthreads(); // the previous item's buffers are no longer read
-        for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256)
-            reinterpret_cast<float4 *>(qlds)[i] = reinterpret_cast<const float4 *>(queries + (size_t)q * v.ld)[i];
+        for (uint32_t j = 0; j < nq; j++) {
+            const float4 *src = reinterpret_cast<const float4 *>(queries + (size_t)p.rs_list[r0 + j] * v.ld);
+            for (uint32_t i = (uint32_t)tid; i < (v.ld >> 2); i += 256) reinterpret_cast<float4 *>(qlds + (size_t)j * v.ld)[i] = src[i];
+        }
+        if (tid < (int)(4 * tq)) {
+            wthr[tid] = ~0ull;
+            wcnt[tid] = 0u;
+        }
         __syncthreads();
-        float *mk = bkey + wave * FSR_BUF;
-        uint32_t *mi = bid + wave * FSR_BUF;
-        uint32_t cnt = 0;
-        unsigned long long thr = ~0ull;
         for (uint32_t base = row_begin + (uint32_t)wave * 4u; base < row_end; base += 16u) {
             const uint32_t r = base + (uint32_t)g;
             const bool act = r < row_end;
             const uint32_t id = act ? (scan_ids ? scan_ids[r] : r + 1u) : 0u;
-            float part;
-            if (PREC == KDB_PREC_F16) {
-                part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
-            } else if (METRIC == KDB_METRIC_COSINE) { // key = -dot
-                part = -kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_COSINE>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
-            } else {
-                part = kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
+            for (uint32_t j = 0; j < nq; j++) {
+                const float *qj = qlds + (size_t)j * v.ld;
+                float part;
+                if (PREC == KDB_PREC_F16) {
+                    part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qj, v.ld, t));
+                } else if (METRIC == KDB_METRIC_COSINE) { // key = -dot
+                    part = -kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_COSINE>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qj, v.ld, t));
+                } else {
+                    part = kdb_reduce16(kdb_row_partial_f32<KDB_METRIC_L2>(reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld, qj, v.ld, t));
+                }
+                float *mk = bkey + ((size_t)j * 4 + wave) * FSR_BUF;
+                uint32_t *mi = bid + ((size_t)j * 4 + wave) * FSR_BUF;
+                uint32_t cnt = wcnt[j * 4 + wave];
+                unsigned long long thr = wthr[j * 4 + wave];
+                const unsigned long long e = fs_pack(part, id);
+                bool pass = act && t == 0 && e < thr;
+                unsigned long long m = __ballot(pass);
+                if (!m) continue;
+                if (cnt + 4u > FSR_BUF) {
+                    thr = fs_compact_wave<1>(mk, mi, cnt, p.kl);
+                    cnt = p.kl;
+                    pass = pass && e <= thr;
+                    m = __ballot(pass);
+                    if (lane == 0) wthr[j * 4 + wave] = thr;
+                }
+                if (pass) {
+                    const uint32_t pos = cnt + kdb_mbcnt(m);
+                    mk[pos] = part;
+                    mi[pos] = id;
+                }
+                cnt += (uint32_t)__builtin_popcountll(m);
+                if (lane == 0) wcnt[j * 4 + wave] = cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
             }
-            const unsigned long long e = fs_pack(part, id);
-            bool pass = act && t == 0 && e < thr;
-            unsigned long long m = __ballot(pass);
-            if (!m) continue;
-            if (cnt + 4u > FSR_BUF) {
-                thr = fs_compact_wave<1>(mk, mi, cnt, p.kl);
-                cnt = p.kl;
-                pass = pass && e <= thr;
-                m = __ballot(pass);
-            }
-            if (pass) {
-                const uint32_t pos = cnt + kdb_mbcnt(m);
-                mk[pos] = part;
-                mi[pos] = id;
-            }
-            cnt += (uint32_t)__builtin_popcountll(m);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         }
-        if (cnt > p.kl) {
-            (void)fs_compact_wave<1>(mk, mi, cnt, p.kl);
-            cnt = p.kl;
+        for (uint32_t j = 0; j < nq; j++) { // every wave trims its own buffers
+            float *mk = bkey + ((size_t)j * 4 + wave) * FSR_BUF;
+            uint32_t *mi = bid + ((size_t)j * 4 + wave) * FSR_BUF;
+            const uint32_t cnt = wcnt[j * 4 + wave];
+            if (cnt > p.kl) {
+                (void)fs_compact_wave<1>(mk, mi, cnt, p.kl);
+                if (lane == 0) wcnt[j * 4 + wave] = p.kl;
+            }
         }
-        if (lane == 0) wcnt[wave] = cnt;
         __syncthreads();
-        if (wave == 0) { // fold the other waves' lists into this one (<= 2 kl <= 288 entries at a time)
+        // wave w folds the four lists of queries w, w+4, ... into the first one (<= 2 kl <= 288 entries at a time)
+        for (uint32_t j = (uint32_t)wave; j < nq; j += 4) {
+            float *mk = bkey + (size_t)j * 4 * FSR_BUF;
+            uint32_t *mi = bid + (size_t)j * 4 * FSR_BUF;
+            uint32_t cnt = wcnt[j * 4];
             for (int w = 1; w < 4; w++) {
-                const uint32_t c = wcnt[w];
+                const uint32_t c = wcnt[j * 4 + w];
                 for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
-                    mk[cnt + i] = bkey[w * FSR_BUF + i];
-                    mi[cnt + i] = bid[w * FSR_BUF + i];
+                    mk[cnt + i] = mk[(size_t)w * FSR_BUF + i];
+                    mi[cnt + i] = mi[(size_t)w * FSR_BUF + i];
                 }
                 cnt += c;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -1258,6 +1288,7 @@ flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p) {
                     cnt = p.kl;
                 }
             }
+            const uint32_t q = p.rs_list[r0 + j];
             const size_t lb = p.lists_query_major ? ((size_t)sidx * qstride + q) * p.cap
                                                   : ((size_t)sidx * p.n_qtiles + q / FS_TQ) * p.cap * FS_TQ + (q % FS_TQ);
             const size_t est = p.lists_query_major ? 1 : (size_t)FS_TQ;
@@ -1683,9 +1714,12 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // exact scans isolate their finalists inside the rounding band (FM_ROUND); what that cannot settle -- a cluster of
     // near-duplicates larger than a stripe list or than the 1024 re-score slots -- is re-scanned in the final summation
     // order.  Both launches return at once when the list is empty (the usual case).
-    const size_t rlds = (size_t)v.ld * 4 + 4 * FSR_BUF * 8 + 64;
+    uint32_t rtq = FSR_TQ; // queries per rescue work item: as many as fit LDS
+    while (rtq > 1 && fsr_lds_bytes(v.ld, rtq) > 150u * 1024u) rtq--;
+    const size_t rlds = fsr_lds_bytes(v.ld, rtq);
     auto rescue = [&](auto scan_k, auto merge_k, const FsParams &pp, const void *qv) -> int {
-        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(qv), pp);
+        KDB_HIP(hipFuncSetAttribute((const void *)scan_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(qv), pp, rtq);
         KDB_HIP(hipGetLastError());
         return launch_merge(merge_k, pp, qv);
     };
@@ -1936,9 +1970,10 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         return KDB_OK;
     };
     auto launch_merge = [&](auto kern) -> int { return launch_merge_on(kern, p); };
-    const size_t rlds = (size_t)v.ld * 4 + 4 * FSR_BUF * 8 + 64;
+    const size_t rlds = fsr_lds_bytes(v.ld, 1); // grouped scan: one query per rescue work item
     auto rescue = [&](auto scan_k, auto merge_k, const FsParams &pp) -> int { // see kdb_launch_flat_scan
-        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(d_q), pp);
+        KDB_HIP(hipFuncSetAttribute((const void *)scan_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(scan_k, dim3(512), dim3(256), rlds, s, v, reinterpret_cast<const float *>(d_q), pp, 1u);
         KDB_HIP(hipGetLastError());
         return launch_merge_on(merge_k, pp);
     };
