@@ -72,6 +72,9 @@ struct FsParams {
     uint32_t lists_query_major; // per-stripe lists: 0 = [tile][entry][128 queries] (tile kernel), 1 = [query][entry] (small kernel)
     uint32_t B, kl;           // kl = per-stripe list length
     uint32_t cap;             // entries allocated per (stripe, query): kl (LDS lists) or kl + max(kl, 64) (buffered mode)
+    // big-tile ranking kernel (flat_scan_big.cuh): rows per tile (0 = FS_TR), and the blockIdx -> (query tile, stripe) map:
+    // query tiles of 256, split into fb_nqg groups of fb_nqx tiles; an XCD serves one group with fb_spx stripes
+    uint32_t tile_rows, fb_nqt, fb_nqg, fb_nqx, fb_spx;
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
     uint32_t *part_id;
     uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
@@ -87,14 +90,15 @@ __device__ __forceinline__ FsGeom fs_resolve(const FsParams &p) {
 __device__ __forceinline__ FsGeom fs_resolve_n(const FsParams &p, uint32_t n_scan) {
     FsGeom g;
     g.n_scan = n_scan;
-    const uint32_t n_tiles = (g.n_scan + FS_TR - 1) / FS_TR;
+    const uint32_t TR = p.tile_rows ? p.tile_rows : (uint32_t)FS_TR;
+    const uint32_t n_tiles = (g.n_scan + TR - 1) / TR;
     uint32_t ns = p.want;
     const uint32_t lim = (n_tiles + p.min_tiles - 1) / p.min_tiles;
     if (ns > lim) ns = lim;
     if (ns < 1) ns = 1;
     const uint32_t tiles_per = (n_tiles + ns - 1) / ns;
     g.n_stripes = tiles_per ? (n_tiles + tiles_per - 1) / tiles_per : 0u;
-    g.rows_per_stripe = tiles_per * FS_TR;
+    g.rows_per_stripe = tiles_per * TR;
     return g;
 }
 
@@ -106,13 +110,12 @@ __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint
 // buffer; when it fills, one wave selects the kl best of the query together.  The kl-th smallest (ordered key,
 // id) pair is found by a bitwise search with compare + ballot + popcount: 32 steps over the keys, and 32 more
 // over the ids only when several entries share the boundary key.  Keepers are then compacted to the front.
-// Returns the new threshold packed as fs_pack() does.  Whole wave, arguments wave-uniform, cnt <= 320.
+// Returns the new threshold packed as fs_pack() does.  Whole wave, arguments wave-uniform, cnt <= 64 * SLOTS.
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id);
 __device__ __forceinline__ float fs_unpack_key(unsigned long long x);
-template <int STRIDE>
+template <int STRIDE, int SLOTS = 5>
 __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
     const uint32_t lane = (uint32_t)kdb_lane();
-    constexpr int SLOTS = 5;
     const uint32_t nslot = (cnt + 63u) >> 6;
     uint32_t ek[SLOTS], ei[SLOTS];
 #pragma unroll
@@ -855,6 +858,8 @@ __device__ __forceinline__ float fs_unpack_key(unsigned long long x) {
     return __uint_as_float(u);
 }
 
+#include "flat_scan_big.cuh"
+
 // Merge the per-stripe lists of one query (block = 256 threads): SELECT the best nf entries of the n gathered
 // ones (nf = k for cosine, the re-score set kl for L2) with a block-wide bitwise search for the nf-th smallest
 // (ordered key, id) -- 32 compare-and-count steps over the keys, 32 more over the ids only when the boundary key
@@ -1519,6 +1524,18 @@ merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t
 
 } // namespace
 
+// Batches of at least this many queries rank with the big-tile kernel (KDB_FLAT_BIG_MIN overrides for measurements;
+// 0x7fffffff switches it off).
+static int kdb_flat_big_min() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("KDB_FLAT_BIG_MIN");
+        v = e ? atoi(e) : 257;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 // Batches up to this many queries use flat_scan_small_kernel (KDB_FLAT_SMALL_MAX overrides for measurements).
 static int kdb_flat_small_max() {
     static int v = -1;
@@ -1615,8 +1632,31 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
     // buffered mode: kl entries + room for max(kl, 64) appends between two compactions (<= 320 in all)
     const uint32_t cap = (small || kl <= (uint32_t)FS_LDS_KL) ? kl : kl + (kl > 64u ? kl : 64u);
-    const size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
-    const size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
+    // ---- large batches rank with the big-tile kernel (flat_scan_big.cuh): 256 queries x 256 rows per workgroup, LDS-DMA
+    //      staging, one workgroup per CU.  Rows must be whole 128-byte slabs (>= 3 of them) in a 1- or 2-byte encoding:
+    //      int8 rows, float16 rows, or the half-precision ranking copy of float32 rows.
+    const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : v.ld * 2u;
+    const bool big = !small && B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u && rowb >= 3u * FB_SLAB &&
+                     (v.precision == KDB_PREC_I8 || v.precision == KDB_PREC_F16 || (rank16 && idx->d_rows16 != nullptr));
+    uint32_t fb_nqt = 0, fb_nqg = 1, fb_nqx = 1, fb_spx = 1, want_big = 1;
+    if (big) {
+        fb_nqt = (B + FB_T - 1) / FB_T;                 // <= 32 (batches above 8192 queries are split)
+        while (fb_nqg * 8u < fb_nqt) fb_nqg *= 2u;      // groups of <= 8 query tiles; 1, 2 or 4 groups
+        fb_nqx = (fb_nqt + fb_nqg - 1u) / fb_nqg;       // query tiles an XCD serves
+        fb_spx = 32u / fb_nqx;                          // stripes an XCD walks (32 CUs, one workgroup each)
+        want_big = (8u / fb_nqg) * fb_spx;
+        if (want_big > stripes_max) want_big = stripes_max;
+        const uint32_t max_tiles = (v.count + FB_T - 1) / FB_T;
+        const uint32_t lim = (max_tiles + 3u) / 4u;
+        if (want_big > lim) want_big = lim;
+        if (want_big < 1) want_big = 1;
+    }
+    const uint32_t cap_big = fb_cap(kl);
+    const size_t n_part_big = big ? (size_t)want_big * fb_nqt * FB_T : 0;
+    size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
+    if (big && n_part_big * cap_big * 8 + n_part_big * 4 + 1024 > part_bytes) part_bytes = n_part_big * cap_big * 8 + n_part_big * 4 + 1024;
+    size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
+    if (big && v.precision == KDB_PREC_F16) fbq_bytes = ((size_t)fb_nqt * FB_T * v.ld * 2 + 255) & ~(size_t)255; // the queries as halfs
     const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
     const size_t rsl_bytes = ((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255; // queries handed to the rescue pass
     int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes + part_bytes + 4096);
@@ -1662,8 +1702,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t stripes8 = (n_stripes + 7) / 8 * 8;
     const uint32_t grid = stripes8 * n_qtiles;
     if (rank16 && small) p.rows16 = idx->d_rows16;
-    if (rank16 && !small) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
-        const size_t nq_elems = (size_t)n_qtiles * FS_TQ * v.ld;
+    if ((rank16 && !small) || (big && v.precision == KDB_PREC_F16)) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
+        const size_t nq_elems = big ? (size_t)fb_nqt * FB_T * v.ld : (size_t)n_qtiles * FS_TQ * v.ld;
         hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq_elems / 4 + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<const float *>(d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
         KDB_HIP(hipGetLastError());
@@ -1685,7 +1725,34 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_OK;
     };
     auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, d_q, lds_s); };
-    if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
+    FsParams p_old = p; // geometry of the 128 x 128 tile kernel (the exact pass of a big-tile ranked scan keeps it)
+    if (big) {
+        p.want = want_big;
+        p.min_tiles = 4u;
+        p.n_qtiles = fb_nqt * (uint32_t)(FB_T / FS_TQ);
+        p.cap = cap_big;
+        p.part_key = reinterpret_cast<float *>(part);
+        p.part_id = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 4);
+        p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 8);
+        p.lists_query_major = 1u;
+        p.tile_rows = FB_T;
+        p.fb_nqt = fb_nqt;
+        p.fb_nqg = fb_nqg;
+        p.fb_nqx = fb_nqx;
+        p.fb_spx = fb_spx;
+    }
+    auto launch_big = [&](auto kern, const void *rows_b, const void *q_b) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), FB_LDS, s, v, reinterpret_cast<const unsigned char *>(rows_b),
+                           reinterpret_cast<const unsigned char *>(q_b), p);
+        return KDB_OK;
+    };
+    if (big) {
+        if (v.precision == KDB_PREC_I8) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, v.rows, d_q);
+        else if (v.precision == KDB_PREC_F16) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16>, v.rows, d_fbq);
+        else if (v.metric == KDB_METRIC_COSINE) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+        else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+    } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
         const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
         if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, d_q, lds_r);
         else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p, d_q, lds_r);
@@ -1703,9 +1770,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
-    const uint32_t nmax = n_stripes * kl; // <= FS_MAX_MERGE entries gathered per query
-    const size_t mlds = (size_t)nmax * 8 + FS_FIN * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)want * 12 + 16;
     auto launch_merge = [&](auto kern, const FsParams &pp, const void *qv) -> int {
+        const uint32_t nmax = pp.want * kl; // <= FS_MAX_MERGE entries gathered per query
+        const size_t mlds = (size_t)nmax * 8 + FS_FIN * 8 + 48 + 1024 + (size_t)v.ld * 4 + (size_t)pp.want * 12 + 16;
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), mlds, s, v, reinterpret_cast<const float *>(qv), d_qnorm, pp, k, nmax, d_out_ids,
                            d_out_dist, d_out_count);
@@ -1740,12 +1807,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         // once); their number never leaves the device
         hipLaunchKernelGGL(gather_queries_kernel, dim3(B), dim3(64), 0, s, reinterpret_cast<const float *>(d_q), v.ld, d_fblist,
                            d_fbcount, d_fbq);
-        FsParams p2 = p;
+        FsParams p2 = big ? p_old : p; // the exact kernels keep their own tiling and list layout
+        p2.band = p.band;
         p2.b_dev = d_fbcount;
         p2.q_map = d_fblist;
         p2.ctr = nullptr;
         p2.fb_count = nullptr;
         p2.fb_list = nullptr;
+        p2.rows16 = nullptr;
+        p2.q16 = nullptr;
         if (small) {
             if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, p2, d_fbq, lds_s);
             else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, d_fbq, lds_s);

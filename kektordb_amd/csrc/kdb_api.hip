@@ -857,7 +857,7 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
         if (rc) return rc;
         d_first = idx->d_work + 8;
     }
-    const uint32_t Bpad = (B + 127u) & ~127u;
+    const uint32_t Bpad = (B + 255u) & ~255u; // whole query tiles of either tile kernel (128 / 256 queries), zero rows behind B
     void *d_q = nullptr;
     float *d_qnorm = nullptr;
     int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);

@@ -1,0 +1,133 @@
+"""GPU parity of the big-tile ranking kernel of the exact scan (flat_scan_big_kernel: 256 queries x 256 rows per workgroup,
+LDS-DMA staging; batches above 256 queries over rows that are whole 128-byte slabs).  Same bar as every other scan: the
+answer is the oracle's (BruteForceIndex.SearchWithScores, pkg/core/vector_index.go:104-140, restated in
+oracle/kdb_oracle.c) bit for bit in the wave accumulation order -- ids and raw f32 distances; int8 within the f32
+rounding of the f64 cosine scaling."""
+import numpy as np
+import pytest
+
+from conftest import make_corpus
+from test_gpu_parity import assert_same_results_tol, flat_stats, raw_to_score
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(O, hip, X, metric, prec, deleted=(), absmax_q=0.999):
+    n, dim = X.shape
+    orc = O.OracleIndex(dim, metric, prec, 8, 16, seed=3)
+    if prec == O.I8:
+        Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+        orc.set_absmax(float(np.quantile(np.abs(Xn), absmax_q)))
+    orc.add_many(X)
+    for d in deleted:
+        orc.mark_deleted(int(d))
+    idx = hip.HipIndex(dim, metric, prec, 8, 16, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    if prec == O.I8:
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())  # carries the deleted bits
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    return orc, idx
+
+
+def _check(O, orc, idx, Q, k, ids, dist, cnt, which, prec, allow=None):
+    for b in which:
+        oi, od = orc.flat_scan(Q[b], k, allow=allow) if allow is not None else orc.flat_scan(Q[b], k)
+        c = int(cnt[b])
+        assert c == len(oi), (b, c, len(oi))
+        if prec == O.I8:
+            assert_same_results_tol(ids[b, :c], raw_to_score(idx, dist[b, :c]), oi, od)
+        else:
+            assert np.array_equal(ids[b, :c], oi), (b, ids[b, :c], oi)
+            assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), b
+
+
+# (metric, precision, n, dim, k, B): several stripes, a ragged last tile, one and several query tiles (the last one
+# ragged), lists in every regime (k+16 = 26 / 66 / 116 / 144 entries), 3 ... 12 slabs per row
+CASES = [
+    (1, 0, 9000, 768, 10, 300),
+    (0, 0, 9000, 192, 10, 520),
+    (1, 0, 21000, 256, 50, 1100),
+    (0, 0, 5003, 384, 100, 257),
+    (0, 1, 9000, 192, 10, 300),     # float16 rows (euclidean only)
+    (0, 1, 6000, 448, 128, 513),
+    (1, 2, 9000, 384, 10, 300),     # int8 rows (cosine only)
+    (1, 2, 7000, 768, 100, 600),
+]
+
+
+@pytest.mark.parametrize("metric,prec,n,dim,k,B", CASES)
+def test_flat_scan_big_tile_vs_oracle(oracle, hip, metric, prec, n, dim, k, B):
+    O = oracle
+    X = make_corpus(n, dim, "normal", seed=141)
+    if prec == O.F16:
+        X = X * 0.5
+    deleted = list(range(3, n, 37))
+    orc, idx = _pair(O, hip, X, metric, prec, deleted)
+    Q = make_corpus(B, dim, "normal", seed=142)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    assert not (set(ids[cnt[:, None] > np.arange(k)[None, :]].tolist()) & set(deleted))
+    which = list(range(0, B, 7)) + [255, 256, B - 1]
+    _check(O, orc, idx, Q, k, ids, dist, cnt, which, prec)
+    # the same batch through the 128 x 128 tile kernel (what small batches use): identical answers for EVERY query
+    if prec != O.I8:
+        ids_s = np.empty_like(ids); dist_s = np.empty_like(dist); cnt_s = np.empty_like(cnt)
+        for b0 in range(0, B, 200):
+            i2, d2, c2 = idx.flat_scan_batch(Q[b0:b0 + 200], k)
+            ids_s[b0:b0 + 200], dist_s[b0:b0 + 200], cnt_s[b0:b0 + 200] = i2, d2, c2
+        assert np.array_equal(cnt, cnt_s)
+        assert np.array_equal(ids, ids_s)
+        assert np.array_equal(dist.view(np.uint32), dist_s.view(np.uint32))
+    # filtered: 3 % of the ids (gathered rows: the DMA's per-lane source addresses come from the id list)
+    from kektordb_amd.index import dense_bitset
+    rng = np.random.default_rng(5)
+    allowed = np.nonzero(rng.random(n + 1) < 0.2)[0]
+    allowed = allowed[allowed >= 1]
+    ab = dense_bitset(allowed, n)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k, allow_bits=ab)
+    got = ids[cnt[:, None] > np.arange(k)[None, :]]
+    assert np.isin(got, allowed).all() and not (set(got.tolist()) & set(deleted))
+    _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, B, 29)) + [B - 1], prec, allow=ab)
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("case", ["near_duplicates", "dense_block"])
+def test_flat_scan_big_tile_band(oracle, hip, metric, case):
+    """the f16 error band behind the big-tile kernel: thousands of rows closer than the f16 error (every band overflows
+    -> exact pass, which keeps the 128 x 128 tile kernel and its own list layout), a block of consecutive ids that beats
+    everything (its stripe saturates inside the band)"""
+    O = oracle
+    rng = np.random.default_rng(23)
+    n, dim, k, B = 12000, 192, 10, 300
+    base = rng.standard_normal(dim).astype(np.float32)
+    base /= np.linalg.norm(base)
+    if case == "near_duplicates":
+        X = base[None, :] + 2e-4 * rng.standard_normal((n, dim)).astype(np.float32)
+    else:
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        X[1000:1400] = base[None, :] + 1e-3 * rng.standard_normal((400, dim)).astype(np.float32)
+    Q = (base[None, :] + 0.05 * rng.standard_normal((B, dim))).astype(np.float32)
+    orc, idx = _pair(O, hip, X, metric, O.F32)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    settled_exactly = flat_stats(idx)[0]
+    if case == "near_duplicates":
+        assert settled_exactly == B
+    else:
+        assert settled_exactly > 0
+    _check(O, orc, idx, Q, k, ids, dist, cnt, range(0, B, 3), O.F32)
+
+
+def test_flat_scan_big_tile_identical_rows(oracle, hip):
+    """64 identical rows next to every query: equal keys, equal distances, the smaller ids win on both sides"""
+    O = oracle
+    rng = np.random.default_rng(29)
+    n, dim, k, B = 8000, 256, 10, 260
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    base = rng.standard_normal(dim).astype(np.float32)
+    X[3000:3064] = base[None, :]
+    Q = (base[None, :] + 0.05 * rng.standard_normal((B, dim))).astype(np.float32)
+    orc, idx = _pair(O, hip, X, 0, O.F32)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    _check(O, orc, idx, Q, k, ids, dist, cnt, range(0, B, 5), O.F32)
+    assert np.array_equal(ids[0], np.arange(3001, 3011, dtype=np.uint32))
