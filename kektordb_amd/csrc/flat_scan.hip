@@ -75,6 +75,9 @@ struct FsParams {
     // big-tile ranking kernel (flat_scan_big.cuh): rows per tile (0 = FS_TR), and the blockIdx -> (query tile, stripe) map:
     // query tiles of 256, split into fb_nqg groups of fb_nqx tiles; an XCD serves one group with fb_spx stripes
     uint32_t tile_rows, fb_nqt, fb_nqg, fb_nqx, fb_spx;
+    uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
+    uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
+    uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
     uint32_t *part_id;
     uint32_t *part_cnt;       // [n_stripes][n_qtiles*FS_TQ]
@@ -123,6 +126,7 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
         const uint32_t i = lane + 64u * (uint32_t)u;
         ek[u] = 0xffffffffu;
         ei[u] = 0xffffffffu;
+        if ((uint32_t)u >= nslot) continue; // (wave-uniform: the cost follows the list, not SLOTS)
         if (i < cnt) {
             ek[u] = (uint32_t)(fs_pack(key[(size_t)i * STRIDE], 0u) >> 32);
             ei[u] = id[(size_t)i * STRIDE];
@@ -133,33 +137,37 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
         const uint32_t test = Tk | ((1u << bit) - 1u);
         uint32_t c = 0;
 #pragma unroll
-        for (int u = 0; u < SLOTS; u++)
-            if ((uint32_t)u < nslot) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
+        for (int u = 0; u < SLOTS; u++) {
+            if ((uint32_t)u >= nslot) break;
+            c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
+        }
         if (c < kl) Tk |= 1u << bit;
     }
     uint32_t c_lt = 0, c_eq = 0;
 #pragma unroll
-    for (int u = 0; u < SLOTS; u++)
-        if ((uint32_t)u < nslot) {
-            c_lt += (uint32_t)__builtin_popcountll(__ballot(ek[u] < Tk));
-            c_eq += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk));
-        }
+    for (int u = 0; u < SLOTS; u++) {
+        if ((uint32_t)u >= nslot) break;
+        c_lt += (uint32_t)__builtin_popcountll(__ballot(ek[u] < Tk));
+        c_eq += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk));
+    }
     const uint32_t need = kl - c_lt; // entries with the boundary key to keep (>= 1), smallest ids first
     uint32_t Ti = 0;                 // smallest Ti with count(key == Tk && id <= Ti) >= need
     if (c_eq == 1u) { // the usual case: one boundary entry, its id is the threshold id
 #pragma unroll
-        for (int u = 0; u < SLOTS; u++)
-            if ((uint32_t)u < nslot) {
-                const unsigned long long m = __ballot(ek[u] == Tk);
-                if (m) Ti = (uint32_t)__shfl((int)ei[u], __builtin_ctzll(m), 64);
-            }
+        for (int u = 0; u < SLOTS; u++) {
+            if ((uint32_t)u >= nslot) break;
+            const unsigned long long m = __ballot(ek[u] == Tk);
+            if (m) Ti = (uint32_t)__shfl((int)ei[u], __builtin_ctzll(m), 64);
+        }
     } else {
         for (int bit = 31; bit >= 0; bit--) {
             const uint32_t test = Ti | ((1u << bit) - 1u);
             uint32_t c = 0;
 #pragma unroll
-            for (int u = 0; u < SLOTS; u++)
-                if ((uint32_t)u < nslot) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk && ei[u] <= test));
+            for (int u = 0; u < SLOTS; u++) {
+                if ((uint32_t)u >= nslot) break;
+                c += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk && ei[u] <= test));
+            }
             if (c < need) Ti |= 1u << bit;
         }
     }
@@ -1641,7 +1649,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     uint32_t fb_nqt = 0, fb_nqg = 1, fb_nqx = 1, fb_spx = 1, want_big = 1;
     if (big) {
         fb_nqt = (B + FB_T - 1) / FB_T;                 // <= 32 (batches above 8192 queries are split)
-        while (fb_nqg * 8u < fb_nqt) fb_nqg *= 2u;      // groups of <= 8 query tiles; 1, 2 or 4 groups
+        uint32_t per_xcd = 8u;
+        if (const char *e = getenv("KDB_FB_NQX")) per_xcd = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 8u;
+        while (fb_nqg * per_xcd < fb_nqt && fb_nqg < 8u) fb_nqg *= 2u; // groups of <= 8 query tiles; 1, 2 or 4 groups
         fb_nqx = (fb_nqt + fb_nqg - 1u) / fb_nqg;       // query tiles an XCD serves
         fb_spx = 32u / fb_nqx;                          // stripes an XCD walks (32 CUs, one workgroup each)
         want_big = (8u / fb_nqg) * fb_spx;
@@ -1651,7 +1661,12 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         if (want_big > lim) want_big = lim;
         if (want_big < 1) want_big = 1;
     }
-    const uint32_t cap_big = fb_cap(kl);
+    uint32_t fb_slack = 64u, fb_period = 4u; // measured at 8192 queries over 1M x 768: period 1 / 2 / 4 = 14.8 / 14.0 / 13.9 ms
+    if (const char *e = getenv("KDB_FB_SLACK")) fb_slack = (uint32_t)atoi(e);
+    if (const char *e = getenv("KDB_FB_PERIOD")) fb_period = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 1u;
+    while (fb_period > 1u && fb_cap(kl, fb_slack, fb_period) > 64u * (uint32_t)FB_CSLOTS) fb_period--;
+    if (fb_cap(kl, fb_slack, fb_period) > 64u * (uint32_t)FB_CSLOTS) fb_slack = 64u * (uint32_t)FB_CSLOTS - kl - fb_period * (uint32_t)FB_T;
+    const uint32_t cap_big = fb_cap(kl, fb_slack, fb_period);
     const size_t n_part_big = big ? (size_t)want_big * fb_nqt * FB_T : 0;
     size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
     if (big && n_part_big * cap_big * 8 + n_part_big * 4 + 1024 > part_bytes) part_bytes = n_part_big * cap_big * 8 + n_part_big * 4 + 1024;
@@ -1740,6 +1755,10 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_nqg = fb_nqg;
         p.fb_nqx = fb_nqx;
         p.fb_spx = fb_spx;
+        p.fb_slack = fb_slack;
+        p.fb_alt = getenv("KDB_FB_NOALT") ? 0u : 1u;
+        p.fb_period = fb_period;
+        { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     }
     auto launch_big = [&](auto kern, const void *rows_b, const void *q_b) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));

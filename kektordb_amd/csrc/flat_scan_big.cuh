@@ -24,13 +24,23 @@
 // The keys are ranking keys only (f16 products summed in the MFMA's order, ||x||^2 - 2 q.x, -dot/||x||): the merge
 // kernel re-scores the finalists in the order of the graph search, exactly as for the other scan kernels.
 
+// measurement switches (KDB_FB_DBG, see FsParams::fb_dbg) exist only in builds with -DKDB_FB_DEBUG: their branches
+// fragment the schedule of the slab loop
+#ifdef KDB_FB_DEBUG
+#define FB_DBG p.fb_dbg
+#else
+#define FB_DBG 0u
+#endif
 constexpr int FB_T = 256;        // rows per tile = queries per tile
 constexpr int FB_SLAB = 128;     // bytes of every row per K slab
-constexpr uint32_t FB_SLACK = 64; // appended entries a list may carry beyond kl before it is compacted
+constexpr int FB_CSLOTS = 20;     // fs_compact_wave register slots: a list never holds more than 64 * 20 entries
+constexpr uint32_t FB_DUMPS = 96; // 16-score blocks a wave can park in its scratch between two phase-B passes
 constexpr uint32_t FB_STAGE = 2u * FB_T * FB_SLAB; // one slab buffer: rows + queries = 64 KB
-constexpr size_t FB_LDS = 2u * FB_STAGE + FB_T * 12u + 2u * FB_T * 8u + 64u;
+constexpr size_t FB_LDS = 2u * FB_STAGE + FB_T * 12u + 2u * FB_T * 8u + FB_T * 4u + 64u;
 
-__host__ __device__ inline uint32_t fb_cap(uint32_t kl) { return kl + FB_SLACK + (uint32_t)FB_T; }
+// entries allocated per (stripe, query): lists are compacted every `period` tiles when they hold more than kl + slack
+// entries, and a tile appends at most FB_T entries to a list
+__host__ __device__ inline uint32_t fb_cap(uint32_t kl, uint32_t slack, uint32_t period) { return kl + slack + period * (uint32_t)FB_T; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -61,6 +71,7 @@ __device__ __forceinline__ void fb_glds4(const unsigned char *g0, const unsigned
                  : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_dst)
                  : "memory", "scc");
 }
+__device__ __forceinline__ float fb_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ void fb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int METRIC, int PREC>
@@ -74,7 +85,8 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     uint32_t *l_cnt = tau_id + FB_T;                                            // [256] entries in the query's list
     uint32_t *sel_id = l_cnt + FB_T;                                            // [2][256] row ids of a tile (by tile parity)
     float *sel_nrm = reinterpret_cast<float *>(sel_id + 2 * FB_T);              // [2][256] their norms
-    uint32_t *flags = reinterpret_cast<uint32_t *>(sel_nrm + 2 * FB_T);         // [2] "somebody appended" per tile parity
+    uint32_t *need_list = reinterpret_cast<uint32_t *>(sel_nrm + 2 * FB_T);     // [256] queries whose list is due for compaction
+    uint32_t *flags = need_list + FB_T;                                         // [0] somebody appended since the last compaction round, [1] length of need_list
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -93,9 +105,11 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     const FsGeom geo = fs_resolve(p);
     if (bid == 0 && tid == 0 && p.ctr) p.ctr[0] = geo.n_scan;
     if (s_local >= p.fb_spx || qtile >= p.fb_nqt || stripe >= geo.n_stripes) return;
-    const uint32_t row_begin = stripe * geo.rows_per_stripe;
-    const uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
-    const uint32_t q0 = qtile * FB_T;
+    uint32_t row_begin = stripe * geo.rows_per_stripe;
+    uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
+    uint32_t q0 = qtile * FB_T;
+    if (FB_DBG & 64u) { row_begin = 0; row_end = geo.rows_per_stripe; }   // measurement: every workgroup walks stripe 0
+    if (FB_DBG & 128u) q0 = 0;                                             // measurement: every workgroup uses query tile 0
     const uint32_t qstride = p.n_qtiles * FS_TQ;
     const uint32_t rowb = PREC == KDB_PREC_I8 ? v.ld : v.ld * 2u;
     const uint32_t nslab = rowb / FB_SLAB;
@@ -126,10 +140,16 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         aptr[j] = rows8 + (size_t)sel_id[(uint32_t)j * 64u + st_row] * rowb + st_piece * 16u;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
-    auto issue = [&](uint32_t buf, uint32_t slab) {
+    // the DMA of a slab is issued in two halves (rows, then queries) between MFMA groups, so that its issue cost
+    // (the M0 writes and 4 requests per half) hides behind matrix-pipe time instead of preceding it
+    auto issue_rows = [&](uint32_t buf, uint32_t slab) {
         const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * FB_STAGE + (uint32_t)wave * 1024u);
         const uint32_t so = slab * FB_SLAB;
         fb_glds4(aptr[0] + so, aptr[1] + so, aptr[2] + so, aptr[3] + so, la);
+    };
+    auto issue_queries = [&](uint32_t buf, uint32_t slab) {
+        const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * FB_STAGE + (uint32_t)wave * 1024u);
+        const uint32_t so = slab * FB_SLAB;
         fb_glds4(qptr[0] + so, qptr[1] + so, qptr[2] + so, qptr[3] + so, la + FB_T * FB_SLAB);
     };
     // ---- fragment map: lane (l31, hi) reads the 16 bytes k-piece kq*2+hi of row l31 of each 32-row block
@@ -141,35 +161,41 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     for (int kq = 0; kq < 4; kq++) slot_off[kq] = (((uint32_t)kq * 2u + (uint32_t)hi) ^ swz) * 16u;
 
     f32x16 acc[4][2];
-    auto compute = [&](uint32_t buf) {
+    // fragments of one 16-deep K step: 4 row blocks + 2 query blocks; two sets alternate (software pipeline)
+    float4 fa[2][4], fb[2][2];
+    auto read_frags = [&](int set, uint32_t buf, int kq) {
         const unsigned char *sb = stage + buf * FB_STAGE;
 #pragma unroll
-        for (int kq = 0; kq < 4; kq++) {
-            float4 fa[4], fb[2];
+        for (int ab = 0; ab < 4; ab++) fa[set][ab] = *reinterpret_cast<const float4 *>(sb + a_off + ab * 4096 + slot_off[kq]);
 #pragma unroll
-            for (int ab = 0; ab < 4; ab++) fa[ab] = *reinterpret_cast<const float4 *>(sb + a_off + ab * 4096 + slot_off[kq]);
+        for (int bb = 0; bb < 2; bb++) fb[set][bb] = *reinterpret_cast<const float4 *>(sb + b_off + bb * 4096 + slot_off[kq]);
+    };
+    auto mfma_step = [&](int set) {
+        if (FB_DBG & 4u) return;
 #pragma unroll
-            for (int bb = 0; bb < 2; bb++) fb[bb] = *reinterpret_cast<const float4 *>(sb + b_off + bb * 4096 + slot_off[kq]);
+        for (int ab = 0; ab < 4; ab++)
 #pragma unroll
-            for (int ab = 0; ab < 4; ab++)
-#pragma unroll
-                for (int bb = 0; bb < 2; bb++) {
-                    if (PREC == KDB_PREC_I8)
-                        acc[ab][bb] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                                                                     __builtin_bit_cast(i32x4, fa[ab]), __builtin_bit_cast(i32x4, fb[bb]),
-                                                                     __builtin_bit_cast(i32x16, acc[ab][bb]), 0, 0, 0));
-                    else
-                        acc[ab][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ab]), __builtin_bit_cast(f16x8, fb[bb]),
-                                                                             acc[ab][bb], 0, 0, 0);
-                }
-        }
+            for (int bb = 0; bb < 2; bb++) {
+                if (PREC == KDB_PREC_I8)
+                    acc[ab][bb] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                                                 __builtin_bit_cast(i32x4, fa[set][ab]), __builtin_bit_cast(i32x4, fb[set][bb]),
+                                                                 __builtin_bit_cast(i32x16, acc[ab][bb]), 0, 0, 0));
+                else
+                    acc[ab][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][ab]),
+                                                                         __builtin_bit_cast(f16x8, fb[set][bb]), acc[ab][bb], 0, 0, 0);
+            }
     };
 
     uint32_t g = 0; // slabs computed so far: buffer parity
-    if (row_begin < row_end) issue(0, 0);
+    if (row_begin < row_end) {
+        issue_rows(0, 0);
+        issue_queries(0, 0);
+    }
     fb_dma_wait();
     __syncthreads();
+    if (row_begin < row_end) read_frags(0, 0, 0);
 
+    unsigned long long tm_sel = 0, tm_cmp = 0;
     uint32_t t = 0;
     for (uint32_t tile = row_begin; tile < row_end; tile += FB_T, t++) {
         const uint32_t tp = t & 1u;
@@ -188,104 +214,173 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
 
+        // One slab: the fragments of its first K step are already in set 0 (read behind the previous slab's barrier).
+        //   step 0: read step 1 -> set 1 | request the next slab's rows    | MFMAs of set 0
+        //   step 1: read step 2 -> set 0 | request the next slab's queries | MFMAs of set 1
+        //   step 2: read step 3 -> set 1 |                                 | MFMAs of set 0
+        //   drain the DMA, barrier (every LDS read of this slab has returned: the buffer may be refilled)
+        //   step 3: read step 0 of the NEXT slab -> set 0                  | MFMAs of set 1
         for (uint32_t s = 0; s < nslab; s++, g++) {
             const uint32_t buf = g & 1u;
-            if (s + 1 < nslab) {
-                issue(buf ^ 1u, s + 1);
-            } else if (has_next) {
+            const bool dma_same = s + 1 < nslab, dma_next = !dma_same && has_next;
+            const bool dma = (dma_same || dma_next) && !(FB_DBG & 2u);
+            // odd tiles walk their slabs backwards: the query slabs the previous tile used last are requested first, while
+            // they are still in the XCD's L2 (a tile period streams more bytes through an XCD than its L2 holds)
+            const uint32_t odd = t & p.fb_alt;
+            const uint32_t nslab_i = dma_same ? (odd ? nslab - 2u - s : s + 1u) : ((odd || !p.fb_alt) ? 0u : nslab - 1u);
+            if (dma_next) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     aptr[j] = rows8 + (size_t)sel_id[(tp ^ 1u) * FB_T + (uint32_t)j * 64u + st_row] * rowb + st_piece * 16u;
-                issue(buf ^ 1u, 0);
             }
-            compute(buf);
+            read_frags(1, buf, 1);
+            if (dma) issue_rows(buf ^ 1u, nslab_i);
+            mfma_step(0);
+            read_frags(0, buf, 2);
+            if (dma) issue_queries(buf ^ 1u, nslab_i);
+            mfma_step(1);
+            read_frags(1, buf, 3);
+            mfma_step(0);
             fb_dma_wait();
             __syncthreads(); // slab s+1 has landed (every wave drained its own DMA), nobody reads slab s any more
+            if (dma_same || dma_next) read_frags(0, buf ^ 1u, 0);
             if (s == 0 && has_next && tid < FB_T) {
                 sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
                 if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
             }
+            mfma_step(1);
         }
 
-        // ---- selection.  acc[ab][bb][r]: query wn*64 + bb*32 + l31, row wm*128 + ab*32 + (r&3) + 8*(r>>2) + 4*hi
+        // ---- selection.  acc[ab][bb][r]: query wn*64 + bb*32 + l31, row wm*128 + ab*32 + (r&3) + 8*(r>>2) + 4*hi.
+        // Scores s = -key (larger is better): the raw dot (cosine), 2 q.x - ||x||^2 (L2), dot/||x|| (int8).
+        // Phase A, every lane, straight-line code: the maximum of each 16-register block against the query's threshold.
+        // A lane whose block may hold survivors DUMPS the 16 scores and a descriptor into the wave's scratch (the slab
+        // buffer the last slab was computed from is idle until the next tile requests its second slab).
+        // Phase B, all 64 lanes on 4 dumped blocks at a time (16 lanes per block): exact test against the threshold
+        // (total order key, id), one LDS atomic per survivor for its place in the query's list, two scattered stores.
+        // The cost of a tile follows the number of survivors, not the number of lanes that hold one.
+        if (FB_DBG & 1u) continue;
         bool appended = false;
-        float t_k[2];
-        uint32_t t_id[2];
-#pragma unroll
-        for (int bb = 0; bb < 2; bb++) {
-            t_k[bb] = tau[wn * 64 + bb * 32 + l31];
-            t_id[bb] = tau_id[wn * 64 + bb * 32 + l31];
-        }
-#pragma unroll
-        for (int ab = 0; ab < 4; ab++) {
-            float nr[16];
-            if (NEED_NORM) {
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const float4 x = *reinterpret_cast<const float4 *>(sel_nrm + tp * FB_T + wm * 128 + ab * 32 + gq * 8 + hi * 4);
-                    nr[gq * 4 + 0] = x.x;
-                    nr[gq * 4 + 1] = x.y;
-                    nr[gq * 4 + 2] = x.z;
-                    nr[gq * 4 + 3] = x.w;
-                }
-                if (PREC == KDB_PREC_I8) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) nr[r] = nr[r] == 0.f ? 0.f : 1.0f / nr[r]; // stored norm 0 => similarity 0
-                }
-            }
-#pragma unroll
-            for (int bb = 0; bb < 2; bb++) {
-                float m = INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float rawv = acc[ab][bb][r];
-                    const float dotv = PREC == KDB_PREC_I8 ? (float)__float_as_int(rawv) : rawv;
-                    const float key = PREC == KDB_PREC_I8 ? -dotv * nr[r]
-                                      : METRIC == KDB_METRIC_COSINE ? -dotv : __builtin_fmaf(-2.0f, dotv, nr[r]);
-                    acc[ab][bb][r] = key;
-                    m = fminf(m, key);
-                }
-                const bool pass = m <= t_k[bb]; // false for NaN
-                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-                if (pass) {
-                    const uint32_t qq = (uint32_t)(wn * 64 + bb * 32 + l31);
-                    const size_t lb = list0 + (size_t)qq * cap;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const float key = acc[ab][bb][r];
-                        if (!(key <= t_k[bb])) continue;
-                        const uint32_t rid = sel_id[tp * FB_T + wm * 128 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
-                        if (rid == 0u) continue; // past the end of the stripe
-                        if (!fs_better(key, rid, t_k[bb], t_id[bb])) continue;
-                        const uint32_t pos = atomicAdd(&l_cnt[qq], 1u); // < cap: see the header comment
-                        p.part_key[lb + pos] = key;
-                        p.part_id[lb + pos] = rid;
-                        appended = true;
+        const unsigned long long tm0 = (FB_DBG & 32u) ? __builtin_readcyclecounter() : 0ull;
+        {
+            unsigned char *scratch = stage + ((g - 1u) & 1u) * FB_STAGE + (uint32_t)wave * 8192u;
+            float *dump = reinterpret_cast<float *>(scratch);                               // [FB_DUMPS][16] scores
+            uint4 *dsc = reinterpret_cast<uint4 *>(scratch + FB_DUMPS * 64u);               // [FB_DUMPS] {t_k, t_id, code}
+            uint32_t n_dump = 0; // wave-uniform
+            auto phase_b = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                for (uint32_t i0 = 0; i0 < n_dump; i0 += 4u) {
+                    const uint32_t d = i0 + ((uint32_t)lane >> 4), r = (uint32_t)lane & 15u;
+                    if (d < n_dump) {
+                        const uint4 ds = dsc[d];
+                        const float key = -dump[d * 16u + r];
+                        const float tk = __uint_as_float(ds.x);
+                        const uint32_t ln = ds.z & 63u, ab = (ds.z >> 6) & 3u, bb = (ds.z >> 8) & 1u;
+                        const uint32_t qq = (uint32_t)wn * 64u + bb * 32u + (ln & 31u);
+                        const uint32_t rloc = (uint32_t)wm * 128u + ab * 32u + 4u * (ln >> 5) + (r & 3u) + 8u * (r >> 2);
+                        const uint32_t rpos = tile + rloc;
+                        if (rpos < row_end && key <= tk) { // rows past the end of the stripe are zero rows, not candidates
+                            const uint32_t rid = p.scan_ids ? sel_id[tp * FB_T + rloc] : rpos + 1u;
+                            if (fs_better(key, rid, tk, ds.y) && !(FB_DBG & 16u)) {
+                                const uint32_t pos = atomicAdd(&l_cnt[qq], 1u); // < cap: see the header comment
+                                const size_t lb = list0 + (size_t)qq * cap;
+                                p.part_key[lb + pos] = key;
+                                p.part_id[lb + pos] = rid;
+                                appended = true;
+                            }
+                        }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                n_dump = 0;
+            };
+            float t_k[2], thr[2];
+            uint32_t t_id[2];
+#pragma unroll
+            for (int bb = 0; bb < 2; bb++) {
+                t_k[bb] = tau[wn * 64 + bb * 32 + l31];
+                t_id[bb] = tau_id[wn * 64 + bb * 32 + l31];
+                thr[bb] = -t_k[bb];
             }
-        }
-        if (appended) flags[tp] = 1u;
-        __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete
-        if (tid == 0) flags[tp ^ 1u] = 0u;
-        if (flags[tp]) { // wave w looks after queries w*32 .. w*32+31: compact what outgrew kl + FB_SLACK
-            const uint32_t myq = (uint32_t)wave * 32u + (uint32_t)l31;
-            const uint32_t c = l_cnt[myq];
-            unsigned long long need = __builtin_amdgcn_ballot_w64(hi == 0 && c > p.kl + FB_SLACK);
-            while (need) {
-                const uint32_t qi = (uint32_t)__builtin_ctzll(need);
-                need &= need - 1ull;
-                const uint32_t qq = (uint32_t)wave * 32u + qi;
-                const uint32_t cq = (uint32_t)__shfl((int)c, (int)qi, 64);
-                const size_t lb = list0 + (size_t)qq * cap;
-                const unsigned long long T = fs_compact_wave<1, 8>(p.part_key + lb, p.part_id + lb, cq, p.kl);
-                if (lane == 0) {
-                    tau[qq] = fs_unpack_key(T);
-                    tau_id[qq] = (uint32_t)(T & 0xffffffffu);
-                    l_cnt[qq] = p.kl;
+#pragma unroll
+            for (int ab = 0; ab < 4; ab++) {
+                if (NEED_NORM) { // scores in place
+                    float nr[16];
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const float4 x = *reinterpret_cast<const float4 *>(sel_nrm + tp * FB_T + wm * 128 + ab * 32 + gq * 8 + hi * 4);
+                        nr[gq * 4 + 0] = x.x;
+                        nr[gq * 4 + 1] = x.y;
+                        nr[gq * 4 + 2] = x.z;
+                        nr[gq * 4 + 3] = x.w;
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float rawv = acc[ab][bb][r];
+                            if (PREC == KDB_PREC_I8) // stored norm 0 => similarity 0
+                                acc[ab][bb][r] = (float)__float_as_int(rawv) * (nr[r] == 0.f ? 0.f : 1.0f / nr[r]);
+                            else
+                                acc[ab][bb][r] = __builtin_fmaf(2.0f, rawv, -nr[r]);
+                        }
+                }
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) {
+                    float m = fb_max3(acc[ab][bb][0], acc[ab][bb][1], acc[ab][bb][2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) m = fb_max3(m, acc[ab][bb][r], acc[ab][bb][r + 1]);
+                    m = fmaxf(m, acc[ab][bb][15]);
+                    const bool pass = m >= thr[bb]; // false for NaN
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+                    if (bal == 0ull) continue;
+                    if (pass) {
+                        const uint32_t slot = n_dump + kdb_mbcnt(bal);
+                        float4 *dst = reinterpret_cast<float4 *>(dump + slot * 16u);
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++)
+                            dst[gq] = make_float4(acc[ab][bb][gq * 4 + 0], acc[ab][bb][gq * 4 + 1], acc[ab][bb][gq * 4 + 2], acc[ab][bb][gq * 4 + 3]);
+                        dsc[slot] = make_uint4(__float_as_uint(t_k[bb]), t_id[bb], (uint32_t)lane | ((uint32_t)ab << 6) | ((uint32_t)bb << 8), 0u);
+                    }
+                    n_dump += (uint32_t)__builtin_popcountll(bal);
+                    if (n_dump + 64u > FB_DUMPS) phase_b(); // the next block may dump 64 more
                 }
             }
+            if (n_dump) phase_b();
         }
+        if (appended) flags[0] = 1u;
+        if (FB_DBG & 32u) tm_sel += __builtin_readcyclecounter() - tm0;
+        const unsigned long long tm1 = (FB_DBG & 32u) ? __builtin_readcyclecounter() : 0ull;
+        // ---- compaction round, every fb_period tiles: the lists that outgrew kl + fb_slack are cut back to their kl best
+        //      and the thresholds follow.  All eight waves share the work (a compaction is a dependent round trip to the
+        //      list in HBM scratch plus a 32-step search: the whole workgroup waits for the slowest wave at the next barrier).
+        __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete; the dump scratch is free again
+        if ((t == 0u || (t + 1u) % p.fb_period == 0u) && has_next) { // (the first tile keeps everything: thresholds start open)
+            if (flags[0] && !(FB_DBG & 8u)) {
+                if (tid < FB_T && l_cnt[tid] > p.kl + p.fb_slack) need_list[atomicAdd(&flags[1], 1u)] = (uint32_t)tid;
+                __syncthreads();
+                const uint32_t nn = flags[1];
+                for (uint32_t i = (uint32_t)wave; i < nn; i += 8u) {
+                    const uint32_t qq = need_list[i];
+                    const size_t lb = list0 + (size_t)qq * cap;
+                    const unsigned long long T = fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, l_cnt[qq], p.kl);
+                    if (lane == 0) {
+                        tau[qq] = fs_unpack_key(T);
+                        tau_id[qq] = (uint32_t)(T & 0xffffffffu);
+                        l_cnt[qq] = p.kl;
+                    }
+                }
+                __syncthreads(); // need_list and its length may be reused
+                if (tid == 0) { flags[0] = 0u; flags[1] = 0u; }
+            }
+        }
+        if (FB_DBG & 32u) tm_cmp += __builtin_readcyclecounter() - tm1;
+    }
+    if ((FB_DBG & 32u) && p.ctr && lane == 0) { // per-wave cycle totals: selection phases, compaction rounds (with their barriers)
+        atomicAdd(p.ctr + 2, tm_sel);
+        atomicAdd(p.ctr + 3, tm_cmp);
     }
 
     // ---- hand the lists over: at most kl entries each
@@ -300,7 +395,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             const uint32_t qq = (uint32_t)wave * 32u + qi;
             const uint32_t cq = (uint32_t)__shfl((int)c, (int)qi, 64);
             const size_t lb = list0 + (size_t)qq * cap;
-            (void)fs_compact_wave<1, 8>(p.part_key + lb, p.part_id + lb, cq, p.kl);
+            (void)fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, cq, p.kl);
         }
         if (hi == 0) p.part_cnt[(size_t)stripe * qstride + q0 + myq] = c > p.kl ? p.kl : c;
     }

@@ -1078,7 +1078,9 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
         r.n_dist = c[0] * (uint64_t)idx->ring_B[slot]; // rows scanned (after filter / deletes) x queries
         r.n_hops = c[1];                               // f16-ranked scan: queries settled by the exact pass
+        r.n_dropped = c[2];                            // big-tile kernel under KDB_FB_DBG=32 (measurement build): wave cycles in
         r.bytes = c[0] * row_bytes + (uint64_t)idx->ring_B[slot] * row_bytes;
+        if (c[3]) r.bytes = c[3];                      // the selection phases / in the compaction rounds
     } else if (kind == 3) {
         r.n_dist = (uint64_t)idx->ring_B[slot] * idx->ring_C[slot];
         r.bytes = r.n_dist * row_bytes + r.n_dist * 8 + (uint64_t)idx->ring_B[slot] * row_bytes;
