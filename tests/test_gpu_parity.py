@@ -352,26 +352,31 @@ def test_merge_topk_device_and_host(oracle, hip):
             assert [e[1] for e in ent[:k]] == hi[b, :c].tolist()
 
 
-def _shard_worker(rank, world, port, out_path):
-    """two ranks sharing the one GPU of the test box (gloo): the GPU shard path end to end"""
+def _shard_worker(rank, world, port, out_path, backend="gloo"):
+    """two ranks sharing the one GPU of the test box (gloo), or one GPU each (nccl = RCCL over xGMI): the GPU shard
+    path end to end"""
     import os, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch, torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = rank if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import kektordb_amd as K
     from kektordb_amd.shard import ShardedSearch, shard_ranges
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
     n_total, dim, k, ef, B = 6000, 64, 10, 80, 96
     rng = np.random.default_rng(9)
     X = rng.standard_normal((n_total, dim)).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
     Q = torch.from_numpy(rng.standard_normal((B, dim)).astype(np.float32)).to(dev)
     base, cnt = shard_ranges(n_total, world)[rank]
-    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 100, capacity=cnt)
+    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 100, capacity=cnt, device_id=local)
     idx.upload_rows(X[base:base + cnt], 1)
     idx.build(cnt, batch=512, ef_construction=100, seed=3 + rank)
     sh = ShardedSearch(K.COSINE, K.F32, id_base=base, hip_index=idx)
@@ -390,15 +395,21 @@ def _shard_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_sharded_search_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_search_two_ranks(tmp_path, backend):
+    """gloo: both ranks on the one GPU of the test box.  nccl: one GPU per rank, the packed all-gather runs over RCCL /
+    xGMI -- skipped unless two GPUs are visible (the round's GPU box has one)."""
     import socket
+    import torch
     import torch.multiprocessing as mp
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL path with world size 2 needs two visible GPUs")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "shard.npz")
-    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_shard_worker, args=(2, port, out, backend), nprocs=2, join=True)
     r = np.load(out)
     n_total, dim, k = 6000, 64, 10
     rng = np.random.default_rng(9)
