@@ -116,17 +116,16 @@ __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint
 // Returns the new threshold packed as fs_pack() does.  Whole wave, arguments wave-uniform, cnt <= 64 * SLOTS.
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id);
 __device__ __forceinline__ float fs_unpack_key(unsigned long long x);
-template <int STRIDE, int SLOTS = 5>
-__device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
+template <int STRIDE, int SLOTS>
+__device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
+    // cnt <= 64 * SLOTS; every loop below has a compile-time trip count (the entries live in registers)
     const uint32_t lane = (uint32_t)kdb_lane();
-    const uint32_t nslot = (cnt + 63u) >> 6;
     uint32_t ek[SLOTS], ei[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; u++) {
         const uint32_t i = lane + 64u * (uint32_t)u;
         ek[u] = 0xffffffffu;
         ei[u] = 0xffffffffu;
-        if ((uint32_t)u >= nslot) continue; // (wave-uniform: the cost follows the list, not SLOTS)
         if (i < cnt) {
             ek[u] = (uint32_t)(fs_pack(key[(size_t)i * STRIDE], 0u) >> 32);
             ei[u] = id[(size_t)i * STRIDE];
@@ -137,16 +136,12 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
         const uint32_t test = Tk | ((1u << bit) - 1u);
         uint32_t c = 0;
 #pragma unroll
-        for (int u = 0; u < SLOTS; u++) {
-            if ((uint32_t)u >= nslot) break;
-            c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
-        }
+        for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
         if (c < kl) Tk |= 1u << bit;
     }
     uint32_t c_lt = 0, c_eq = 0;
 #pragma unroll
     for (int u = 0; u < SLOTS; u++) {
-        if ((uint32_t)u >= nslot) break;
         c_lt += (uint32_t)__builtin_popcountll(__ballot(ek[u] < Tk));
         c_eq += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk));
     }
@@ -155,7 +150,6 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
     if (c_eq == 1u) { // the usual case: one boundary entry, its id is the threshold id
 #pragma unroll
         for (int u = 0; u < SLOTS; u++) {
-            if ((uint32_t)u >= nslot) break;
             const unsigned long long m = __ballot(ek[u] == Tk);
             if (m) Ti = (uint32_t)__shfl((int)ei[u], __builtin_ctzll(m), 64);
         }
@@ -164,17 +158,13 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
             const uint32_t test = Ti | ((1u << bit) - 1u);
             uint32_t c = 0;
 #pragma unroll
-            for (int u = 0; u < SLOTS; u++) {
-                if ((uint32_t)u >= nslot) break;
-                c += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk && ei[u] <= test));
-            }
+            for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] == Tk && ei[u] <= test));
             if (c < need) Ti |= 1u << bit;
         }
     }
     uint32_t base = 0;
 #pragma unroll
     for (int u = 0; u < SLOTS; u++) { // keepers to the front, buffer order preserved
-        if ((uint32_t)u >= nslot) break;
         const bool keep = ek[u] < Tk || (ek[u] == Tk && ei[u] <= Ti);
         const unsigned long long m = __ballot(keep);
         if (keep) {
@@ -185,6 +175,17 @@ __device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32
         base += (uint32_t)__builtin_popcountll(m);
     }
     return ((unsigned long long)Tk << 32) | Ti;
+}
+// cnt <= 64 * SLOTS (wave-uniform): the instantiation that just holds the list does the work, so the cost follows the
+// list length and not the largest length the caller allows
+template <int STRIDE, int SLOTS = 5>
+__device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
+    if (SLOTS > 2 && cnt <= 128u) return fs_compact_core<STRIDE, 2>(key, id, cnt, kl);
+    if (SLOTS > 3 && cnt <= 192u) return fs_compact_core<STRIDE, 3>(key, id, cnt, kl);
+    if (SLOTS > 5 && cnt <= 320u) return fs_compact_core<STRIDE, 5>(key, id, cnt, kl);
+    if (SLOTS > 8 && cnt <= 512u) return fs_compact_core<STRIDE, 8>(key, id, cnt, kl);
+    if (SLOTS > 12 && cnt <= 768u) return fs_compact_core<STRIDE, 12>(key, id, cnt, kl);
+    return fs_compact_core<STRIDE, SLOTS>(key, id, cnt, kl);
 }
 
 // worst entry of an entry-major list (stride FS_TQ): 8 entries per step so that the loads of a list living in

@@ -37,6 +37,19 @@ def test_header_symbols_exported(K):
         getattr(lib, s)
 
 
+def test_legacy_compute_symbols_exported(K):
+    """the ten symbols of the reference's own native header (native/compute/include/kektordb_compute.h:8-24), declared
+    in include/kektor_compute_legacy.h: exported by the shared library and by the static archive"""
+    txt = open(os.path.join(ROOT, "include", "kektor_compute_legacy.h")).read()
+    syms = sorted(set(re.findall(r"^(?:float|int32_t|int|void)\s+(\w+)\s*\(", txt, flags=re.M)))
+    assert len(syms) == 10, syms
+    for path in (K.LIB_PATH, os.path.join(os.path.dirname(K.LIB_PATH), "libkektordb_compute.a")):
+        flags = ["-D", "--defined-only"] if path.endswith(".so") else ["--defined-only"]
+        out = subprocess.run(["nm", *flags, path], capture_output=True, text=True, check=True).stdout
+        exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+        assert not [s for s in syms if s not in exported], (path, syms)
+
+
 def test_header_compiles_as_plain_c():
     src = '#include "kektor_hip.h"\nint main(void){kdb_index_desc d; (void)d; return sizeof(kdb_counters) == 40 ? 0 : 1;}\n'
     p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o",
