@@ -579,10 +579,8 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     auto kselect = build_select_kernel<METRIC, PREC>;
     auto krev = build_reverse_kernel<METRIC, PREC>;
     if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
-    hipDeviceProp_t prop;
-    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
-    const uint32_t slots_vis = (uint32_t)prop.multiProcessorCount * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
-    int rc = kdb_ensure_visited(idx, slots_vis);
+    const uint32_t slots_vis = (uint32_t)idx->n_cu * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
+    int rc = kdb_ensure_visited(idx, slots_vis, idx->stream);
     if (rc) return rc;
 
     // first node: entry point, no links (:656-670)
@@ -665,7 +663,20 @@ int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
         kdb_set_error("build: mMax0 %u exceeds %d", idx->deg0, PR_MAXSEL);
         return KDB_ERR_UNSUPPORTED;
     }
-    if (idx->desc.precision == KDB_PREC_F16) return build_impl<KDB_METRIC_L2, KDB_PREC_F16>(idx, count, p); // f16 is euclidean only
-    return idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE, KDB_PREC_F32>(idx, count, p)
-                                                 : build_impl<KDB_METRIC_L2, KDB_PREC_F32>(idx, count, p);
+    // kernels of callers' streams may still walk the graph this call is about to overwrite (adjacency arrays, the upper
+    // pool it may reallocate): wait for the whole device once
+    KDB_HIP(hipDeviceSynchronize());
+    int rc;
+    if (idx->desc.precision == KDB_PREC_F16) rc = build_impl<KDB_METRIC_L2, KDB_PREC_F16>(idx, count, p); // f16 is euclidean only
+    else rc = idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE, KDB_PREC_F32>(idx, count, p)
+                                                    : build_impl<KDB_METRIC_L2, KDB_PREC_F32>(idx, count, p);
+    if (rc != KDB_OK) { // a half-linked graph must not answer searches: the handle is back to "rows without a graph"
+        (void)hipStreamSynchronize(idx->stream);
+        idx->has_graph = false;
+        idx->entry = 0;
+        idx->max_level = -1;
+        idx->h_levels.clear();
+        idx->h_up_idx.clear();
+    }
+    return rc;
 }

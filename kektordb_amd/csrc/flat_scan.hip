@@ -1931,10 +1931,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     uint32_t stripes_max = FS_MAX_MERGE / kl;
     // stripes per group: T*want workgroups should fill whole rounds of the resident slots (LDS decides how many
     // workgroups share a CU); the fewest stripes that fill >= 90 % of their rounds win (every stripe pays a start-up)
-    hipDeviceProp_t prop;
-    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
     const uint32_t per_cu = (uint32_t)(160u * 1024u / lds_s) > 0 ? (uint32_t)(160u * 1024u / lds_s) : 1u;
-    const uint32_t slots = (uint32_t)prop.multiProcessorCount * (per_cu > 2 ? 2u : per_cu);
+    const uint32_t slots = (uint32_t)idx->n_cu * (per_cu > 2 ? 2u : per_cu);
     uint32_t want = 1;
     {
         double best = 0.0;

@@ -97,7 +97,58 @@ int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
     return KDB_OK;
 }
 
-int kdb_ensure_visited(kdb_index *idx, uint32_t slots) {
+static void lane_store(kdb_index *idx) { // the current lane's buffers may have grown
+    kdb_lane &l = idx->lanes[idx->cur_lane];
+    l.d_visited = idx->d_visited;
+    l.vis_slots = idx->vis_slots;
+    l.d_scratch = idx->d_scratch;
+    l.scratch_bytes = idx->scratch_bytes;
+    l.d_qbuf = idx->d_qbuf;
+    l.qbuf_bytes = idx->qbuf_bytes;
+    l.d_gentry = idx->d_gentry;
+    l.gentry_cap = idx->gentry_cap;
+    l.d_work = idx->d_work;
+}
+static void lane_load(kdb_index *idx, int li) {
+    const kdb_lane &l = idx->lanes[li];
+    idx->cur_lane = li;
+    idx->d_visited = l.d_visited;
+    idx->vis_slots = l.vis_slots;
+    idx->d_scratch = l.d_scratch;
+    idx->scratch_bytes = l.scratch_bytes;
+    idx->d_qbuf = l.d_qbuf;
+    idx->qbuf_bytes = l.qbuf_bytes;
+    idx->d_gentry = l.d_gentry;
+    idx->gentry_cap = l.gentry_cap;
+    idx->d_work = l.d_work;
+}
+
+int kdb_lane_acquire(kdb_index *idx, hipStream_t s) {
+    lane_store(idx);
+    int pick = -1;
+    for (int i = 0; i < KDB_LANES; i++)
+        if (idx->lanes[i].used && idx->lanes[i].last_stream == s) pick = i; // same stream: ordered already
+    if (pick < 0) {
+        pick = 0;
+        for (int i = 1; i < KDB_LANES; i++)
+            if (idx->lanes[i].last_use < idx->lanes[pick].last_use) pick = i;
+        if (idx->lanes[pick].used) KDB_HIP(hipStreamWaitEvent(s, idx->lanes[pick].done, 0));
+    }
+    lane_load(idx, pick);
+    return KDB_OK;
+}
+
+int kdb_lane_release(kdb_index *idx, hipStream_t s) {
+    lane_store(idx);
+    kdb_lane &l = idx->lanes[idx->cur_lane];
+    l.last_stream = s;
+    l.used = true;
+    l.last_use = ++idx->lane_clock;
+    KDB_HIP(hipEventRecord(l.done, s));
+    return KDB_OK;
+}
+
+int kdb_ensure_visited(kdb_index *idx, uint32_t slots, hipStream_t s) {
     if (idx->vis_slots >= slots) return KDB_OK;
     if (idx->d_visited) {
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
@@ -107,7 +158,7 @@ int kdb_ensure_visited(kdb_index *idx, uint32_t slots) {
     }
     uint32_t words = (((idx->cap >> 5) + 1) + 3u) & ~3u;
     KDB_HIP(hipMalloc(&idx->d_visited, (size_t)slots * words * 4));
-    KDB_HIP(hipMemsetAsync(idx->d_visited, 0, (size_t)slots * words * 4, idx->stream));
+    KDB_HIP(hipMemsetAsync(idx->d_visited, 0, (size_t)slots * words * 4, s)); // on the stream the walk will run on
     idx->vis_slots = slots;
     return KDB_OK;
 }
@@ -244,8 +295,17 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     const size_t dw = ((n1 + 31) / 32 + 3) & ~(size_t)3;
     KDB_TRY(hipMalloc(&idx->d_deleted, dw * 4));
     KDB_TRY(hipMemsetAsync(idx->d_deleted, 0, dw * 4, idx->stream));
-    KDB_TRY(hipMalloc(&idx->d_work, 64 * 4));
-    KDB_TRY(hipMemsetAsync(idx->d_work, 0, 64 * 4, idx->stream));
+    for (int i = 0; i < KDB_LANES; i++) {
+        KDB_TRY(hipEventCreateWithFlags(&idx->lanes[i].done, hipEventDisableTiming));
+        KDB_TRY(hipMalloc(&idx->lanes[i].d_work, 64 * 4));
+        KDB_TRY(hipMemsetAsync(idx->lanes[i].d_work, 0, 64 * 4, idx->stream));
+    }
+    idx->d_work = idx->lanes[0].d_work;
+    {
+        hipDeviceProp_t prop;
+        KDB_TRY(hipGetDeviceProperties(&prop, desc->device_id));
+        idx->n_cu = prop.multiProcessorCount;
+    }
     KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 32));
     KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 32, idx->stream));
     KDB_TRY(hipStreamSynchronize(idx->stream));
@@ -258,11 +318,18 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    (void)hipDeviceSynchronize(); // callers' streams may still run kernels of this index
+    lane_store(idx);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
-                    idx->d_deleted, idx->d_visited, idx->d_scratch, idx->d_work,  idx->d_ctr,    idx->d_qbuf,
-                    idx->d_iobuf, idx->d_build, idx->d_gentry, idx->d_rows16};
+                    idx->d_deleted, idx->d_ctr, idx->d_iobuf, idx->d_build, idx->d_rows16};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (kdb_lane &l : idx->lanes) {
+        void *lb[] = {l.d_visited, l.d_scratch, l.d_qbuf, l.d_gentry, l.d_work};
+        for (void *b : lb)
+            if (b) (void)hipFree(b);
+        if (l.done) (void)hipEventDestroy(l.done);
+    }
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         if (idx->ring_ev0[i]) (void)hipEventDestroy(idx->ring_ev0[i]);
         if (idx->ring_ev1[i]) (void)hipEventDestroy(idx->ring_ev1[i]);
@@ -280,6 +347,8 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
     const size_t rb = (size_t)idx->desc.dim * idx->elem, lb = (size_t)idx->ld * idx->elem;
     unsigned char *dst = reinterpret_cast<unsigned char *>(idx->d_rows) + (size_t)first_id * lb;
     if (lb != rb) KDB_HIP(hipMemsetAsync(dst, 0, (size_t)n * lb, idx->stream)); // zero the pad columns
@@ -415,7 +484,10 @@ extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
         }
     }
     if (slots > idx->up_slots_cap) {
-        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
+        if (idx->d_adj_up) {
+            KDB_HIP(hipDeviceSynchronize()); // walks of callers' streams may still read the old pool
+            KDB_HIP(hipFree(idx->d_adj_up));
+        }
         idx->d_adj_up = nullptr;
         KDB_HIP(hipMalloc(&idx->d_adj_up, (slots * idx->deg_up + 1) * 4));
         idx->up_slots_cap = slots;
@@ -539,6 +611,8 @@ extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_
     }
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     int rc = kdb_ensure_scratch(idx, al(rows.size() * 4) + al((size_t)n * 4) + 256);
     if (rc) return rc;
@@ -757,6 +831,8 @@ extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
     return search_dev_locked(idx, d_queries, B, k, ef, d_allow_bits, flags, d_out_ids, d_out_dist, d_out_count, s);
 }
 
@@ -801,6 +877,8 @@ extern "C" int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
     if (G == 0 || !d_allow_lists || !d_allow_of_query) // no lists: the plain batch
         return search_dev_locked(idx, d_queries, B, k, ef, nullptr, flags, d_out_ids, d_out_dist, d_out_count, s);
     if (words_per_list < ((uint64_t)(idx->count >> 6) + 1)) {
@@ -826,6 +904,8 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
     return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
                           [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
                               return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
@@ -881,6 +961,8 @@ extern "C" int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, 
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
     if (words_per_list < ((uint64_t)(idx->count >> 6) + 1)) {
         kdb_set_error("flat_scan_groups: words_per_list %llu < (count>>6)+1", (unsigned long long)words_per_list);
         return KDB_ERR_INVALID;
@@ -913,6 +995,8 @@ extern "C" int kdb_flat_scan_batch_dev(kdb_index *idx, const float *d_queries, u
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
     return flat_dev_locked(idx, d_queries, B, k, d_allow_bits, flags, d_out_ids, d_out_dist, d_out_count, s);
 }
 
@@ -927,6 +1011,8 @@ extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
     return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
                           [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
                               return flat_dev_locked(idx, d_q, B, k, d_allow, flags, d_ids, d_dist, d_cnt, s);
@@ -958,6 +1044,8 @@ extern "C" int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, ui
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, stream ? (hipStream_t)stream : idx->stream);
+    if (lane.rc) return lane.rc;
     return distance_dev_locked(idx, d_queries, B, d_ids, C, flags, d_out, stream ? (hipStream_t)stream : idx->stream);
 }
 
@@ -971,6 +1059,8 @@ extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t
     }
     std::lock_guard<std::mutex> lk(idx->mu); // one lock for staging + launch + read-back
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
     const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
     const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
     int rc = ensure_iobuf(idx, qbytes + 2 * ibytes + 256);
@@ -992,6 +1082,8 @@ extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_p
     KDB_CHECK_IDX(idx);
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
     return kdb_build_graph(idx, count, params);
 }
 

@@ -42,6 +42,28 @@ struct KdbMultiAllow {
     uint32_t words32 = 0;
 };
 
+// Per-call scratch of the asynchronous entry points.  An index keeps KDB_LANES sets; a call takes the set last used on
+// its stream (else the least recently used one), waits -- on the device, through an event -- for the previous call that
+// used the set if that ran on ANOTHER stream, and leaves its own event behind.  Two callers driving two streams
+// therefore overlap on the GPU (the waves idling at the end of one batch's launch run the next batch's first queries)
+// without sharing visited bitsets, entry-point tables, prepared queries or scan lists.
+#define KDB_LANES 2
+struct kdb_lane {
+    uint32_t *d_visited = nullptr;
+    uint32_t vis_slots = 0;
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *d_qbuf = nullptr;
+    size_t qbuf_bytes = 0;
+    uint32_t *d_gentry = nullptr;
+    uint32_t gentry_cap = 0;
+    uint32_t *d_work = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool used = false;
+    uint64_t last_use = 0;
+};
+
 struct kdb_index {
     kdb_index_desc desc;
     uint32_t ld = 0, deg0 = 0, deg_up = 0, cap = 0;
@@ -97,6 +119,25 @@ struct kdb_index {
     uint32_t ring_B[RING] = {}, ring_C[RING] = {};
     uint64_t launch_seq = 0;
     std::mutex mu;
+    // scratch lanes: the fields d_visited / d_scratch / d_qbuf / d_gentry / d_work above always name the CURRENT lane's
+    // buffers (kdb_lane_acquire copies them in, kdb_lane_release copies them back: calls are serialised by `mu`)
+    kdb_lane lanes[KDB_LANES];
+    int cur_lane = 0;
+    uint64_t lane_clock = 0;
+    // cached device facts (one query per index, not per launch)
+    int n_cu = 0;
+};
+
+// take the scratch set for a call on stream s (device-side wait on its previous user if that was another stream) ...
+int kdb_lane_acquire(kdb_index *idx, hipStream_t s);
+// ... and leave it: records the call's completion event on s
+int kdb_lane_release(kdb_index *idx, hipStream_t s);
+struct KdbLaneGuard { // RAII: release on every return path
+    kdb_index *idx;
+    hipStream_t s;
+    int rc;
+    KdbLaneGuard(kdb_index *i, hipStream_t st) : idx(i), s(st), rc(kdb_lane_acquire(i, st)) {}
+    ~KdbLaneGuard() { if (rc == KDB_OK) (void)kdb_lane_release(idx, s); }
 };
 
 // ---- error plumbing --------------------------------------------------------------------------
@@ -113,7 +154,7 @@ void kdb_set_error(const char *fmt, ...);
 
 KdbView kdb_make_view(const kdb_index *idx);
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes);
-int kdb_ensure_visited(kdb_index *idx, uint32_t slots);
+int kdb_ensure_visited(kdb_index *idx, uint32_t slots, hipStream_t s);
 int kdb_ensure_group_entries(kdb_index *idx, uint32_t n);
 // start a new statistics slot: selects ring events (idx->ev0/ev1) and returns the slot's counter words
 unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32_t C);

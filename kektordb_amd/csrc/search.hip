@@ -16,6 +16,8 @@
 //     caller's buffer; queries are pulled from an atomic work counter by persistent waves;
 //   * one allow list per batch or one per query; its entry point (hnsw_index.go:437-447) is chosen on the device.
 #include "kdb_search_core.cuh"
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -447,10 +449,19 @@ __global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32
     }
 }
 
+// resident workgroups per CU of a kernel at a given LDS size: asked once per (kernel, size), not per launch
+// (the query costs tens of microseconds on the host -- visible in the latency of small batches)
 template <typename K>
 int occupancy_blocks(K kern, int threads, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, int> cache;
+    const std::pair<const void *, size_t> key(reinterpret_cast<const void *>(kern), lds);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) nb = 1;
+    cache[key] = nb;
     return nb;
 }
 
@@ -518,15 +529,13 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
         return KDB_ERR_UNSUPPORTED;
     }
-    hipDeviceProp_t prop;
-    KDB_HIP(hipGetDeviceProperties(&prop, idx->device));
-    const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
+    const uint32_t ncu = (uint32_t)idx->n_cu;
     auto launch = [&](auto kern, uint32_t vis_size) -> int {
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, 64, lds);
         if (grid > B) grid = B;
         if (grid == 0) return KDB_OK;
-        int rc = kdb_ensure_visited(idx, grid);
+        int rc = kdb_ensure_visited(idx, grid, s);
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill

@@ -51,7 +51,7 @@ class ShardedSearch:
     """Top-k exchange + merge around a per-rank local search."""
 
     def __init__(self, metric: int, precision: int, id_base: int, group=None,
-                 hip_index: Optional["_index.HipIndex"] = None, force_exchange: bool = False):
+                 hip_index: Optional["_index.HipIndex"] = None, force_exchange: bool = False, overlap: bool = False):
         self.metric, self.precision = metric, precision
         # force_exchange: run the all-gather + merge even with ONE rank (exercises the RCCL plumbing on a 1-GPU box)
         self.force_exchange = bool(force_exchange) and dist.is_initialized()
@@ -71,16 +71,23 @@ class ShardedSearch:
             self.bases = np.array([id_base], dtype=np.uint32)
         self._dev_bases = None
         self._bufs = {}
-        # the whole search path (library kernels, RCCL all-gather, merge kernel) is ordered on ONE
-        # dedicated HIP stream; callers synchronise with torch.cuda.synchronize() / stream.synchronize()
-        self.stream = torch.cuda.Stream() if hip_index is not None else None
+        # one batch's whole search path (library kernels, RCCL all-gather, merge kernel) is ordered on ONE dedicated HIP
+        # stream.  overlap=True: consecutive batches alternate between two such streams (the library keeps two sets of
+        # per-call scratch), so the waves idling at the end of batch i's launch already walk the first queries of batch
+        # i+1 -- the caller must then give consecutive batches different output buffers.
+        # Callers synchronise with torch.cuda.synchronize().
+        self.overlap = bool(overlap)
+        self.streams = [torch.cuda.Stream() for _ in range(2 if overlap else 1)] if hip_index is not None else []
+        self._turn = 0
 
     # ---- GPU path: device tensors, RCCL all-gather, merge kernel -------------------------------------
     def search_dev(self, d_queries, k: int, ef: int, out_ids, out_dist, out_cnt, d_allow=None, flat=False):
         idx = self.hip_index
         B = d_queries.shape[0]
         dev = d_queries.device
-        key = (B, k)
+        self._turn = (self._turn + 1) % len(self.streams)
+        stream = self.streams[self._turn]
+        key = (B, k, self._turn)
         L = 2 * B * k + B  # packed block: ids[B][k] | dist[B][k] (f32 bits) | count[B], 32-bit words
         if key not in self._bufs:
             self._bufs[key] = (torch.zeros((L,), dtype=torch.int32, device=dev),
@@ -89,9 +96,9 @@ class ShardedSearch:
         l_ids = local[:B * k].view(B, k)
         l_dist = local[B * k:2 * B * k].view(torch.float32).view(B, k)
         l_cnt = local[2 * B * k:]
-        self.stream.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
-        with torch.cuda.stream(self.stream):
-            raw = self.stream.cuda_stream
+        stream.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
+        with torch.cuda.stream(stream):
+            raw = stream.cuda_stream
             tgt = (out_ids, out_dist, out_cnt) if self.world == 1 and not self.force_exchange else (l_ids, l_dist, l_cnt)
             if flat:
                 idx.flat_scan_batch_dev(d_queries, k, *tgt, d_allow, stream=raw)
