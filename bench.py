@@ -350,8 +350,10 @@ def main():
                 fl["roofline"]["traffic"] = int(2 * fetch["flat"]["FETCH_SIZE"] * 1024 + write["flat"]["WRITE_SIZE"] * 1024)
             if fl and busy and "flat" in busy:
                 b = busy["flat"]
-                if b.get("GRBM_GUI_ACTIVE"):  # matrix-pipe busy cycles summed over the 1024 SIMDs / (active cycles x 1024)
-                    fl["roofline"]["mfma_busy_frac"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / (b["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+                # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs (SQ_BUSY_CYCLES over
+                # the 32 shader engines: both give the same active-cycle count per SIMD)
+                if b.get("GRBM_GUI_ACTIVE"):
+                    fl["roofline"]["mfma_busy_frac"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / (b["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
                 elif b.get("SQ_BUSY_CYCLES"):  # SQ_BUSY_CYCLES is summed over the 32 shader engines (32 SIMDs each)
                     fl["roofline"]["mfma_busy_frac"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / (b["SQ_BUSY_CYCLES"] * 32.0), 4)
                 fl["roofline"]["mfma_counters"] = {kk: round(vv, 1) for kk, vv in b.items()}

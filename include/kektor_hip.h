@@ -235,6 +235,16 @@ KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint3
 /* GPU batched graph construction over rows 1..count already uploaded.                             */
 KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
 
+/* TEST HOOK -- selectNeighbors (hnsw_index.go:2629-2701) exactly as the GPU builder runs it (build_select_kernel's
+ * workgroup routine), on caller-supplied candidate lists: list t holds cand_cnt[t] <= stride <= 320 entries at
+ * cand_ids / cand_keys + t*stride, ids of rows already uploaded, keys = distance of the candidate to the centre in the
+ * library's ordering form (squared L2; MINUS the dot product for cosine), ASCENDING.  out_ids: [n_lists][maxm], 0-filled
+ * behind out_cnt[t].  maxm <= 64.  Host pointers.  Exists so that the parity suite can hand identical lists to this and
+ * to the oracle's select_neighbors; the shim has no use for it.                                                  */
+KDB_API int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *cand_ids,
+                                      const float *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
+                                      uint32_t *out_cnt);
+
 /* Shard merge: G per-shard results for B queries -> global top-k.  in_ids/in_dist: [G][B][k],
  * in_count: [G][B]; id_base: NULL or [G] offsets added to shard g's (local, 1-based) ids so that
  * global id = id_base[g] + local id (shard g owns the contiguous id range that starts at id_base[g]+1).

@@ -177,6 +177,7 @@ class BasicMicroBatcher {
     struct Stats {
         uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
     };
+    static constexpr int kMaxFlatK = 128; // kdb_flat_scan_batch: k <= 128
     explicit BasicMicroBatcher(IndexT &idx) : idx_(idx) {}
     BasicMicroBatcher(IndexT &idx, const Options &o) : idx_(idx), opt_(o) {}
     ~BasicMicroBatcher() { Stop(); }
@@ -246,12 +247,22 @@ class BasicMicroBatcher {
                 uint64_t allowed = 0;
                 for (uint64_t w : allowList->words) allowed += (uint64_t)__builtin_popcountll(w);
                 const uint32_t count = idx_.Count();
-                flat = allowed > 0 && count > 0 && (double)allowed < opt_.flatScanSelectivity * (double)count;
+                // the exact scan answers k <= kMaxFlatK (kdb_flat_scan_batch); larger k keeps the graph walk, which still
+                // answers -- routing must never turn a query the reference would answer into []
+                flat = allowed > 0 && count > 0 && k <= kMaxFlatK && (double)allowed < opt_.flatScanSelectivity * (double)count;
             }
             try {
                 out = flat ? idx_.FlatScanBatch(Q.data(), B, k, allowList) : idx_.SearchBatch(Q.data(), B, k, allowList, efSearch);
-            } catch (const std::exception &) { // ":356-359": log and return []
+            } catch (const std::exception &) {
                 out.clear();
+                if (flat) { // the scan refused (an argument it does not take): the walk is the reference's own path
+                    flat = false;
+                    try {
+                        out = idx_.SearchBatch(Q.data(), B, k, allowList, efSearch);
+                    } catch (const std::exception &) { // ":356-359": log and return []
+                        out.clear();
+                    }
+                }
             }
         }
         lk.lock();

@@ -424,7 +424,8 @@ func (h *Index) searchBatchHIP(reqs []*hipRequest, k, ef int, allow *roaring.Bit
 		}
 		allowPtr = (*C.uint64_t)(unsafe.Pointer(&dense[0]))
 		card := allow.GetCardinality()
-		useFlat = card > 0 && float64(card) < hipFlatScanSelectivity*float64(count)
+		// the exact scan answers k <= 128 (kdb_flat_scan_batch); larger k keeps the walk, as the C++ twin does
+		useFlat = card > 0 && k <= 128 && float64(card) < hipFlatScanSelectivity*float64(count)
 	}
 	ids := make([]uint32, B*k)
 	dist := make([]float32, B*k)

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
     "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
-    "kdb_index_sync",
+    "kdb_index_sync", "kdb_test_select_neighbors",
 ]
 
 

@@ -471,6 +471,28 @@ build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
     }
 }
 
+// ---- test hook: selectNeighbors on caller-supplied candidate lists (kdb_test_select_neighbors) -----------------------
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+select_probe_kernel(KdbView v, const uint32_t *cand_id, const float *cand_key, const uint32_t *cand_cnt, uint32_t stride,
+                    uint32_t maxm, uint32_t *out_id, uint32_t *out_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLds p;
+    prune_carve(smem, p);
+    const int tid = (int)threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    const uint32_t n = cand_cnt[task];
+    for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
+        p.c_id[i] = cand_id[(size_t)task * stride + i];
+        p.c_key[i] = cand_key[(size_t)task * stride + i];
+    }
+    __syncthreads();
+    select_neighbors_wg<METRIC, PREC>(v, p, n, maxm);
+    const uint32_t nsel = p.misc[0];
+    if ((uint32_t)tid < maxm) out_id[(size_t)task * maxm + tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
+    if (tid == 0) out_cnt[task] = nsel;
+}
+
 uint64_t splitmix64(uint64_t &s) {
     uint64_t z = (s += 0x9e3779b97f4a7c15ull);
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -649,6 +671,30 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
 }
 
 } // namespace
+
+int kdb_select_probe(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *d_ids, const float *d_keys,
+                     const uint32_t *d_cnt, uint32_t maxm, uint32_t *d_out_ids, uint32_t *d_out_cnt, hipStream_t s) {
+    if (maxm == 0 || maxm > PR_MAXSEL || stride > PR_MAXC) {
+        kdb_set_error("select probe: maxm must be 1..%d and lists at most %d long", PR_MAXSEL, PR_MAXC);
+        return KDB_ERR_INVALID;
+    }
+    if (idx->desc.precision == KDB_PREC_I8) {
+        kdb_set_error("select probe: float32 and float16 rows only (as the GPU builder)");
+        return KDB_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
+                       (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
+    const KdbView v = kdb_make_view(idx);
+    auto go = [&](auto kern) -> int {
+        KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_lists), dim3(256), lds, s, v, d_ids, d_keys, d_cnt, stride, maxm, d_out_ids, d_out_cnt);
+        KDB_HIP(hipGetLastError());
+        return KDB_OK;
+    };
+    if (idx->desc.precision == KDB_PREC_F16) return go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
+    return idx->desc.metric == KDB_METRIC_COSINE ? go(select_probe_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>)
+                                                 : go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+}
 
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
     if (count == 0 || count > idx->cap) {

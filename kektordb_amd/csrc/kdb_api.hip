@@ -1087,6 +1087,53 @@ extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_p
     return kdb_build_graph(idx, count, params);
 }
 
+// test hook (see kektor_hip.h): host buffers in, selections out
+extern "C" int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *cand_ids,
+                                         const float *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
+                                         uint32_t *out_cnt) {
+    KDB_CHECK_IDX(idx);
+    if (n_lists == 0) return KDB_OK;
+    if (!cand_ids || !cand_keys || !cand_cnt || !out_ids || !out_cnt || stride == 0) {
+        kdb_set_error("test_select_neighbors: null buffer");
+        return KDB_ERR_INVALID;
+    }
+    for (uint32_t t = 0; t < n_lists; t++) {
+        if (cand_cnt[t] > stride) {
+            kdb_set_error("test_select_neighbors: list %u holds %u > stride %u entries", t, cand_cnt[t], stride);
+            return KDB_ERR_INVALID;
+        }
+        for (uint32_t i = 0; i < cand_cnt[t]; i++)
+            if (cand_ids[(size_t)t * stride + i] == 0 || cand_ids[(size_t)t * stride + i] > idx->cap) {
+                kdb_set_error("test_select_neighbors: candidate id out of range");
+                return KDB_ERR_INVALID;
+            }
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    KdbLaneGuard lane(idx, s);
+    if (lane.rc) return lane.rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nb = (size_t)n_lists * stride * 4;
+    int rc = kdb_ensure_scratch(idx, 2 * al(nb) + al((size_t)n_lists * 4) * 2 + al((size_t)n_lists * maxm * 4) + 256);
+    if (rc) return rc;
+    unsigned char *b = reinterpret_cast<unsigned char *>(idx->d_scratch);
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(b);
+    float *d_keys = reinterpret_cast<float *>(b + al(nb));
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(b + 2 * al(nb));
+    uint32_t *d_ocnt = reinterpret_cast<uint32_t *>(b + 2 * al(nb) + al((size_t)n_lists * 4));
+    uint32_t *d_oid = reinterpret_cast<uint32_t *>(b + 2 * al(nb) + 2 * al((size_t)n_lists * 4));
+    KDB_HIP(hipMemcpyAsync(d_ids, cand_ids, nb, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_keys, cand_keys, nb, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_cnt, cand_cnt, (size_t)n_lists * 4, hipMemcpyHostToDevice, s));
+    rc = kdb_select_probe(idx, n_lists, stride, d_ids, d_keys, d_cnt, maxm, d_oid, d_ocnt, s);
+    if (rc) return rc;
+    KDB_HIP(hipMemcpyAsync(out_ids, d_oid, (size_t)n_lists * maxm * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_cnt, d_ocnt, (size_t)n_lists * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    return KDB_OK;
+}
+
 extern "C" int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, uint32_t B, uint32_t k,
                               const uint32_t *in_ids, const float *in_dist, const uint32_t *in_count,
                               const uint32_t *id_base, uint32_t *out_ids, float *out_dist, uint32_t *out_count) {

@@ -167,6 +167,19 @@ class HipIndex:
         p = _lib.BuildParams(batch, ef_construction, seed, 0, 0)
         check(self.L.kdb_index_build(self.h, int(count), C.byref(p)), "kdb_index_build")
 
+    def test_select_neighbors(self, cand_ids, cand_keys, cand_cnt, maxm: int):
+        """TEST HOOK: the GPU builder's selectNeighbors on caller-supplied lists ([n_lists, stride] ids / ascending keys)"""
+        self._live()
+        ids = np.ascontiguousarray(cand_ids, dtype=np.uint32)
+        keys = np.ascontiguousarray(cand_keys, dtype=np.float32)
+        cnt = np.ascontiguousarray(cand_cnt, dtype=np.uint32)
+        n_lists, stride = ids.shape
+        out = np.zeros((n_lists, maxm), dtype=np.uint32)
+        oc = np.zeros(n_lists, dtype=np.uint32)
+        check(self.L.kdb_test_select_neighbors(self.h, n_lists, stride, _ptr(ids), _ptr(keys), _ptr(cnt), int(maxm), _ptr(out),
+                                               _ptr(oc)), "kdb_test_select_neighbors")
+        return out, oc
+
     def graph_info(self):
         c, e, ml = C.c_uint32(), C.c_uint32(), C.c_int32()
         check(self.L.kdb_index_graph_info(self.h, C.byref(c), C.byref(e), C.byref(ml)), "graph_info")

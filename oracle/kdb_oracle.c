@@ -28,8 +28,13 @@
  * is pinned against every known-answer test the reference holds for this path
  * (tests/test_oracle_kat.py):  distance KATs (distance_test.go:37-84,
  * lib.rs:423-458), heap pop orders (hnsw_heap_test.go:9-54), self-match ranks
- * first at ef=12/100 (pkg/client/client_test.go:171-236), recall@10 >= 0.95 on
- * 10k x 64 uniform L2 (clients/python/stress_test_recall.py:11-87).
+ * first at ef=12/100 (pkg/client/client_test.go:171-236).
+ * NOT reproduced, hence UNPINNED: the recall bar of clients/python/stress_test_recall.py:11-87 (recall@10 >= 0.95 on
+ * 10k x 64 uniform L2 through single vadd calls = the sequential Add below).  The restated Add re-prunes full neighbour
+ * lists over an UNSORTED candidate list, as :748-771 reads, and reaches 0.17 / 0.53 / 0.90 at ef 10 / 100 / 1000 on that
+ * corpus (tests/test_oracle_kat.py); whether the reference really behaves so cannot be settled without a Go toolchain.
+ * The traversal (searchLayerUnlocked), on which the GPU parity tests rest, holds no test vectors in the reference at
+ * all: its fidelity is by review against :2351-2611.
  * Bit-level accumulation order of the cosine kernel (gonum v0.16.0 Sdot amd64
  * assembly, a go.mod dependency absent from the reference tree) is PARITY
  * UNPINNED; tolerance-level parity (1e-6) is pinned by distance_test.go:47-57.
@@ -921,6 +926,173 @@ ORC_EXPORT uint32_t orc_index_add(orc_index *h, const float *vec, int forced_lev
     }
     free(cands); free(sel); free(allc); free(best); free(tmpids);
     return id;
+}
+
+/* ---- hnsw_index.go:1479-2088 addBatchInternal --------------------------------------------------------
+ * The reference fans phases 0.B / 1B / 1 out over runtime.NumCPU() goroutines and phase 3 over 128 shards.  Restated
+ * here for ONE worker.  What the goroutine interleaving can change in the reference, and what it cannot:
+ *   - the order of the randomLevel() draws from the process-global RNG (:1741) -- here: batch order (or the caller's
+ *     `forced_levels`), from the seeded stream;
+ *   - nothing else: phase 1 reads a graph that no phase writes (links are committed in phase 3), every worker freezes
+ *     entry point / maxLevel / maxID once (:1796-1801, same values for all), and phase 3 handles each target node in
+ *     exactly one shard, from requests that are merged, SORTED and de-duplicated per level (:1983-2003) -- their arrival
+ *     order is erased.  The one unspecified order left is that of equal distances in the unstable sort before the prune
+ *     (:2025-2033, slices.SortFunc): restated as (distance, id).
+ * The id quirk of :1620 is restated as written: startID = nodeCounter.Add(n) - n is the id of the LAST node inserted
+ * before the batch (Add numbers nodes from 1, :590), so the batch's first node takes over that slot -- new vector, new
+ * level, empty Connections; links that pointed at the old node now point at the new one -- and the last reserved id
+ * stays without a node.  Returns startID, or 0 when the batch took the sequential path (:1505-1516).                */
+typedef struct { uint32_t target; int level; uint32_t nb; } orc_linkreq;
+static int linkreq_cmp(const void *a, const void *b) {
+    const orc_linkreq *x = (const orc_linkreq *)a, *y = (const orc_linkreq *)b;
+    if (x->target != y->target) return x->target < y->target ? -1 : 1;
+    if (x->level != y->level) return x->level < y->level ? -1 : 1;
+    if (x->nb != y->nb) return x->nb < y->nb ? -1 : 1;
+    return 0;
+}
+static int cand_cmp_dist_id(const void *a, const void *b) {
+    const orc_cand *x = (const orc_cand *)a, *y = (const orc_cand *)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    if (x->id != y->id) return x->id < y->id ? -1 : 1;
+    return 0;
+}
+
+ORC_EXPORT uint32_t orc_index_add_batch(orc_index *h, const float *vecs, uint32_t n, int ef_const, const int *forced_levels) {
+    if (n == 0) return 0;
+    const size_t dim = (size_t)h->dim;
+    if (ef_const <= 0) ef_const = h->efc;
+    if (h->counter < (uint32_t)ef_const) { /* small graph: one Add per object, :1505-1516 */
+        for (uint32_t i = 0; i < n; i++) (void)orc_index_add(h, vecs + (size_t)i * dim, forced_levels ? forced_levels[i] : -1);
+        return 0;
+    }
+    if (h->precision == ORC_I8 && h->absmax == 0.0f) h->absmax = orc_quantizer_train(vecs, n, dim); /* phase 0.A, :1521-1535 */
+    /* phase 1A: ids (:1620-1622), first-batch entry point (:1634-1638; unreachable: counter >= efConst > 0) */
+    const uint32_t start = h->counter;
+    h->counter += n;
+    index_grow(h, h->counter);
+    if (h->max_level == -1) { h->entry = start; h->max_level = 0; }
+    /* phase 1B: nodes, in order (:1665-1755) */
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t id = start + i;
+        orc_node *nd = &h->nodes[id];
+        for (int l = 0; l < nd->nlevels; l++) free(nd->conn[l].ids); /* a fresh Node replaces whatever held the slot */
+        free(nd->conn);
+        nd->conn = NULL;
+        nd->nlevels = 0;
+        nd->deleted = 0;
+        store_vector(h, id, vecs + (size_t)i * dim);
+        int level = forced_levels ? forced_levels[i] : random_level(h);
+        if (level > h->max_level + 1) level = h->max_level + 1; /* randomLevel's own cap, :2620-2623 */
+        node_ensure_levels(nd, level + 1);
+    }
+    /* phase 1: every new node searches the frozen graph (:1766-1855) */
+    const uint32_t ep0 = h->entry, max_id = h->counter;
+    const int cur_max = h->max_level;
+    size_t nreq = 0, capreq = (size_t)n * (size_t)ef_const * 2 + 16;
+    orc_linkreq *req = (orc_linkreq *)malloc(capreq * sizeof(orc_linkreq));
+    orc_cand *cands = (orc_cand *)malloc((size_t)(ef_const + 1) * sizeof(orc_cand));
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t id = start + i;
+        orc_query q;
+        make_query_from_row(h, id, &q);
+        const int node_level = h->nodes[id].nlevels - 1;
+        uint32_t ep = ep0;
+        for (int l = cur_max; l > node_level; l--) { /* :1821-1826 */
+            int c = search_layer(h, &q, ep, 1, l, NULL, 1, max_id, cands, ef_const);
+            if (c > 0) ep = cands[0].id;
+        }
+        for (int l = node_level < cur_max ? node_level : cur_max; l >= 0; l--) { /* :1829-1851 */
+            int c = search_layer(h, &q, ep, ef_const, l, NULL, ef_const, max_id, cands, ef_const);
+            if (c <= 0) continue;
+            if (nreq + 2 * (size_t)c > capreq) {
+                capreq = (nreq + 2 * (size_t)c) * 2;
+                req = (orc_linkreq *)realloc(req, capreq * sizeof(orc_linkreq));
+            }
+            for (int e = 0; e < c; e++) { /* phase 2 (:1864-1890): the direct request and one reverse request per candidate */
+                req[nreq].target = id; req[nreq].level = l; req[nreq].nb = cands[e].id; nreq++;
+                req[nreq].target = cands[e].id; req[nreq].level = l; req[nreq].nb = id; nreq++;
+            }
+            ep = cands[0].id;
+        }
+    }
+    /* phase 3: per target node, per level (:1902-2060) */
+    qsort(req, nreq, sizeof(orc_linkreq), linkreq_cmp);
+    uint32_t *uniq = (uint32_t *)malloc(((size_t)h->mmax0 + (size_t)n * 2 + (size_t)ef_const + 16) * 4 + nreq * 0);
+    size_t ucap = (size_t)h->mmax0 + (size_t)n * 2 + (size_t)ef_const + 16;
+    orc_cand *pc = NULL, *ps = NULL;
+    size_t pcap = 0;
+    for (size_t a = 0; a < nreq;) {
+        const uint32_t t = req[a].target;
+        size_t b = a;
+        while (b < nreq && req[b].target == t) b++;
+        orc_node *tn = &h->nodes[t];
+        if (t == 0 || t > h->counter || tn->nlevels == 0 || tn->deleted) { a = b; continue; } /* nil or deleted node, :1927-1930 */
+        for (size_t c = a; c < b;) {
+            const int lvl = req[c].level;
+            size_t d = c;
+            while (d < b && req[d].level == lvl) d++;
+            const uint32_t ncur = lvl < tn->nlevels ? tn->conn[lvl].len : 0;
+            const size_t need = (size_t)ncur + (d - c) + 1;
+            if (need > ucap) { ucap = need * 2; uniq = (uint32_t *)realloc(uniq, ucap * 4); }
+            size_t nu = 0;
+            for (uint32_t e = 0; e < ncur; e++) uniq[nu++] = tn->conn[lvl].ids[e];
+            for (size_t e = c; e < d; e++) uniq[nu++] = req[e].nb;
+            /* slices.Sort + in-place de-duplication without the node itself (:1983-2003) */
+            for (size_t i2 = 1; i2 < nu; i2++) { /* insertion sort: lists are short and mostly sorted */
+                uint32_t x = uniq[i2];
+                size_t j = i2;
+                while (j > 0 && uniq[j - 1] > x) { uniq[j] = uniq[j - 1]; j--; }
+                uniq[j] = x;
+            }
+            size_t nq = 0;
+            for (size_t i2 = 0; i2 < nu; i2++)
+                if (uniq[i2] != t && (nq == 0 || uniq[nq - 1] != uniq[i2])) uniq[nq++] = uniq[i2];
+            const int maxm = lvl == 0 ? h->mmax0 : h->m;
+            node_ensure_levels(tn, lvl + 1); /* :2047-2051 */
+            if ((int)nq <= maxm) { /* :2011-2013: the union as it is -- ascending ids */
+                list_set(&tn->conn[lvl], uniq, (uint32_t)nq);
+            } else { /* prune (:2015-2040) */
+                if (nq + 1 > pcap) {
+                    pcap = (nq + 1) * 2;
+                    pc = (orc_cand *)realloc(pc, pcap * sizeof(orc_cand));
+                    ps = (orc_cand *)realloc(ps, pcap * sizeof(orc_cand));
+                }
+                int np = 0;
+                for (size_t i2 = 0; i2 < nq; i2++) {
+                    const uint32_t x = uniq[i2];
+                    if (x >= 1 && x <= h->counter && h->nodes[x].nlevels > 0 && !h->nodes[x].deleted) {
+                        pc[np].id = x;
+                        pc[np].dist = node_node(h, t, x);
+                        np++;
+                    }
+                }
+                qsort(pc, (size_t)np, sizeof(orc_cand), cand_cmp_dist_id);
+                const int nsel = select_neighbors(h, pc, np, maxm, ps);
+                for (int e = 0; e < nsel; e++) uniq[e] = ps[e].id;
+                list_set(&tn->conn[lvl], uniq, (uint32_t)nsel);
+            }
+            c = d;
+        }
+        a = b;
+    }
+    /* phase 4: entry point / maxLevel (:2066-2080) */
+    for (uint32_t i = 0; i < n; i++) {
+        const int l = h->nodes[start + i].nlevels - 1;
+        if (l > h->max_level) { h->max_level = l; h->entry = start + i; }
+    }
+    free(req); free(cands); free(uniq); free(pc); free(ps);
+    return start;
+}
+
+/* selectNeighbors on a caller-supplied candidate list (ids of stored nodes, distances to the centre, in the order
+ * given): what the tests feed to both the oracle and the GPU's build_select_kernel.  Returns the count.           */
+ORC_EXPORT int orc_select_neighbors(orc_index *h, const uint32_t *ids, const double *dist, int n, int m, uint32_t *out_ids) {
+    orc_cand *in = (orc_cand *)malloc((size_t)(n + 1) * sizeof(orc_cand)), *out = (orc_cand *)malloc((size_t)(n + 1) * sizeof(orc_cand));
+    for (int i = 0; i < n; i++) { in[i].id = ids[i]; in[i].dist = dist[i]; }
+    const int r = select_neighbors(h, in, n, m, out);
+    for (int i = 0; i < r; i++) out_ids[i] = out[i].id;
+    free(in); free(out);
+    return r;
 }
 
 /* hnsw_index.go:369-468 searchInternal + :343-366 SearchWithScores.

@@ -86,6 +86,10 @@ def lib():
     L.orc_index_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_index_add.restype = C.c_uint32
     L.orc_index_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_index_add_batch.restype = C.c_uint32
+    L.orc_index_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.orc_select_neighbors.restype = C.c_int
+    L.orc_select_neighbors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.orc_search.restype = C.c_int
     L.orc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                              C.c_void_p, C.c_void_p, C.POINTER(Counters)]
@@ -197,6 +201,20 @@ class OracleIndex:
         vecs = np.ascontiguousarray(vecs, dtype=np.float32)
         for i in range(vecs.shape[0]):
             self.L.orc_index_add(self.h, vecs[i].ctypes.data_as(C.c_void_p), -1)
+
+    def add_batch(self, vecs, ef_const=0, levels=None):
+        """addBatchInternal (hnsw_index.go:1479-2088), single worker; returns startID (0 = sequential path taken)"""
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
+        return int(self.L.orc_index_add_batch(self.h, _p(vecs), vecs.shape[0], int(ef_const), _p(lv)))
+
+    def select_neighbors(self, ids, dist, m):
+        """selectNeighbors (hnsw_index.go:2629-2701) over a caller-supplied candidate list"""
+        ii = np.ascontiguousarray(ids, dtype=np.uint32)
+        dd = np.ascontiguousarray(dist, dtype=np.float64)
+        out = np.zeros(max(ii.size, 1), dtype=np.uint32)
+        n = self.L.orc_select_neighbors(self.h, _p(ii), _p(dd), ii.size, int(m), _p(out))
+        return out[:n].copy()
 
     def mark_deleted(self, id_):
         self.L.orc_index_mark_deleted(self.h, id_)

@@ -26,8 +26,10 @@ struct FakeIndex {
     }
     std::vector<std::vector<kektor::SearchResult>> FlatScanBatch(const float *q, uint32_t B, int k, const kektor::AllowList *) {
         flat_calls++;
+        if (k > 128 || refuse_flat) throw kektor::Error(KDB_ERR_INVALID, "flat scan: k must be in 1..128"); // as kdb_flat_scan_batch does
         return answer(q, B, k, -1);
     }
+    std::atomic<bool> refuse_flat{false};
 };
 
 int main() {
@@ -60,6 +62,19 @@ int main() {
     const auto st = mb.stats();
     if (st.calls != 24 * 60 || st.batches >= st.calls || st.largest > 16 || st.flatBatches == 0) bad++;
     if (idx.calls.load() + idx.flat_calls.load() != (int)st.batches) bad++;
+    // a selective filter with k > 128 must still be answered (by the walk: the exact scan takes k <= 128), and a scan that
+    // refuses its arguments falls back to the walk instead of returning []
+    {
+        std::vector<float> q(8, 0.f);
+        q[0] = 7.f;
+        const int before_flat = idx.flat_calls.load();
+        auto r = mb.SearchWithScores(q, 200, &narrow, 64);
+        if (r.size() != 200 || r[0].Score != 64.0 || idx.flat_calls.load() != before_flat) bad++;
+        idx.refuse_flat = true;
+        r = mb.SearchWithScores(q, 5, &narrow, 33);
+        if (r.size() != 5 || r[0].Score != 33.0) bad++;
+        idx.refuse_flat = false;
+    }
     // Stop() releases callers that are still waiting for company, later calls return []
     std::vector<std::thread> late;
     std::atomic<int> empty{0};

@@ -88,6 +88,17 @@ int main() {
                         (unsigned long long)st.batches, (unsigned long long)st.largest, (unsigned long long)st.flatBatches);
             bad++;
         }
+        // k > 128 under a selective filter: the exact scan does not take it, the walk answers (never [] where the
+        // reference answers); with a wide filter the walk fills all 200 places
+        {
+            std::vector<float> qq(X.begin() + dim, X.begin() + 2 * dim);
+            auto narrow = mb.SearchWithScores(qq, 200, &few, 300);
+            auto direct = idx.SearchWithScores(qq, 200, &few, 300);
+            if (narrow.empty() || narrow.size() != direct.size()) bad++;
+            for (size_t j = 0; j < narrow.size() && j < direct.size(); j++)
+                if (narrow[j].DocID != direct[j].DocID) bad++;
+            if (mb.SearchWithScores(qq, 200, &allow, 300).size() != 200) bad++;
+        }
         if (!mb.SearchWithScores(std::vector<float>(3, 0.f), 5, nullptr, 10).empty()) bad++; // wrong width -> []
         mb.Stop();
         if (!mb.SearchWithScores(q, 5, nullptr, 10).empty()) bad++; // stopped batcher -> []

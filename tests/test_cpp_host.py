@@ -51,6 +51,11 @@ def test_micro_batcher_logic_under_thread_sanitizer(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+        # the sanitizer runtime cannot place its shadow under this kernel's address-space randomisation: retry without it
+        r = subprocess.run(["setarch", "-R", exe], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert r.stdout.startswith("ok"), r.stdout
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]

@@ -188,3 +188,101 @@ def test_incremental_refresh_matches_full_upload(oracle, hip, metric):
         idx.patch_adjacency(0, [n1 + n2 + 5], [[1]])
     with pytest.raises(Exception):
         idx.patch_adjacency(0, [1], [list(range(1, 40))])   # longer than mMax0 = 16
+
+
+@pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1)])
+def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
+    """a13: identical candidate lists -> identical selections.  The GPU builder's selectNeighbors (build_select_kernel's
+    workgroup routine, through the kdb_test_select_neighbors hook) against the oracle's select_neighbors
+    (hnsw_index.go:2629-2701): lists shorter than m (returned as they are), lists that fill m on the heuristic alone, lists
+    that need the back-fill from the discarded, 32-candidate block boundaries, m = 16 and 32.  Candidate distances to the
+    centre come from the library's own distance kernel (the values the search hands the builder) on both sides; the pair
+    distances the heuristic compares are summed in another order by the two sides, so a list may only differ where some
+    d(e, r) ties with d(e, centre) to within that rounding -- checked, not assumed."""
+    O = oracle
+    rng = np.random.default_rng(61)
+    n, dim = 3000, 96
+    X = make_corpus(n, dim, "clustered", seed=62).astype(np.float32)
+    if prec == O.F16:
+        X = X * 0.25
+    orc = O.OracleIndex(dim, metric, prec, 16, 64, seed=5)
+    orc.add_many(X)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rows = orc.rows()
+    idx = hip.HipIndex(dim, metric, prec, 16, 64, capacity=n + 8)
+    idx.upload_rows(rows[1:], 1)
+    idx.set_count(n)
+    stored = rows[1:].astype(np.float32) if prec == O.F16 else rows[1:]
+    lens = [5, 16, 31, 32, 33, 64, 100, 200, 300, 17, 90, 257]
+    n_lists = len(lens) * 4
+    stride = 320
+    cand = np.zeros((n_lists, stride), np.uint32)
+    keys = np.zeros((n_lists, stride), np.float32)
+    cnt = np.zeros(n_lists, np.uint32)
+    centres, dists = [], []
+    for t in range(n_lists):
+        L = lens[t % len(lens)]
+        c = int(rng.integers(1, n + 1))
+        # half of the lists: the centre's true neighbourhood (where the heuristic really prunes); half: random nodes
+        if t % 2 == 0:
+            d = ((stored - stored[c - 1]) ** 2).sum(1) if metric == 0 else -(stored @ stored[c - 1])
+            pool = np.argsort(d)[1:L + 1] + 1
+        else:
+            pool = rng.choice(np.setdiff1d(np.arange(1, n + 1), [c]), L, replace=False)
+        q = stored[c - 1]
+        raw = idx.distance_batch(q[None, :], pool[None, :].astype(np.uint32), prepared=True)[0]  # L2 sum / dot, wave order
+        key = raw if metric == 0 else -raw
+        order = np.lexsort((pool, key))
+        cand[t, :L], keys[t, :L], cnt[t] = pool[order], key[order], L
+        centres.append(c)
+        dists.append(np.array([idx.score(r) for r in raw[order]], dtype=np.float64))
+    for m in (16, 32):
+        got, gc = idx.test_select_neighbors(cand, keys, cnt, m)
+        for t in range(n_lists):
+            L = int(cnt[t])
+            want = orc.select_neighbors(cand[t, :L], dists[t], m)
+            g = got[t, :int(gc[t])]
+            if np.array_equal(g, want):
+                continue
+            # a difference is acceptable only next to a rounding-level tie between a pair distance and a centre distance
+            P = stored[cand[t, :L].astype(np.int64) - 1].astype(np.float64)
+            pd = ((P[:, None, :] - P[None, :, :]) ** 2).sum(2) if metric == 0 else 1.0 - P @ P.T
+            gap = np.abs(pd - dists[t][:, None])
+            assert (gap < 1e-5 * (1.0 + np.abs(dists[t][:, None]))).any(), (metric, prec, m, t, g, want)
+
+
+def test_gpu_builder_vs_restated_batch_insert(oracle, hip):
+    """f2: the GPU builder follows addBatchInternal's phases but links differently (reverse requests only to the neighbours
+    a node KEEPS, at most 16 requests per target and round, requesters appended in id order instead of the sorted union --
+    DESIGN section 5.4).  A/B on the same stored rows, both graphs searched by the same HIP kernel: the GPU-built graph must
+    not be worse than the graph the restated reference batch path (oracle add_batch, hnsw_index.go:1479-2088) builds."""
+    O = oracle
+    rng = np.random.default_rng(1)
+    n, dim, efc, k = 10000, 64, 100, 10
+    X = rng.random((n, dim), dtype=np.float32)
+    Q = rng.random((256, dim), dtype=np.float32)
+    orc = O.OracleIndex(dim, O.L2, O.F32, 16, efc, seed=3)
+    orc.add_many(X[:200])
+    for s in range(200, n, 400):
+        orc.add_batch(X[s:s + 400], efc)
+    cnt = orc.count - 1                      # the last reserved id holds no node (:1620)
+    g = orc.export_graph()
+    assert int(g.levels[cnt + 1]) == 0
+    rows = orc.rows()[1:cnt + 1]
+    exact = np.argsort(((rows[None, :, :] - Q[:, None, :]) ** 2).sum(2), axis=1)[:, :k] + 1
+    ref = hip.HipIndex(dim, 0, 0, 16, efc, capacity=cnt + 8)
+    ref.upload_rows(orc.rows()[1:], 1)
+    ref.upload_graph_obj(g)
+    gpu = hip.HipIndex(dim, 0, 0, 16, efc, capacity=cnt + 8)
+    gpu.upload_rows(rows, 1)
+    gpu.build(cnt, batch=400, ef_construction=efc, seed=3)
+    out = {}
+    for ef in (20, 50, 100):
+        r = []
+        for idx in (ref, gpu):
+            ids, _, c = idx.search_batch(Q, k, ef)
+            r.append(np.mean([len(set(ids[b, :int(c[b])].tolist()) & set(exact[b].tolist())) / k for b in range(Q.shape[0])]))
+        out[ef] = r
+        assert r[1] >= r[0] - 0.02, out
+    assert out[100][1] >= 0.9, out
+    print("recall@10 (restated batch path, GPU builder):", out)
