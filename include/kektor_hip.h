@@ -23,6 +23,8 @@
  *   kdb_index_build         addBatchInternal (hnsw_index.go:1479-2088), phases 1-4, on the GPU
  *   kdb_merge_topk          the merge step of the id-range shard (no reference
  *                           counterpart -- the reference is single process)
+ *   kdb_sharded_search_batch  the same path over every GPU of a node from ONE process: fan-out,
+ *                           one RCCL all-gather of the per-shard top-k, merge
  *
  * Conventions (mirroring native/compute's embedder half, native/compute/src/embedder.rs:33-63):
  *   - every function returns 0 on success and a negative kdb_status on failure; the message for the
@@ -262,6 +264,27 @@ KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t 
 KDB_API int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_packed,
                               uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
                               float *d_out_dist, uint32_t *d_out_count, void *stream);
+
+/* ---- the id-range shards of one node behind one handle (single-process callers: the Go shim) ------------------------
+ * shards[g]: an index created on its device (kdb_index_desc.device_id) that owns the global ids id_base[g]+1 ...
+ * id_base[g]+count_g (local id i <-> global id id_base[g]+i); bases ascend, shards of one device are consecutive and
+ * every device holds the same number.  The cluster borrows the handles (destroy it before them).
+ * kdb_sharded_search_batch = SearchWithScores over the whole corpus: the batch visits every shard (each on its own
+ * GPU), ONE RCCL all-gather of the per-shard top-k blocks over xGMI, merge under the total order (distance, global id).
+ * allow_bits: NULL or a dense bitset over GLOBAL ids (allow_words uint64 words), sliced per shard by the library; the
+ * per-shard semantics are those of kdb_search_batch (a list that allows nothing in a shard yields nothing from it).
+ * Host pointers; ids returned are global.  kdb_sharded_flat_scan_batch: the exact scan, same exchange.
+ * RCCL (librccl.so.1) is loaded at the first kdb_cluster_create.                                                 */
+typedef struct kdb_cluster kdb_cluster;
+KDB_API int kdb_cluster_create(kdb_index *const *shards, const uint32_t *id_base, uint32_t n_shards, kdb_cluster **out);
+KDB_API void kdb_cluster_destroy(kdb_cluster *c);
+KDB_API int kdb_cluster_info(const kdb_cluster *c, uint32_t *n_shards, uint32_t *n_devices, uint32_t *shards_per_device);
+KDB_API int kdb_sharded_search_batch(kdb_cluster *c, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                     const uint64_t *allow_bits, uint64_t allow_words, uint32_t flags, uint32_t *out_ids,
+                                     float *out_dist, uint32_t *out_count);
+KDB_API int kdb_sharded_flat_scan_batch(kdb_cluster *c, const float *queries, uint32_t B, uint32_t k,
+                                        const uint64_t *allow_bits, uint64_t allow_words, uint32_t flags, uint32_t *out_ids,
+                                        float *out_dist, uint32_t *out_count);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each

@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
     "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
-    "kdb_index_sync", "kdb_test_select_neighbors",
+    "kdb_index_sync", "kdb_test_select_neighbors", "kdb_cluster_create", "kdb_cluster_destroy", "kdb_cluster_info",
+    "kdb_sharded_search_batch", "kdb_sharded_flat_scan_batch",
 ]
 
 
@@ -117,6 +118,13 @@ def load():
     L.kdb_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.kdb_get_launch_stats.argtypes = [vp, u32, C.POINTER(Counters)]
     L.kdb_index_sync.argtypes = [vp]
+    L.kdb_test_select_neighbors.argtypes = [vp, u32, u32, vp, vp, vp, u32, vp, vp]
+    L.kdb_cluster_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.kdb_cluster_destroy.argtypes = [vp]
+    L.kdb_cluster_destroy.restype = None
+    L.kdb_cluster_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.kdb_sharded_search_batch.argtypes = [vp, vp, u32, u32, u32, vp, C.c_uint64, u32, vp, vp, vp]
+    L.kdb_sharded_flat_scan_batch.argtypes = [vp, vp, u32, u32, vp, C.c_uint64, u32, vp, vp, vp]
     _lib = L
     return L
 
