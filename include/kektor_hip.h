@@ -65,7 +65,8 @@ typedef enum {
     KDB_ERR_HIP = -3,       /* a HIP runtime call failed */
     KDB_ERR_OOM = -4,
     KDB_ERR_STATE = -5,     /* e.g. search before a graph was uploaded */
-    KDB_ERR_UNSUPPORTED = -6
+    KDB_ERR_UNSUPPORTED = -6,
+    KDB_ERR_DIVERGED = -7   /* KDB_SEARCH_FAIL_ON_DROP: answers delivered, but a walk was not the reference's step for step */
 } kdb_status;
 
 enum { KDB_METRIC_L2 = 0, KDB_METRIC_COSINE = 1 };       /* distance.Euclidean / distance.Cosine */
@@ -75,7 +76,11 @@ enum { KDB_PREC_F32 = 0, KDB_PREC_F16 = 1, KDB_PREC_I8 = 2 }; /* arena.go:73-77 
 enum {
     KDB_SEARCH_STRICT = 0,            /* one candidate expanded per step: the reference's best-first order */
     KDB_SEARCH_NEEDS_REFINE = 1u << 0, /* apply the needsRefine ef boost (hnsw_index.go:387-399)            */
-    KDB_SEARCH_PREPARED = 1u << 1      /* queries are already in stored form (normalised); skip query prep  */
+    KDB_SEARCH_PREPARED = 1u << 1,     /* queries are already in stored form (normalised); skip query prep  */
+    KDB_SEARCH_FAIL_ON_DROP = 1u << 2  /* kdb_search_batch (host pointers) only: return KDB_ERR_DIVERGED when a walk had to discard  *
+                                        * pending traversal-only candidates (more than 2047 soft-deleted nodes waiting at once:       *
+                                        * kdb_counters.n_dropped > 0), i.e. when some answer may differ from the reference's walk.    *
+                                        * The outputs are still filled.  Without the flag the count is only reported.                */
 };
 
 typedef struct kdb_index kdb_index;

@@ -906,10 +906,21 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);
     if (lane.rc) return lane.rc;
-    return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
-                          [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
-                              return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                          });
+    int rc = with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
+                            [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
+                                return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
+                            });
+    if (rc == KDB_OK && (flags & KDB_SEARCH_FAIL_ON_DROP) && idx->n_deleted > 2047u && idx->launch_seq > 0 && idx->last_kind == 1) {
+        // (the call is complete: with_staged_io synchronised the stream)
+        unsigned long long c[4] = {0, 0, 0, 0};
+        KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)((idx->launch_seq - 1) % kdb_index::RING) * 4, 32, hipMemcpyDeviceToHost));
+        if (c[3]) {
+            kdb_set_error("search: %llu pending traversal-only candidates were discarded (more than 2047 deleted nodes waiting in one "
+                          "walk): answers may differ from the reference's", c[3]);
+            return KDB_ERR_DIVERGED;
+        }
+    }
+    return rc;
 }
 
 extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device) {

@@ -210,8 +210,10 @@ class HipIndex:
     def _flags(self, prepared=False):
         return (SEARCH_NEEDS_REFINE if self.needs_refine else 0) | (SEARCH_PREPARED if prepared else 0)
 
-    def search_batch(self, queries, k: int, ef: int = 0, allow_bits=None, trace: bool = False, prepared=False):
-        """B queries -> (ids [B,k] u32, raw dist [B,k] f32, count [B] u32[, (n_dist[B], n_hops[B])])."""
+    def search_batch(self, queries, k: int, ef: int = 0, allow_bits=None, trace: bool = False, prepared=False,
+                     fail_on_drop: bool = False):
+        """B queries -> (ids [B,k] u32, raw dist [B,k] f32, count [B] u32[, (n_dist[B], n_hops[B])]).
+        fail_on_drop: KDB_SEARCH_FAIL_ON_DROP -- raise KdbError (status -7) when a walk discarded pending deleted candidates"""
         self._live()
         q = np.ascontiguousarray(queries, dtype=np.float32)
         assert q.ndim == 2 and q.shape[1] == self.dim
@@ -226,8 +228,8 @@ class HipIndex:
             nh = np.zeros(B, dtype=np.uint32)
             check(self.L.kdb_search_set_trace(self.h, _ptr(nd), _ptr(nh), 0), "set_trace")
         try:
-            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared), _ptr(ids),
-                                          _ptr(dist), _ptr(cnt)), "kdb_search_batch")
+            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared) | (4 if fail_on_drop else 0),
+                                          _ptr(ids), _ptr(dist), _ptr(cnt)), "kdb_search_batch")
         finally:
             if trace:
                 self.L.kdb_search_set_trace(self.h, None, None, 0)

@@ -922,3 +922,67 @@ def test_flat_scan_batch_larger_than_one_launch(oracle, hip, prec, metric):
         else:
             assert np.array_equal(ids[b, :k], oi), b
             assert np.array_equal(raw_to_score(idx, dist[b, :k]), od), b
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_duplicate_vectors_at_the_ef_boundary(oracle, hip, metric):
+    """96 identical rows next to every query, with ef and k cutting through the block.  The reference pops equal distances in
+    container/heap order, the beam orders them by id: WHICH copies are returned may differ, their distances may not -- the
+    returned distance multiset must equal the oracle's, every returned id must be a real neighbour at that distance, and
+    the exact scan (total order distance, id) must match the oracle id for id."""
+    O = oracle
+    rng = np.random.default_rng(71)
+    n, dim, k = 4000, 48, 20
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    base = rng.standard_normal(dim).astype(np.float32)
+    dup = rng.choice(n, 96, replace=False)
+    X[dup] = base[None, :]
+    Q = (base[None, :] + 0.02 * rng.standard_normal((40, dim))).astype(np.float32)
+    orc, idx = build_pair(O, hip, X, metric, efc=60)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rows = orc.rows()
+    for ef in (20, 50, 130):
+        ids, dist, cnt = idx.search_batch(Q, k, ef)
+        for b in range(Q.shape[0]):
+            oi, od = orc.search(Q[b], k, ef=ef)
+            c = int(cnt[b])
+            got_d = raw_to_score(idx, dist[b, :c])
+            assert c == len(oi)
+            assert np.array_equal(np.sort(got_d), np.sort(od)), (metric, ef, b)          # same distance multiset
+            chk = orc.distances(Q[b], ids[b, :c])                                          # ... and honest ids
+            assert np.array_equal(chk, got_d), (metric, ef, b)
+            assert len(set(ids[b, :c].tolist())) == c
+    fi, fd, fc = idx.flat_scan_batch(Q, k)
+    for b in range(Q.shape[0]):
+        oi, od = orc.flat_scan(Q[b], k)
+        assert np.array_equal(fi[b, :int(fc[b])], oi) and np.array_equal(raw_to_score(idx, fd[b, :int(fc[b])]), od)
+        assert np.isin(fi[b, :k], dup + 1).all()                                            # the block fills the top-k
+
+
+def test_dropped_candidates_are_reported(oracle, hip):
+    """more than 2047 soft-deleted nodes can be pending in one walk: the side list then discards its farthest entries, the
+    walk may differ from the reference's, kdb_counters.n_dropped says so, and KDB_SEARCH_FAIL_ON_DROP turns that into
+    KDB_ERR_DIVERGED (-7) on the host-pointer entry point while the outputs are still delivered.  (Only bottom-layer
+    nodes are deleted: with the upper layers emptied the reference's descent itself returns [], hnsw_index.go:450-468.)"""
+    n, dim, k, ef = 12000, 16, 10, 300
+    X = make_corpus(n, dim, "normal", seed=77)
+    rng = np.random.default_rng(78)
+    idx = hip.HipIndex(dim, 0, 0, 16, 40, capacity=n + 8)
+    idx.upload_rows(X, 1)
+    idx.build(n, batch=512, ef_construction=40, seed=3)
+    levels = idx.download_graph()[3]
+    lvl0 = np.nonzero(levels[1:n + 1] == 0)[0] + 1
+    deleted = rng.choice(lvl0, lvl0.size - 300, replace=False)
+    idx.Delete(deleted.tolist())
+    Q = make_corpus(32, dim, "normal", seed=79)
+    ids, dist, cnt = idx.search_batch(Q, k, ef)                     # no flag: answers, and the count says what happened
+    assert np.all(cnt == k) and not (set(ids.flatten().tolist()) & set(deleted.tolist()))
+    assert idx.counters()["n_dropped"] > 0
+    with pytest.raises(hip.KdbError) as e:
+        idx.search_batch(Q, k, ef, fail_on_drop=True)
+    assert "status -7" in str(e.value) and "discarded" in str(e.value)
+    # a walk that stays below the limit is the reference's, and the flag changes nothing
+    a = idx.search_batch(Q, k, 40, fail_on_drop=True)
+    assert idx.counters()["n_dropped"] == 0
+    b = idx.search_batch(Q, k, 40)
+    assert np.array_equal(a[0], b[0])
