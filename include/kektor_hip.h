@@ -239,6 +239,16 @@ KDB_API int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t B,
 KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids,
                            uint32_t C, uint32_t flags, float *d_out, void *stream);
 
+/* DB.Compress (pkg/core/core.go:1128-1290) on the device: a new index of `precision` (KDB_PREC_F16 / KDB_PREC_I8) from a
+ * float32 one, rows never leaving HBM.  int8: Quantizer.Train (quantizer.go:49-135: strided sample, 99.9th percentile of
+ * |v|, found exactly by a radix select), Quantize and the stored norms for every row; float16: RNE conversion.  The new
+ * index keeps the float32 index's GRAPH (ids, links, deleted bits) unless KDB_COMPRESS_REBUILD_GRAPH asks the GPU builder
+ * to re-insert every row with the new precision's distances, which is what the reference's AddBatch loop does (float16
+ * only).  The source is left as it is; the caller owns *out (kdb_index_destroy).                                   */
+#define KDB_COMPRESS_REBUILD_GRAPH 1u
+KDB_API int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t flags, kdb_index **out);
+KDB_API int kdb_index_get_quantizer(kdb_index *idx, float *abs_max);
+
 /* GPU batched graph construction over rows 1..count already uploaded.                             */
 KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
 

@@ -425,6 +425,13 @@ extern "C" int kdb_index_set_quantizer(kdb_index *idx, float abs_max) {
     return KDB_OK;
 }
 
+extern "C" int kdb_index_get_quantizer(kdb_index *idx, float *abs_max) {
+    KDB_CHECK_IDX(idx);
+    if (!abs_max) return KDB_ERR_INVALID;
+    *abs_max = idx->absmax;
+    return KDB_OK;
+}
+
 extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
     KDB_CHECK_IDX(idx);
     if (count > idx->cap) {

@@ -90,6 +90,24 @@ class HipIndex:
         if self._closed:
             raise KdbError("index is closed")
 
+    def Compress(self, precision: int, rebuild_graph: bool = False) -> "HipIndex":
+        """DB.Compress (pkg/core/core.go:1128-1290) on the device: a NEW index of `precision` (F16 / I8) from this
+        float32 one -- quantizer trained and rows converted in HBM; the graph is kept, or rebuilt by the GPU builder
+        (float16 only) when rebuild_graph is set."""
+        self._live()
+        h = C.c_void_p()
+        check(self.L.kdb_index_compress(self.h, int(precision), 1 if rebuild_graph else 0, C.byref(h)), "kdb_index_compress")
+        new = HipIndex.__new__(HipIndex)
+        new.L, new.dim, new.metric, new.precision = self.L, self.dim, self.metric, int(precision)
+        new.m, new.ef_construction, new.capacity, new.device_id = self.m, self.ef_construction, self.capacity, self.device_id
+        new.needs_refine, new.h, new._closed = False, h, False
+        return new
+
+    def quantizer_absmax(self) -> float:
+        a = C.c_float()
+        check(self.L.kdb_index_get_quantizer(self.h, C.byref(a)), "kdb_index_get_quantizer")
+        return float(a.value)
+
     # ---- population ------------------------------------------------------------------------------
     def upload_rows(self, rows, first_id: int = 1):
         """rows: (n, dim) array already in STORED form (see kdb_index_upload_rows) or a torch device tensor."""
