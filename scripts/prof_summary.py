@@ -16,11 +16,12 @@ def kernel_stats(db):
     print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for n, c, s, a, mn, mx in rows[:14]:
         print(f"{short(n):72s} {c:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
-    for pat in ("hnsw_search_kernel", "flat_scan_kernel"):
+    for pat in ("hnsw_search_kernel", "flat_scan_big_kernel"):
         d = [r[0] for r in cur.execute("select duration from kernels where name like ? order by start", (f"%{pat}%",))]
         if d:
             last = d[-20:]
-            print(f"# {pat}: last {len(last)} launches (the timed steps) avg {sum(last)/len(last)/1e3:.2f} us; all: " + " ".join(f"{x/1e3:.0f}" for x in d))
+            print(f"# {pat}: last {len(last)} launches (the timed steps) avg {sum(last)/len(last)/1e3:.2f} us; the last 30 of {len(d)}: "
+                  + " ".join(f"{x/1e3:.0f}" for x in d[-30:]))
 
 def pmc_stats(db):
     con = sqlite3.connect(db); cur = con.cursor()
