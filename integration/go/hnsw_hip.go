@@ -1,3 +1,6 @@
+// UNTESTED SKETCH: no Go toolchain exists in the build image, nothing compiles or runs this file.  The routing rules
+// below are those of kektor::hnsw::MicroBatcher (include/kektor_hip.hpp), which is compiled, sanitised and run on the GPU.
+
 //go:build hip
 
 // hnsw_hip.go -- the binding a KektorDB maintainer adds to package hnsw to route SearchWithScores through
