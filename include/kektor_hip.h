@@ -31,7 +31,11 @@
  *     calling thread is available from kdb_last_error(); nothing throws or unwinds across the ABI;
  *   - the caller owns every buffer it passes; host inputs are consumed before the call returns
  *     (cgo rule: Go memory need not stay pinned after the call);
- *   - handles are opaque, usable from any thread, calls on one handle are serialised internally;
+ *   - handles are opaque, usable from any thread; calls on one handle are serialised internally (the enqueue: the *_dev
+ *     entry points are asynchronous on the stream they are given).  An index keeps two sets of per-call scratch: a *_dev
+ *     call on a stream other than the one that last used its set first waits -- on the device -- for that use, so two
+ *     streams run concurrently without sharing scratch and any number of streams is SAFE.  Uploads, kdb_index_mark_deleted
+ *     and kdb_index_set_entry are snapshots for kernels that were already launched;
  *   - ids are the reference's internal ids: uint32, 1-based, id 0 never names a vector
  *     (hnsw_index.go:590); at most 2^30-1 ids per index;
  *   - distances are returned as the RAW f32 accumulate: sum (q-x)^2 for KDB_METRIC_L2, the dot

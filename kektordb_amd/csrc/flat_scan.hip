@@ -75,6 +75,8 @@ struct FsParams {
     // big-tile ranking kernel (flat_scan_big.cuh): rows per tile (0 = FS_TR), and the blockIdx -> (query tile, stripe) map:
     // query tiles of 256, split into fb_nqg groups of fb_nqx tiles; an XCD serves one group with fb_spx stripes
     uint32_t tile_rows, fb_nqt, fb_nqg, fb_nqx, fb_spx;
+    float *g_pub;             // [n_stripes][qstride] shared thresholds: stripe s publishes the r-th smallest key of its list, r = ceil(kl / n_stripes)
+    float *part_thr;          // [n_stripes][qstride] the threshold a stripe ended with: its list is complete for keys <= that
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
     uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
     uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
@@ -116,8 +118,10 @@ __device__ __forceinline__ bool fs_better(float k1, uint32_t id1, float k2, uint
 // Returns the new threshold packed as fs_pack() does.  Whole wave, arguments wave-uniform, cnt <= 64 * SLOTS.
 __device__ __forceinline__ unsigned long long fs_pack(float key, uint32_t id);
 __device__ __forceinline__ float fs_unpack_key(unsigned long long x);
+// r2 > 0: *key_r2 receives the r2-th smallest key of the list (r2 <= kl) -- what a stripe publishes for the shared threshold
 template <int STRIDE, int SLOTS>
-__device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
+__device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32_t *id, uint32_t cnt, uint32_t kl, uint32_t r2 = 0,
+                                                              float *key_r2 = nullptr) {
     // cnt <= 64 * SLOTS; every loop below has a compile-time trip count (the entries live in registers)
     const uint32_t lane = (uint32_t)kdb_lane();
     uint32_t ek[SLOTS], ei[SLOTS];
@@ -138,6 +142,17 @@ __device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32
 #pragma unroll
         for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
         if (c < kl) Tk |= 1u << bit;
+    }
+    if (r2) { // the same search for rank r2
+        uint32_t T2 = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t test = T2 | ((1u << bit) - 1u);
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
+            if (c < r2) T2 |= 1u << bit;
+        }
+        *key_r2 = fs_unpack_key((unsigned long long)T2 << 32);
     }
     uint32_t c_lt = 0, c_eq = 0;
 #pragma unroll
@@ -179,13 +194,14 @@ __device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32
 // cnt <= 64 * SLOTS (wave-uniform): the instantiation that just holds the list does the work, so the cost follows the
 // list length and not the largest length the caller allows
 template <int STRIDE, int SLOTS = 5>
-__device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl) {
-    if (SLOTS > 2 && cnt <= 128u) return fs_compact_core<STRIDE, 2>(key, id, cnt, kl);
-    if (SLOTS > 3 && cnt <= 192u) return fs_compact_core<STRIDE, 3>(key, id, cnt, kl);
-    if (SLOTS > 5 && cnt <= 320u) return fs_compact_core<STRIDE, 5>(key, id, cnt, kl);
-    if (SLOTS > 8 && cnt <= 512u) return fs_compact_core<STRIDE, 8>(key, id, cnt, kl);
-    if (SLOTS > 12 && cnt <= 768u) return fs_compact_core<STRIDE, 12>(key, id, cnt, kl);
-    return fs_compact_core<STRIDE, SLOTS>(key, id, cnt, kl);
+__device__ __forceinline__ unsigned long long fs_compact_wave(float *key, uint32_t *id, uint32_t cnt, uint32_t kl, uint32_t r2 = 0,
+                                                              float *key_r2 = nullptr) {
+    if (SLOTS > 2 && cnt <= 128u) return fs_compact_core<STRIDE, 2>(key, id, cnt, kl, r2, key_r2);
+    if (SLOTS > 3 && cnt <= 192u) return fs_compact_core<STRIDE, 3>(key, id, cnt, kl, r2, key_r2);
+    if (SLOTS > 5 && cnt <= 320u) return fs_compact_core<STRIDE, 5>(key, id, cnt, kl, r2, key_r2);
+    if (SLOTS > 8 && cnt <= 512u) return fs_compact_core<STRIDE, 8>(key, id, cnt, kl, r2, key_r2);
+    if (SLOTS > 12 && cnt <= 768u) return fs_compact_core<STRIDE, 12>(key, id, cnt, kl, r2, key_r2);
+    return fs_compact_core<STRIDE, SLOTS>(key, id, cnt, kl, r2, key_r2);
 }
 
 // worst entry of an entry-major list (stride FS_TQ): 8 entries per step so that the loads of a list living in
@@ -1099,8 +1115,14 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         const unsigned long long Tb = fs_pack(fs_unpack_key(T) + band, 0xffffffffu);
         uint32_t c = 0, sat = 0;
         for (uint32_t i = (uint32_t)tid; i < n; i += 256) c += ent[i] <= Tb ? 1u : 0u;
-        for (uint32_t sidx = (uint32_t)tid; sidx < n_stripes; sidx += 256)
-            sat += (scnt[sidx] >= p.kl && fs_pack(sworst[sidx], 0u) <= Tb) ? 1u : 0u;
+        // a stripe's list may miss entries in two ways: it kept kl entries and cut the rest (its worst kept key bounds what was
+        // cut), or it filtered with a threshold tighter than its own kl-th key (shared thresholds of the big-tile kernel:
+        // complete only for keys <= the threshold it ended with)
+        for (uint32_t sidx = (uint32_t)tid; sidx < n_stripes; sidx += 256) {
+            bool open = scnt[sidx] >= p.kl && fs_pack(sworst[sidx], 0u) <= Tb;
+            if (p.part_thr) open = open || fs_pack(p.part_thr[(size_t)sidx * qstride + q], 0u) <= Tb;
+            sat += open ? 1u : 0u;
+        }
         __syncthreads(); // the reduction scratch may still be read by a slower thread of the selection above
         const uint32_t n_band = fs_block_sum(c, red, tid, 0);
         const uint32_t n_sat = fs_block_sum(sat, red, tid, 1);
@@ -1670,7 +1692,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t cap_big = fb_cap(kl, fb_slack, fb_period);
     const size_t n_part_big = big ? (size_t)want_big * fb_nqt * FB_T : 0;
     size_t part_bytes = n_part * cap * 8 + n_part * 4 + 1024;
-    if (big && n_part_big * cap_big * 8 + n_part_big * 4 + 1024 > part_bytes) part_bytes = n_part_big * cap_big * 8 + n_part_big * 4 + 1024;
+    // big-tile kernel: lists + counts + the thresholds the stripes publish / end with (two floats per (stripe, query))
+    if (big && n_part_big * cap_big * 8 + n_part_big * 12 + 1024 > part_bytes) part_bytes = n_part_big * cap_big * 8 + n_part_big * 12 + 1024;
     size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
     if (big && v.precision == KDB_PREC_F16) fbq_bytes = ((size_t)fb_nqt * FB_T * v.ld * 2 + 255) & ~(size_t)255; // the queries as halfs
     const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
@@ -1750,6 +1773,11 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.part_key = reinterpret_cast<float *>(part);
         p.part_id = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 4);
         p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 8);
+        if (!getenv("KDB_FB_NOSHARE")) {
+            p.g_pub = reinterpret_cast<float *>(part + n_part_big * cap_big * 8 + n_part_big * 4);
+            p.part_thr = p.g_pub + n_part_big;
+            KDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.g_pub), 0x7f800000, n_part_big, s)); // +inf: nothing published yet
+        }
         p.lists_query_major = 1u;
         p.tile_rows = FB_T;
         p.fb_nqt = fb_nqt;

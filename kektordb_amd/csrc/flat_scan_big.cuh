@@ -115,6 +115,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     const uint32_t nslab = rowb / FB_SLAB;
     const uint32_t cap = p.cap;
     const size_t list0 = ((size_t)stripe * qstride + q0) * cap; // first entry of query q0's list
+    const uint32_t pub_rank = (p.kl + geo.n_stripes - 1u) / geo.n_stripes; // >= 1
 
     if (tid < FB_T) {
         const bool real = q0 + (uint32_t)tid < p.B;
@@ -365,15 +366,30 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                 for (uint32_t i = (uint32_t)wave; i < nn; i += 8u) {
                     const uint32_t qq = need_list[i];
                     const size_t lb = list0 + (size_t)qq * cap;
-                    const unsigned long long T = fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, l_cnt[qq], p.kl);
+                    float key_r = INFINITY;
+                    const unsigned long long T = fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, l_cnt[qq], p.kl,
+                                                                               p.g_pub ? pub_rank : 0u, &key_r);
                     if (lane == 0) {
-                        tau[qq] = fs_unpack_key(T);
-                        tau_id[qq] = (uint32_t)(T & 0xffffffffu);
+                        if (fs_better(fs_unpack_key(T), (uint32_t)(T & 0xffffffffu), tau[qq], tau_id[qq])) { // (a shared threshold may be tighter already)
+                            tau[qq] = fs_unpack_key(T);
+                            tau_id[qq] = (uint32_t)(T & 0xffffffffu);
+                        }
                         l_cnt[qq] = p.kl;
+                        if (p.g_pub) // this stripe holds pub_rank rows with key <= key_r: n_stripes such statements bound the global kl-th key
+                            __hip_atomic_store(p.g_pub + (size_t)stripe * qstride + q0 + qq, key_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 __syncthreads(); // need_list and its length may be reused
                 if (tid == 0) { flags[0] = 0u; flags[1] = 0u; }
+            }
+            if (p.g_pub && tid < FB_T) { // shared threshold: the largest of the stripes' published keys bounds the GLOBAL kl-th best key
+                float th = -INFINITY;
+                for (uint32_t s2 = 0; s2 < geo.n_stripes; s2++)
+                    th = fmaxf(th, __hip_atomic_load(p.g_pub + (size_t)s2 * qstride + q0 + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (th < tau[tid]) { // rows with key > th cannot be among the kl best of the corpus; key == th stays in
+                    tau[tid] = th;
+                    tau_id[tid] = 0xffffffffu;
+                }
             }
         }
         if (FB_DBG & 32u) tm_cmp += __builtin_readcyclecounter() - tm1;
@@ -398,5 +414,6 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             (void)fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, cq, p.kl);
         }
         if (hi == 0) p.part_cnt[(size_t)stripe * qstride + q0 + myq] = c > p.kl ? p.kl : c;
+        if (hi == 0 && p.part_thr) p.part_thr[(size_t)stripe * qstride + q0 + myq] = tau[myq];
     }
 }
