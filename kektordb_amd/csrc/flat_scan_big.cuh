@@ -31,6 +31,7 @@
 #else
 #define FB_DBG 0u
 #endif
+#define FB_SB() __builtin_amdgcn_sched_barrier(0)
 constexpr int FB_T = 256;        // rows per tile = queries per tile
 constexpr int FB_SLAB = 128;     // bytes of every row per K slab
 constexpr int FB_CSLOTS = 20;     // fs_compact_wave register slots: a list never holds more than 64 * 20 entries
@@ -194,9 +195,9 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     }
     fb_dma_wait();
     __syncthreads();
-    if (row_begin < row_end) read_frags(0, 0, 0);
 
     unsigned long long tm_sel = 0, tm_cmp = 0;
+    unsigned long long n_app = 0, n_dmp = 0, n_cmp = 0; // debug counts (FB_DBG & 256 / 512)
     uint32_t t = 0;
     for (uint32_t tile = row_begin; tile < row_end; tile += FB_T, t++) {
         const uint32_t tp = t & 1u;
@@ -214,6 +215,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             for (int bb = 0; bb < 2; bb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
+        read_frags(0, g & 1u, 0); // the tile's first slab landed behind the last barrier
 
         // One slab: the fragments of its first K step are already in set 0 (read behind the previous slab's barrier).
         //   step 0: read step 1 -> set 1 | request the next slab's rows    | MFMAs of set 0
@@ -234,22 +236,33 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                 for (int j = 0; j < 4; j++)
                     aptr[j] = rows8 + (size_t)sel_id[(tp ^ 1u) * FB_T + (uint32_t)j * 64u + st_row] * rowb + st_piece * 16u;
             }
+            // FB_SB: the phases stay in this order.  Left alone, the scheduler hoists the LDS reads of later steps above
+            // the MFMAs that still use the set they overwrite, keeps a third fragment set alive, runs out of registers and
+            // reloads spilled fragments inside this loop -- behind an s_waitcnt vmcnt(0) that also waits for the slab DMA.
             read_frags(1, buf, 1);
             if (dma) issue_rows(buf ^ 1u, nslab_i);
+            FB_SB();
             mfma_step(0);
+            FB_SB();
             read_frags(0, buf, 2);
             if (dma) issue_queries(buf ^ 1u, nslab_i);
+            FB_SB();
             mfma_step(1);
+            FB_SB();
             read_frags(1, buf, 3);
+            FB_SB();
             mfma_step(0);
+            FB_SB();
             fb_dma_wait();
             __syncthreads(); // slab s+1 has landed (every wave drained its own DMA), nobody reads slab s any more
-            if (dma_same || dma_next) read_frags(0, buf ^ 1u, 0);
+            if (dma_same) read_frags(0, buf ^ 1u, 0); // (the next tile reads its first fragments after the selection: kept across it, they spill)
             if (s == 0 && has_next && tid < FB_T) {
                 sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
                 if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
             }
+            FB_SB();
             mfma_step(1);
+            FB_SB();
         }
 
         // ---- selection.  acc[ab][bb][r]: query wn*64 + bb*32 + l31, row wm*128 + ab*32 + (r&3) + 8*(r>>2) + 4*hi.
@@ -289,6 +302,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                                 p.part_key[lb + pos] = key;
                                 p.part_id[lb + pos] = rid;
                                 appended = true;
+                                if (FB_DBG & 256u) n_app++;
                             }
                         }
                     }
@@ -346,6 +360,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                         dsc[slot] = make_uint4(__float_as_uint(t_k[bb]), t_id[bb], (uint32_t)lane | ((uint32_t)ab << 6) | ((uint32_t)bb << 8), 0u);
                     }
                     n_dump += (uint32_t)__builtin_popcountll(bal);
+                    if ((FB_DBG & 256u) && lane == 0) n_dmp += (uint32_t)__builtin_popcountll(bal);
                     if (n_dump + 64u > FB_DUMPS) phase_b(); // the next block may dump 64 more
                 }
             }
@@ -369,6 +384,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                     float key_r = INFINITY;
                     const unsigned long long T = fs_compact_wave<1, FB_CSLOTS>(p.part_key + lb, p.part_id + lb, l_cnt[qq], p.kl,
                                                                                p.g_pub ? pub_rank : 0u, &key_r);
+                    if ((FB_DBG & 512u) && lane == 0) { n_cmp++; n_app += l_cnt[qq]; }
                     if (lane == 0) {
                         if (fs_better(fs_unpack_key(T), (uint32_t)(T & 0xffffffffu), tau[qq], tau_id[qq])) { // (a shared threshold may be tighter already)
                             tau[qq] = fs_unpack_key(T);
@@ -382,13 +398,29 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                 __syncthreads(); // need_list and its length may be reused
                 if (tid == 0) { flags[0] = 0u; flags[1] = 0u; }
             }
-            if (p.g_pub && tid < FB_T) { // shared threshold: the largest of the stripes' published keys bounds the GLOBAL kl-th best key
+            if (p.g_pub) { // shared threshold: the largest of the stripes' published keys bounds the GLOBAL kl-th best key
+                const uint32_t qq = (uint32_t)tid & (FB_T - 1u), half = (uint32_t)tid >> 8; // two threads per query, every other stripe each
                 float th = -INFINITY;
-                for (uint32_t s2 = 0; s2 < geo.n_stripes; s2++)
-                    th = fmaxf(th, __hip_atomic_load(p.g_pub + (size_t)s2 * qstride + q0 + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (th < tau[tid]) { // rows with key > th cannot be among the kl best of the corpus; key == th stays in
-                    tau[tid] = th;
-                    tau_id[tid] = 0xffffffffu;
+                const float *src = p.g_pub + q0 + qq;
+                for (uint32_t s0 = half; s0 < geo.n_stripes; s0 += 16u) { // eight loads in flight, then their maximum
+                    float x[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; u++) {
+                        const uint32_t s2 = s0 + 2u * u < geo.n_stripes ? s0 + 2u * u : s0;
+                        x[u] = __hip_atomic_load(src + (size_t)s2 * qstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; u++) th = fmaxf(th, x[u]);
+                }
+                float *tmp = reinterpret_cast<float *>(need_list);
+                if (half) tmp[qq] = th;
+                __syncthreads();
+                if (!half) {
+                    th = fmaxf(th, tmp[qq]);
+                    if (th < tau[qq]) { // rows with key > th cannot be among the kl best of the corpus; key == th stays in
+                        tau[qq] = th;
+                        tau_id[qq] = 0xffffffffu;
+                    }
                 }
             }
         }
@@ -399,6 +431,14 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         atomicAdd(p.ctr + 3, tm_cmp);
     }
 
+    if ((FB_DBG & 256u) && p.ctr) { // survivors appended, blocks dumped
+        atomicAdd(p.ctr + 2, n_app);
+        if (lane == 0) atomicAdd(p.ctr + 3, n_dmp);
+    }
+    if ((FB_DBG & 512u) && p.ctr && lane == 0) { // entries compacted, compactions
+        atomicAdd(p.ctr + 2, n_app);
+        atomicAdd(p.ctr + 3, n_cmp);
+    }
     // ---- hand the lists over: at most kl entries each
     __syncthreads();
     {

@@ -39,7 +39,9 @@ struct WaveLds {
     float *nr_d;       // [nr_cap] traversal-only candidates (NrList)
     uint32_t *nr_id;   // [nr_cap]
     uint32_t nr_cap;
+    uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit, [1] query norm bits
 };
+constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
 // told they are uniform
@@ -256,6 +258,50 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         if (act && t == 0) s.nb_d[r] = key;
     }
     wave_lds_fence();
+}
+
+// Latency mode: WIDE waves share one query.  Wave 0 walks the graph (beam, visited set, insertion order: the walk of
+// search_layer, unchanged); the rows of a hop are split into WIDE contiguous runs, one per wave, so that a hop with 32
+// fresh neighbours is ONE round trip to HBM instead of three.  A row's distance does not depend on which wave or
+// 16-lane group evaluates it (same pieces per lane, same reduction), so results and counters equal the one-wave walk.
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave) {
+    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
+    const uint32_t lo = wave * chunk;
+    if (lo >= n) return;
+    WaveLds s2 = s;
+    s2.nb_id = s.nb_id + lo;
+    s2.nb_d = s.nb_d + lo;
+    compute_dists<PREC, METRIC, NCH>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
+}
+// wave 0's side (the other waves sit in coop_helper_loop)
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
+    if constexpr (WIDE == 1) {
+        compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
+    } else {
+        if (n <= 4u) { // one 16-lane group per row: a single trip anyway
+            compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
+            return;
+        }
+        if (kdb_lane() == 0) {
+            s.ctl[0] = n;
+            s.ctl[1] = __float_as_uint(qnorm);
+        }
+        __syncthreads(); // rows posted (nb_id, the query) ...
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
+        __syncthreads(); // ... distances back in nb_d
+    }
+}
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
+    for (;;) {
+        __syncthreads();
+        const uint32_t n = uni(s.ctl[0]);
+        if (n == KDB_COOP_EXIT) return;
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[1])), wave);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,10 +774,19 @@ struct NrList {
 
 struct QCtr {
     uint32_t n_dist, n_hops, n_dropped;
+#ifdef KDB_SEARCH_TIMERS // measurement build (make dbgs): where a walk's time goes
+    uint32_t n_ins;
+    unsigned long long t_adj, t_dist, t_ins;
+#endif
 };
+#ifdef KDB_SEARCH_TIMERS
+#define KDB_T(x) x
+#else
+#define KDB_T(x)
+#endif
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
-template <int PREC, int METRIC, int NCH, class BeamT, class VisT>
+template <int PREC, int METRIC, int NCH, class BeamT, class VisT, int WIDE = 1>
 __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT &vis,
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr) {
     const int lane = kdb_lane();
@@ -742,7 +797,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     if (lane == 0) s.nb_id[0] = ep;
     wave_lds_fence();
-    compute_dists<PREC, METRIC, NCH>(v, s, 1, qnorm);
+    dists<PREC, METRIC, NCH, WIDE>(v, s, 1, qnorm);
     ctr.n_dist++;
     {
         (void)vis.test_and_set(ep, lane == 0);
@@ -789,6 +844,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
         if (level > 0 && (int)v.levels[cur] < level) continue; // :2524-2527 node lacks this level
         ctr.n_hops++;
+        KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter();)
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
                                          : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
         uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
@@ -797,6 +853,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
         const unsigned long long m = __ballot(fresh);
         const uint32_t n = (uint32_t)__builtin_popcountll(m);
+        KDB_T(ctr.t_adj += __builtin_readcyclecounter() - tq0;)
         if (n == 0) continue;
         if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
         wave_lds_fence();
@@ -804,12 +861,14 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         // skipped when the index holds no deleted node
         uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
-        compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
+        KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter();)
+        dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || my_d < b.worst));
+        KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); ctr.t_dist += tq2 - tq1;)
         while (pass) { // sequential, in stored order (:2577-2590)
             const uint32_t j = (uint32_t)__builtin_ctzll(pass);
             pass &= pass - 1;
@@ -826,8 +885,10 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 b.insert(d, id);
                 b.n_res++;
                 b.trim(ef);
+                KDB_T(ctr.n_ins++;)
             }
         }
+        KDB_T(ctr.t_ins += __builtin_readcyclecounter() - tq2;)
     }
     ctr.n_dropped += nr.dropped;
     vis.end_layer();

@@ -49,8 +49,9 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #endif
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
-template <int PREC, int METRIC, int NCH, int BS, int VIS>
-__global__ void __launch_bounds__(64, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+// WIDE > 1: latency mode, WIDE waves per query (see dists() in kdb_search_core.cuh).
+template <int PREC, int METRIC, int NCH, int BS, int VIS, int WIDE = 1>
+__global__ void __launch_bounds__(64 * WIDE, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
@@ -69,6 +70,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
+    s.ctl = reinterpret_cast<uint32_t *>(smem + off);
+    if (WIDE > 1) off += 16;
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
     s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
@@ -78,6 +81,12 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.beam_cap = beam_cap;
 
     const int lane = kdb_lane();
+    if constexpr (WIDE > 1) {
+        if (threadIdx.x >= 64u) { // the walk belongs to wave 0; the others evaluate their share of every hop's rows
+            coop_helper_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6);
+            return;
+        }
+    }
     unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
     typename BeamSel<BS>::type b;
     b.bind(s);
@@ -153,7 +162,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         __threadfence_block();
         wave_lds_fence();
 
-        QCtr ctr{0, 0, 0};
+        QCtr ctr{};
+        KDB_T(const unsigned long long tq_start = __builtin_readcyclecounter();)
         // the query's allow list and entry point: one list for the whole batch, or its own (heterogeneous batch)
         const uint32_t *q_allow = allow;
         uint32_t ep = entry;
@@ -168,7 +178,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         bool failed = ep == 0u;
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
-            search_layer<PREC, METRIC, NCH>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr);
             const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
@@ -180,7 +190,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
         uint32_t nout = 0;
         if (!failed) {
-            search_layer<PREC, METRIC, NCH>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
             // results, ascending (:2596-2610), first k
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
                                    PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
@@ -194,10 +204,15 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
             if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
         }
+        KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu adj+visited %llu dists %llu inserts %llu\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_adj, ctr.t_dist, ctr.t_ins);)
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         tot_dropped += ctr.n_dropped;
         wave_lds_fence();
+    }
+    if constexpr (WIDE > 1) {
+        if (lane == 0) s.ctl[0] = KDB_COOP_EXIT;
+        __syncthreads();
     }
     if (lane == 0 && gctr) {
         atomicAdd(&gctr[0], tot_dist);
@@ -524,15 +539,16 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
     const uint32_t hsize = (BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
-    const size_t lds = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
-    if (lds > 160 * 1024) {
-        kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds);
+    const size_t lds1 = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
+    if (lds1 + 16 > 160 * 1024) {
+        kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds1);
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t ncu = (uint32_t)idx->n_cu;
-    auto launch = [&](auto kern, uint32_t vis_size) -> int {
+    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
+        const size_t lds = lds1 + (waves > 1u ? 16u : 0u);
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, 64, lds);
+        uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
         if (grid == 0) return KDB_OK;
         int rc = kdb_ensure_visited(idx, grid, s);
@@ -540,12 +556,18 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
     };
+    if constexpr (BS == 2) {
+        // latency mode: a batch that leaves most of the chip idle gives every query four waves (one HBM round trip per
+        // hop instead of three); same walk, same results, same counters
+        static const uint32_t wide_max = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? (uint32_t)atoi(e) : 128u; }();
+        if (hsize && B <= wide_max) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>, hsize, 4u);
+    }
     if constexpr (BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
     }

@@ -26,6 +26,7 @@ for B in [int(b) for b in a.bs.split(",")]:
     st = idx.launch_stats(a.reps)
     ms = np.mean([s["kernel_ms"] for s in st])
     if os.environ.get("KDB_FB_DBG"):
+        print(f"  dbg raw: ctr2 {st[-1]['n_dropped']} ({st[-1]['n_dropped'] / B:.1f} per query), ctr3 {st[-1]['bytes']} ({st[-1]['bytes'] / B:.1f} per query); exact-pass queries {st[-1].get('n_hops')}")
         print(f"  dbg: per-wave cycles: selection {st[-1]['n_dropped'] / 2048 / 1e6:.2f} M, compaction rounds {st[-1]['bytes'] / 2048 / 1e6:.2f} M (kernel {ms * 2.1e3 / 1e3:.1f} M cycles at 2.1 GHz)")
     print(f"B={B}: kernel {ms:.2f} ms, {2*B*a.n*a.dim/ms/1e9:.1f} TFLOP/s, {B/ms*1e3:.0f} QPS, rows {a.n*a.dim*4/ms/1e6:.0f} GB/s; whole call {wall:.2f} ms")
     # exactness spot check vs torch (measurement tool only)
