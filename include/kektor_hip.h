@@ -85,6 +85,11 @@ enum {
                                         * pending traversal-only candidates (more than 2047 soft-deleted nodes waiting at once:       *
                                         * kdb_counters.n_dropped > 0), i.e. when some answer may differ from the reference's walk.    *
                                         * The outputs are still filled.  Without the flag the count is only reported.                */
+    ,
+    KDB_SEARCH_DIST_F64 = 1u << 3      /* int8 indexes, kdb_search_batch[_dev] and kdb_flat_scan_batch[_dev]: out_dist points to B*k    *
+                                        * DOUBLES and receives the reference's float64 distances (hnsw_index.go:2429-2454 computes and *
+                                        * orders them as float64).  Without the flag the same doubles are rounded to float on the way  *
+                                        * out; the ORDER of the results is the float64 order either way.  Other precisions: INVALID.   */
 };
 
 typedef struct kdb_index kdb_index;

@@ -56,6 +56,13 @@ class Index {
         if (rc) throw Error(rc, "hnsw.New");
     }
     ~Index() { Close(); }
+    // DB.Compress (core.go:1128-1290) on the device: a new index of `precision` (KDB_PREC_F16 / KDB_PREC_I8) over the same
+    // graph (or re-inserted by the GPU builder when rebuildGraph); this index stays as it is
+    std::unique_ptr<Index> Compress(uint32_t precision, bool rebuildGraph = false) const {
+        kdb_index *h = nullptr;
+        check(kdb_index_compress(h_, precision, rebuildGraph ? KDB_COMPRESS_REBUILD_GRAPH : 0u, &h), "compress");
+        return std::unique_ptr<Index>(new Index(h, dim_, metric_, precision));
+    }
     Index(const Index &) = delete;
     Index &operator=(const Index &) = delete;
 
@@ -100,11 +107,11 @@ class Index {
         std::vector<SearchResult> out;
         if (!h_ || k <= 0 || query.size() != dim_) return out;
         std::vector<uint32_t> ids((size_t)k), cnt(1);
-        std::vector<float> dist((size_t)k);
+        DistBuf dist((size_t)k, wide());
         int rc = kdb_search_batch(h_, query.data(), 1, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0),
-                                  allowList ? allowList->words.data() : nullptr, flags(), ids.data(), dist.data(), cnt.data());
+                                  allowList ? allowList->words.data() : nullptr, flags(), ids.data(), dist.ptr(), cnt.data());
         if (rc) return out; // ":356-359": log and return []
-        for (uint32_t i = 0; i < cnt[0]; i++) out.push_back({ids[i], score(dist[i])});
+        for (uint32_t i = 0; i < cnt[0]; i++) out.push_back({ids[i], score(dist, i)});
         return out;
     }
     // the micro-batcher's call: B queries, row-major; results[b] has <= k entries
@@ -113,12 +120,12 @@ class Index {
         std::vector<std::vector<SearchResult>> out(B);
         if (!h_ || k <= 0 || B == 0) return out;
         std::vector<uint32_t> ids((size_t)B * k), cnt(B);
-        std::vector<float> dist((size_t)B * k);
+        DistBuf dist((size_t)B * k, wide());
         int rc = kdb_search_batch(h_, queries, B, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0),
-                                  allowList ? allowList->words.data() : nullptr, flags(), ids.data(), dist.data(), cnt.data());
+                                  allowList ? allowList->words.data() : nullptr, flags(), ids.data(), dist.ptr(), cnt.data());
         if (rc) return out;
         for (uint32_t b = 0; b < B; b++)
-            for (uint32_t i = 0; i < cnt[b]; i++) out[b].push_back({ids[(size_t)b * k + i], score(dist[(size_t)b * k + i])});
+            for (uint32_t i = 0; i < cnt[b]; i++) out[b].push_back({ids[(size_t)b * k + i], score(dist, (size_t)b * k + i)});
         return out;
     }
     // exact scan over live (and allowed) rows: BruteForceIndex.SearchWithScores semantics (vector_index.go:104-140)
@@ -126,11 +133,11 @@ class Index {
         std::vector<std::vector<SearchResult>> out(B);
         if (!h_ || k <= 0 || B == 0) return out;
         std::vector<uint32_t> ids((size_t)B * k), cnt(B);
-        std::vector<float> dist((size_t)B * k);
+        DistBuf dist((size_t)B * k, wide());
         check(kdb_flat_scan_batch(h_, queries, B, (uint32_t)k, allowList ? allowList->words.data() : nullptr, flags(), ids.data(),
-                                  dist.data(), cnt.data()), "flat_scan");
+                                  dist.ptr(), cnt.data()), "flat_scan");
         for (uint32_t b = 0; b < B; b++)
-            for (uint32_t i = 0; i < cnt[b]; i++) out[b].push_back({ids[(size_t)b * k + i], score(dist[(size_t)b * k + i])});
+            for (uint32_t i = 0; i < cnt[b]; i++) out[b].push_back({ids[(size_t)b * k + i], score(dist, (size_t)b * k + i)});
         return out;
     }
     kdb_index *handle() const { return h_; }
@@ -143,11 +150,24 @@ class Index {
     }
 
   private:
+    Index(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {}
+    // distances of one call: floats, or -- int8 indexes -- the float64 values the reference computes (hnsw_index.go:2429-2454),
+    // asked for with KDB_SEARCH_DIST_F64
+    struct DistBuf {
+        std::vector<float> f;
+        std::vector<double> d;
+        DistBuf(size_t n, bool wide) : f(wide ? 0 : n), d(wide ? n : 0) {}
+        float *ptr() { return d.empty() ? f.data() : reinterpret_cast<float *>(d.data()); }
+    };
+    bool wide() const { return precision_ == KDB_PREC_I8; }
     // the reference's f64 epilogue: float64(sum) (distance_go.go:67) / 1.0 - float64(dot) (:127)
-    double score(float raw) const {
-        return (metric_ == KDB_METRIC_COSINE && precision_ == KDB_PREC_F32) ? 1.0 - (double)raw : (double)raw;
+    double score(const DistBuf &b, size_t i) const {
+        if (!b.d.empty()) return b.d[i];
+        return (metric_ == KDB_METRIC_COSINE && precision_ == KDB_PREC_F32) ? 1.0 - (double)b.f[i] : (double)b.f[i];
     }
-    uint32_t flags() const { return needsRefine_ ? (uint32_t)KDB_SEARCH_NEEDS_REFINE : 0u; }
+    uint32_t flags() const {
+        return (needsRefine_ ? (uint32_t)KDB_SEARCH_NEEDS_REFINE : 0u) | (wide() ? (uint32_t)KDB_SEARCH_DIST_F64 : 0u);
+    }
     static void check(int rc, const char *what) {
         if (rc) throw Error(rc, what);
     }

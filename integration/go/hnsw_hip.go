@@ -431,19 +431,29 @@ func (h *Index) searchBatchHIP(reqs []*hipRequest, k, ef int, allow *roaring.Bit
 		useFlat = card > 0 && k <= 128 && float64(card) < hipFlatScanSelectivity*float64(count)
 	}
 	ids := make([]uint32, B*k)
+	// int8 indexes: the distances are float64 in the reference (hnsw_index.go:2429-2454); KDB_SEARCH_DIST_F64 makes the
+	// library hand over those doubles (out_dist then points to B*k float64) instead of their float32 rounding
+	wide := h.precision == distance.Int8
 	dist := make([]float32, B*k)
+	var dist64 []float64
+	distPtr := (*C.float)(unsafe.Pointer(&dist[0]))
+	var flags C.uint32_t
+	if wide {
+		dist64 = make([]float64, B*k)
+		distPtr = (*C.float)(unsafe.Pointer(&dist64[0]))
+		flags |= C.KDB_SEARCH_DIST_F64
+	}
 	cnt := make([]uint32, B)
 	var rc C.int
 	if useFlat { // the filtered path of north_star: exact scan over the allowed rows
-		rc = C.kdb_flat_scan_batch(h.gpu.h, (*C.float)(unsafe.Pointer(&queries[0])), C.uint32_t(B), C.uint32_t(k), allowPtr, 0,
-			(*C.uint32_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dist[0])), (*C.uint32_t)(unsafe.Pointer(&cnt[0])))
+		rc = C.kdb_flat_scan_batch(h.gpu.h, (*C.float)(unsafe.Pointer(&queries[0])), C.uint32_t(B), C.uint32_t(k), allowPtr, flags,
+			(*C.uint32_t)(unsafe.Pointer(&ids[0])), distPtr, (*C.uint32_t)(unsafe.Pointer(&cnt[0])))
 	} else {
-		var flags C.uint32_t
 		if h.needsRefine.Load() {
 			flags |= C.KDB_SEARCH_NEEDS_REFINE // the ef boost of hnsw_index.go:387-399 is applied by the library
 		}
 		rc = C.kdb_search_batch(h.gpu.h, (*C.float)(unsafe.Pointer(&queries[0])), C.uint32_t(B), C.uint32_t(k), C.uint32_t(ef),
-			allowPtr, flags, (*C.uint32_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dist[0])),
+			allowPtr, flags, (*C.uint32_t)(unsafe.Pointer(&ids[0])), distPtr,
 			(*C.uint32_t)(unsafe.Pointer(&cnt[0])))
 	}
 	if rc != 0 {
@@ -455,6 +465,9 @@ func (h *Index) searchBatchHIP(reqs []*hipRequest, k, ef int, allow *roaring.Bit
 		res := make([]types.SearchResult, n)
 		for i := 0; i < n; i++ {
 			raw := float64(dist[b*k+i]) // float64(sum), distance_go.go:67
+			if wide {
+				raw = dist64[b*k+i]
+			}
 			score := raw
 			if h.metric == distance.Cosine && h.precision == distance.Float32 {
 				score = 1.0 - raw // the library returns the raw dot product; distance_go.go:127

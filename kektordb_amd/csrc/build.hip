@@ -78,6 +78,10 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     s.nr_d = nullptr; // construction never meets a deleted node or a filter
     s.nr_id = nullptr;
     s.nr_cap = 0;
+    s.nb_lo = nullptr; // (int8 graphs are never built: Compress keeps the float32 graph)
+    s.beam_lo = nullptr;
+    s.nr_lo = nullptr;
+    s.ctl = nullptr;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
@@ -121,8 +125,8 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
             }
             if (b.count > 0) { // nearest (:786-788 / :1849)
                 float d0;
-                uint32_t f0;
-                b.get(0, d0, f0);
+                uint32_t l0, f0;
+                b.get(0, d0, l0, f0);
                 ep = f0 & KDB_ID_MASK;
             }
         }

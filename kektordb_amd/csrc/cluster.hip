@@ -245,6 +245,10 @@ static int sharded_call(kdb_cluster *c, bool flat, const float *queries, uint32_
         kdb_set_error("sharded search: null buffer or k == 0");
         return KDB_ERR_INVALID;
     }
+    if (flags & KDB_SEARCH_DIST_F64) { // the exchange block and the merge carry float distances
+        kdb_set_error("sharded search: KDB_SEARCH_DIST_F64 is a single-index option");
+        return KDB_ERR_INVALID;
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     const uint32_t G = (uint32_t)c->shards.size(), nd = (uint32_t)c->devs.size(), spd = c->spd;
     const size_t L = 2ull * B * k + B; // packed block, 32-bit words

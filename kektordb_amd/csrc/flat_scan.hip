@@ -75,6 +75,7 @@ struct FsParams {
     // big-tile ranking kernel (flat_scan_big.cuh): rows per tile (0 = FS_TR), and the blockIdx -> (query tile, stripe) map:
     // query tiles of 256, split into fb_nqg groups of fb_nqx tiles; an XCD serves one group with fb_spx stripes
     uint32_t tile_rows, fb_nqt, fb_nqg, fb_nqx, fb_spx;
+    uint32_t dist64;          // int8: out_dist is a double array (KDB_SEARCH_DIST_F64)
     float *g_pub;             // [n_stripes][qstride] shared thresholds: stripe s publishes the r-th smallest key of its list, r = ceil(kl / n_stripes)
     float *part_thr;          // [n_stripes][qstride] the threshold a stripe ended with: its list is complete for keys <= that
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
@@ -913,6 +914,7 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem); // [nmax]
     float *fin_d = reinterpret_cast<float *>(ent + nmax);                   // [FS_FIN]
     uint32_t *fin_id = reinterpret_cast<uint32_t *>(fin_d + FS_FIN);        // [FS_FIN]
+    uint32_t *fin_lo = reinterpret_cast<uint32_t *>(ent);                   // [nf <= n] int8: low key words; the entries are dead once the finalists are gathered
     uint32_t *red = fin_id + FS_FIN;                                        // [8]
     uint32_t *ctl = red + 8;                                                // [4]: total, nfin
     uint32_t *hist = ctl + 4;                                               // [256] radix-select bins
@@ -1170,10 +1172,12 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
             const bool act = r < nf;
             const uint32_t id = act ? fin_id[r] : 0u;
             float part;
-            if (PREC == KDB_PREC_I8) {
+            if (PREC == KDB_PREC_I8) { // the float64 distance as a (hi, lo) key: the reference orders doubles (kdb_i8_key)
                 const int dot = kdb_reduce16_i(kdb_row_partial_i8(reinterpret_cast<const int8_t *>(v.rows) + (size_t)id * v.ld,
                                                                   reinterpret_cast<const int8_t *>(qlds), v.ld, t));
-                part = kdb_i8_distance(dot, qnorm[q], v.norms[id]);
+                uint32_t plo;
+                kdb_i8_key(dot, qnorm[q], v.norms[id], part, plo);
+                if (act && t == 0) fin_lo[r] = plo;
             } else if (PREC == KDB_PREC_F16) {
                 part = kdb_reduce16(kdb_row_partial_f16(reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld, qlds, v.ld, t));
             } else if (METRIC == KDB_METRIC_COSINE) { // key = -dot
@@ -1185,19 +1189,36 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         }
         __syncthreads();
     }
+    const bool d64 = PREC == KDB_PREC_I8 && p.dist64; // out_dist is a double array (int8: the reference's float64 distances)
     for (uint32_t e = (uint32_t)tid; e < nf; e += 256) { // rank by counting over the total order (distance key, id)
         const float d = fin_d[e];
         const uint32_t id = fin_id[e];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
+        if (PREC == KDB_PREC_I8) {
+            const uint32_t lo = fin_lo[e];
+            for (uint32_t j = 0; j < nf; j++) {
+                const float dj = fin_d[j];
+                const uint32_t lj = fin_lo[j];
+                rank += (dj < d || (dj == d && (lj < lo || (lj == lo && fin_id[j] < id)))) ? 1u : 0u;
+            }
+        } else {
+            for (uint32_t j = 0; j < nf; j++) rank += fs_better(fin_d[j], fin_id[j], d, id) ? 1u : 0u;
+        }
         if (rank < k) {
             out_ids[(size_t)qo * k + rank] = id;
-            out_dist[(size_t)qo * k + rank] = (METRIC == KDB_METRIC_COSINE && PREC == KDB_PREC_F32) ? -d : d; // f32 cosine: raw dot
+            if (PREC == KDB_PREC_I8) {
+                const double dv = kdb_i8_key_double(d, fin_lo[e]);
+                if (d64) reinterpret_cast<double *>(out_dist)[(size_t)qo * k + rank] = dv;
+                else out_dist[(size_t)qo * k + rank] = (float)dv;
+            } else {
+                out_dist[(size_t)qo * k + rank] = (METRIC == KDB_METRIC_COSINE && PREC == KDB_PREC_F32) ? -d : d; // f32 cosine: raw dot
+            }
         }
     }
     for (uint32_t i = nout + (uint32_t)tid; i < k; i += 256) {
         out_ids[(size_t)qo * k + i] = 0u;
-        out_dist[(size_t)qo * k + i] = INFINITY;
+        if (d64) reinterpret_cast<double *>(out_dist)[(size_t)qo * k + i] = (double)INFINITY;
+        else out_dist[(size_t)qo * k + i] = INFINITY;
     }
     if (tid == 0) out_count[qo] = nout;
 }
@@ -1608,6 +1629,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_ERR_INVALID;
     }
     if (B == 0) return KDB_OK;
+    const bool dist64 = (queries_normalised & 2) != 0; // int8: d_out_dist is a double array (KDB_SEARCH_DIST_F64)
+    const int qn_arg = queries_normalised;
+    queries_normalised &= 1;
     // One launch = one round of 512 workgroups = (stripes) x (query tiles): with more than 64 query tiles the stripes
     // get so long, and so many workgroups stream the same stripe out of step, that the rows fall out of L2 (32768
     // queries in one launch: 3x slower per query, 150x the HBM traffic).  Larger batches run as 8192-query launches.
@@ -1618,7 +1642,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
             const uint32_t nb = B - b0 < FS_MAX_B ? B - b0 : FS_MAX_B;
             int rc = kdb_launch_flat_scan(idx, v, reinterpret_cast<const unsigned char *>(d_q) + (size_t)b0 * qbytes,
                                           d_qnorm ? d_qnorm + b0 : nullptr, nb, k, d_allow, d_first_allowed, d_out_ids + (size_t)b0 * k,
-                                          d_out_dist + (size_t)b0 * k, d_out_count + b0, queries_normalised, s);
+                                          d_out_dist + (size_t)b0 * k * (dist64 ? 2u : 1u), d_out_count + b0, qn_arg, s);
             if (rc) return rc;
         }
         return KDB_OK;
@@ -1749,6 +1773,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.q16 = reinterpret_cast<const uint16_t *>(d_fbq);
         p.rows16 = idx->d_rows16;
     }
+    p.dist64 = dist64 ? 1u : 0u;
     p.ctr = kdb_stats_begin(idx, 2, B, 0);
     unsigned long long *stat_slot = p.ctr;
     KDB_HIP(hipMemsetAsync(stat_slot, 0, 32, s));

@@ -805,7 +805,10 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         rc = prepare_queries(idx, v, d_queries, B, B, flags, &d_qp, &d_qnorm, s);
         if (rc) return rc;
         d_q = d_qp;
-        raw = 0;
+        raw = (flags & KDB_SEARCH_DIST_F64) ? 4u : 0u; // bit 2: d_out_dist is a double array
+    } else if (flags & KDB_SEARCH_DIST_F64) {
+        kdb_set_error("search: KDB_SEARCH_DIST_F64 applies to int8 indexes (the other precisions compute float32 distances)");
+        return KDB_ERR_INVALID;
     }
     uint32_t *tr_nd = nullptr, *tr_nh = nullptr;
     if (idx->trace_ndist && idx->trace_on_device) {
@@ -846,10 +849,10 @@ extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint
 // host-pointer wrapper: stage in, run, stage out (inputs consumed before return)
 template <typename F>
 static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits,
-                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run) {
+                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run, size_t dist_bytes = 4) {
     const size_t qbytes = (size_t)B * idx->desc.dim * 4;
     const size_t aw = allow_bits ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
-    const size_t obytes = (size_t)B * k * 8 + (size_t)B * 4;
+    const size_t obytes = (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 16;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     int rc = ensure_iobuf(idx, al(qbytes) + al(aw) + al(obytes) + 1024);
     if (rc) return rc;
@@ -857,15 +860,15 @@ static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint
     float *d_q = reinterpret_cast<float *>(p);
     uint64_t *d_allow = allow_bits ? reinterpret_cast<uint64_t *>(p + al(qbytes)) : nullptr;
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + al(qbytes) + al(aw));
-    float *d_dist = reinterpret_cast<float *>(d_ids + (size_t)B * k);
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_dist + (size_t)B * k);
+    float *d_dist = reinterpret_cast<float *>(p + al(qbytes) + al(aw) + (((size_t)B * k * 4 + 7) & ~(size_t)7)); // 8-byte aligned: may hold doubles
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_dist) + (size_t)B * k * dist_bytes);
     hipStream_t s = idx->stream;
     KDB_HIP(hipMemcpyAsync(d_q, queries, qbytes, hipMemcpyHostToDevice, s));
     if (allow_bits) KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, s));
     rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
     if (rc) return rc;
     KDB_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * dist_bytes, hipMemcpyDeviceToHost, s));
     KDB_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     KDB_HIP(hipStreamSynchronize(s));
     return KDB_OK;
@@ -879,6 +882,10 @@ extern "C" int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries
     if (B == 0) return KDB_OK;
     if (!d_queries || !d_out_ids || !d_out_dist || !d_out_count || k == 0) {
         kdb_set_error("search_multi: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    if (flags & KDB_SEARCH_DIST_F64) {
+        kdb_set_error("search_multi: KDB_SEARCH_DIST_F64 is an option of kdb_search_batch[_dev] and kdb_flat_scan_batch[_dev]");
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -916,7 +923,7 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     int rc = with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
                             [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
                                 return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                            });
+                            }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4);
     if (rc == KDB_OK && (flags & KDB_SEARCH_FAIL_ON_DROP) && idx->n_deleted > 2047u && idx->launch_seq > 0 && idx->last_kind == 1) {
         // (the call is complete: with_staged_io synchronised the stream)
         unsigned long long c[4] = {0, 0, 0, 0};
@@ -960,8 +967,12 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
     float *d_qnorm = nullptr;
     int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
+    if ((flags & KDB_SEARCH_DIST_F64) && idx->desc.precision != KDB_PREC_I8) {
+        kdb_set_error("flat scan: KDB_SEARCH_DIST_F64 applies to int8 indexes (the other precisions compute float32 distances)");
+        return KDB_ERR_INVALID;
+    }
     rc = kdb_launch_flat_scan(idx, v, d_q, d_qnorm, B, k, d_allow, d_first, d_out_ids, d_out_dist, d_out_count,
-                              (flags & KDB_SEARCH_PREPARED) ? 0 : 1, s);
+                              ((flags & KDB_SEARCH_PREPARED) ? 0 : 1) | ((flags & KDB_SEARCH_DIST_F64) ? 2 : 0), s);
     if (rc) return rc;
     return KDB_OK;
 }
@@ -974,6 +985,10 @@ extern "C" int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, 
     if (B == 0) return KDB_OK;
     if (!d_queries || !d_out_ids || !d_out_dist || !d_out_count || !group_offsets || !d_allow_lists || G == 0) {
         kdb_set_error("flat_scan_groups: null buffer or no group");
+        return KDB_ERR_INVALID;
+    }
+    if (flags & KDB_SEARCH_DIST_F64) {
+        kdb_set_error("flat_scan_groups: KDB_SEARCH_DIST_F64 is an option of kdb_search_batch[_dev] and kdb_flat_scan_batch[_dev]");
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1034,7 +1049,7 @@ extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_
     return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
                           [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
                               return flat_dev_locked(idx, d_q, B, k, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                          });
+                          }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4);
 }
 
 static int distance_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids, uint32_t C,

@@ -423,6 +423,36 @@ __device__ __forceinline__ float kdb_i8_distance(int dot, float qnorm, float sno
     return (float)(1.0 - sim);
 }
 
+// The same distance as a 64-bit ordering key: the reference compares these distances as float64 (heap order, the
+// "d < worst" tests), and two distinct doubles can round to one float.  d is never negative (sim <= 1), so its bit
+// pattern orders like the number: hi = d truncated to float (sign, exponent, the leading 23 mantissa bits), lo = the
+// 29 mantissa bits that follow.  (hi, lo) compared lexicographically IS the float64 comparison; kdb_i8_key_double
+// puts the double back together (exact), and its float cast is what kdb_i8_distance returns.
+__device__ __forceinline__ void kdb_i8_key(int dot, float qnorm, float snorm, float &hi, uint32_t &lo) {
+    double d = 1.0;
+    if (snorm != 0.f) {
+        double sim = (double)dot / ((double)qnorm * (double)snorm);
+        if (sim > 1.0) sim = 1.0;
+        if (sim < -1.0) sim = -1.0;
+        d = 1.0 - sim;
+    }
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    const uint32_t e = (uint32_t)(u >> 52) & 0x7ffu;
+    if (e <= 896u) { // 0 (or below the float range: cannot happen, the smallest non-zero d is 2^-53)
+        hi = 0.f;
+        lo = 0u;
+        return;
+    }
+    hi = __uint_as_float(((e - 896u) << 23) | (uint32_t)((u >> 29) & 0x7fffffu));
+    lo = (uint32_t)u & 0x1fffffffu;
+}
+__device__ __forceinline__ double kdb_i8_key_double(float hi, uint32_t lo) {
+    const uint32_t h = __float_as_uint(hi);
+    if (h == 0u) return 0.0;
+    const unsigned long long u = ((unsigned long long)((h >> 23) + 896u) << 52) | ((unsigned long long)(h & 0x7fffffu) << 29) | lo;
+    return __longlong_as_double((long long)u);
+}
+
 // Key used for ordering inside the kernels (ascending = nearer):
 //   f32/f16 L2: the raw sum;  f32 cosine: -dot (1-dot is monotone in -dot);  int8: the distance.
 template <int PREC, int METRIC>

@@ -39,6 +39,9 @@ struct WaveLds {
     float *nr_d;       // [nr_cap] traversal-only candidates (NrList)
     uint32_t *nr_id;   // [nr_cap]
     uint32_t nr_cap;
+    uint32_t *nb_lo;   // [64]   int8 only: low word of the 64-bit distance key (kdb_i8_key)
+    uint32_t *beam_lo; // [cap]  int8 + LdsBeam
+    uint32_t *nr_lo;   // [nr_cap] int8
     uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit, [1] query norm bits
 };
 constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;
@@ -160,8 +163,13 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int dot = kdb_reduce16_i(p[r]);
-                const float key = kdb_i8_distance(dot, qnorm, v.norms[ids[r]]);
-                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                float key;
+                uint32_t klo;
+                kdb_i8_key(dot, qnorm, v.norms[ids[r]], key, klo);
+                if (rr[r] < n && t == 0) {
+                    s.nb_d[rr[r]] = key;
+                    if (s.nb_lo) s.nb_lo[rr[r]] = klo;
+                }
             }
         }
         wave_lds_fence();
@@ -205,8 +213,13 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int dot = kdb_reduce16_i(p[r]);
-                const float key = kdb_i8_distance(dot, qnorm, v.norms[ids[r]]);
-                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                float key;
+                uint32_t klo;
+                kdb_i8_key(dot, qnorm, v.norms[ids[r]], key, klo);
+                if (rr[r] < n && t == 0) {
+                    s.nb_d[rr[r]] = key;
+                    if (s.nb_lo) s.nb_lo[rr[r]] = klo;
+                }
             }
         }
         wave_lds_fence();
@@ -253,7 +266,9 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
             const int8_t *row = reinterpret_cast<const int8_t *>(v.rows) + (size_t)id * v.ld;
             int p = kdb_row_partial_i8(row, reinterpret_cast<const int8_t *>(s.q), v.ld, t);
             p = kdb_reduce16_i(p);
-            key = kdb_i8_distance(p, qnorm, v.norms[id]);
+            uint32_t klo;
+            kdb_i8_key(p, qnorm, v.norms[id], key, klo);
+            if (act && t == 0 && s.nb_lo) s.nb_lo[r] = klo;
         }
         if (act && t == 0) s.nb_d[r] = key;
     }
@@ -272,6 +287,7 @@ __device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, u
     WaveLds s2 = s;
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
+    if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
     compute_dists<PREC, METRIC, NCH>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
 }
 // wave 0's side (the other waves sit in coop_helper_loop)
@@ -304,36 +320,54 @@ __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds
     }
 }
 
+// Ordering keys.  WK (int8 indexes): a key is (float hi, uint32 lo) = the float64 distance (kdb_i8_key), compared
+// lexicographically; otherwise the float alone and every `lo` below is dead code.
+template <bool WK>
+__device__ __forceinline__ bool key_lt(float a, uint32_t alo, float b, uint32_t blo) {
+    return a < b || (WK && a == b && alo < blo);
+}
+template <bool WK>
+__device__ __forceinline__ bool key_eq(float a, uint32_t alo, float b, uint32_t blo) {
+    return a == b && (!WK || alo == blo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident beam
 // ------------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool WK = false>
 struct RegBeam {
     static constexpr uint32_t CAP = 64u * S;
+    static constexpr bool kWide = WK;
     float d[S];
+    uint32_t lo[WK ? S : 1];
     uint32_t id[S]; // id | flags
     uint32_t count, n_res, scan_from;
     float worst;
+    uint32_t worst_lo;
 
     __device__ __forceinline__ void bind(const WaveLds &) {}
     __device__ __forceinline__ void reset(uint32_t) {
         count = n_res = scan_from = 0;
         worst = INFINITY;
+        worst_lo = 0u;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             d[s] = INFINITY;
             id[s] = 0u;
+            if constexpr (WK) lo[s] = 0u;
         }
     }
-    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const { // idx wave-uniform
+    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &dlo, uint32_t &idf) const { // idx wave-uniform
         const uint32_t slot = idx >> 6, l = idx & 63u;
         dd = 0.f;
+        dlo = 0u;
         idf = 0u;
 #pragma unroll
         for (int s = 0; s < S; s++)
             if (slot == (uint32_t)s) {
                 dd = readlane_f(d[s], l);
                 idf = readlane_u(id[s], l);
+                if constexpr (WK) dlo = readlane_u(lo[s], l);
             }
     }
     __device__ __forceinline__ void mark_expanded(uint32_t idx) {
@@ -354,7 +388,7 @@ struct RegBeam {
         }
         return -1;
     }
-    __device__ __forceinline__ void insert(float dd, uint32_t idf) {
+    __device__ __forceinline__ void insert(float dd, uint32_t dlo, uint32_t idf) {
         const uint32_t lane = (uint32_t)kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
         uint32_t pos = 0;
@@ -363,8 +397,9 @@ struct RegBeam {
             if (64u * s >= count) continue;
             const uint32_t i = 64u * s + lane;
             const float e = d[s];
+            const uint32_t elo = WK ? lo[WK ? s : 0] : 0u;
             const uint32_t eid = id[s] & KDB_ID_MASK;
-            const bool less = i < count && ((e < dd) || (e == dd && eid < idm));
+            const bool less = i < count && (key_lt<WK>(e, elo, dd, dlo) || (key_eq<WK>(e, elo, dd, dlo) && eid < idm));
             pos += (uint32_t)__builtin_popcountll(__ballot(less));
         }
 #pragma unroll
@@ -373,20 +408,25 @@ struct RegBeam {
             const uint32_t i = 64u * s + lane;
             float pd = shr1_f(d[s]);
             uint32_t pi = shr1_u(id[s]);
+            uint32_t pl = WK ? shr1_u(lo[WK ? s : 0]) : 0u;
             if (s > 0) {
                 const float cd = readlane_f(d[s > 0 ? s - 1 : 0], 63);
                 const uint32_t ci = readlane_u(id[s > 0 ? s - 1 : 0], 63);
+                const uint32_t cl = WK ? readlane_u(lo[WK ? (s > 0 ? s - 1 : 0) : 0], 63) : 0u;
                 if (lane == 0) {
                     pd = cd;
                     pi = ci;
+                    pl = cl;
                 }
             }
             if (i > pos) {
                 d[s] = pd;
                 id[s] = pi;
+                if constexpr (WK) lo[s] = pl;
             } else if (i == pos) {
                 d[s] = dd;
                 id[s] = idf;
+                if constexpr (WK) lo[s] = dlo;
             }
         }
         count++;
@@ -404,11 +444,13 @@ struct RegBeam {
         }
         if (n_res >= ef && count > 0) {
             float dd;
-            uint32_t idf;
-            get(count - 1, dd, idf);
+            uint32_t dlo, idf;
+            get(count - 1, dd, dlo, idf);
             worst = dd;
+            worst_lo = dlo;
         } else {
             worst = INFINITY;
+            worst_lo = 0u;
         }
     }
     __device__ __forceinline__ int first_result() const { // index of the nearest result entry, -1 if none
@@ -424,7 +466,8 @@ struct RegBeam {
         return -1;
     }
     // results (ascending), first k -> out arrays; returns the number written
-    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate) const {
+    // out64 (int8 indexes only): the distances as the reference's float64 instead of their float rounding
+    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate, double *out64 = nullptr) const {
         const uint32_t lane = (uint32_t)kdb_lane();
         uint32_t nout = 0;
 #pragma unroll
@@ -436,7 +479,13 @@ struct RegBeam {
             const uint32_t p = nout + kdb_mbcnt(m);
             if (f && p < k) {
                 out_ids[p] = id[s] & KDB_ID_MASK;
-                out_key[p] = negate ? -d[s] : d[s];
+                if constexpr (WK) {
+                    const double dv = kdb_i8_key_double(d[s], lo[s]);
+                    if (out64) out64[p] = dv;
+                    else out_key[p] = (float)dv;
+                } else {
+                    out_key[p] = negate ? -d[s] : d[s];
+                }
             }
             nout += (uint32_t)__builtin_popcountll(m);
         }
@@ -447,24 +496,31 @@ struct RegBeam {
 // ------------------------------------------------------------------------------------------------
 // LDS-resident beam (any ef)
 // ------------------------------------------------------------------------------------------------
-struct LdsBeam {
+template <bool WK = false>
+struct LdsBeamT {
+    static constexpr bool kWide = WK;
     float *bd;
+    uint32_t *bl; // low key words (WK)
     uint32_t *bi;
     uint32_t cap;
     uint32_t count, n_res, scan_from;
     float worst;
+    uint32_t worst_lo;
 
     __device__ __forceinline__ void bind(const WaveLds &s) {
         bd = s.beam_d;
+        bl = s.beam_lo;
         bi = s.beam_id;
         cap = s.beam_cap;
     }
     __device__ __forceinline__ void reset(uint32_t) {
         count = n_res = scan_from = 0;
         worst = INFINITY;
+        worst_lo = 0u;
     }
-    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &idf) const {
+    __device__ __forceinline__ void get(uint32_t idx, float &dd, uint32_t &dlo, uint32_t &idf) const {
         dd = unif(bd[idx]);
+        dlo = WK ? uni(bl[idx]) : 0u;
         idf = uni(bi[idx]);
     }
     __device__ __forceinline__ void mark_expanded(uint32_t idx) {
@@ -480,7 +536,7 @@ struct LdsBeam {
         }
         return -1;
     }
-    __device__ __forceinline__ void insert(float dd, uint32_t idf) {
+    __device__ __forceinline__ void insert(float dd, uint32_t dlo, uint32_t idf) {
         const int lane = kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
         uint32_t pos = 0;
@@ -489,8 +545,9 @@ struct LdsBeam {
             bool less = false;
             if (i < count) {
                 const float e = bd[i];
+                const uint32_t elo = WK ? bl[i] : 0u;
                 const uint32_t eid = bi[i] & KDB_ID_MASK;
-                less = (e < dd) || (e == dd && eid < idm);
+                less = key_lt<WK>(e, elo, dd, dlo) || (key_eq<WK>(e, elo, dd, dlo) && eid < idm);
             }
             pos += (uint32_t)__builtin_popcountll(__ballot(less));
         }
@@ -498,21 +555,24 @@ struct LdsBeam {
             const int i = hi - lane;
             const bool act = i >= (int)pos;
             float e = 0.f;
-            uint32_t x = 0;
+            uint32_t x = 0, l = 0;
             if (act) {
                 e = bd[i];
                 x = bi[i];
+                if (WK) l = bl[i];
             }
             wave_lds_fence();
             if (act) {
                 bd[i + 1] = e;
                 bi[i + 1] = x;
+                if (WK) bl[i + 1] = l;
             }
             wave_lds_fence();
         }
         if (lane == 0) {
             bd[pos] = dd;
             bi[pos] = idf;
+            if (WK) bl[pos] = dlo;
         }
         wave_lds_fence();
         count++;
@@ -527,7 +587,9 @@ struct LdsBeam {
             count--;
             n_res--;
         }
-        worst = (n_res >= ef && count > 0) ? unif(bd[count - 1]) : INFINITY;
+        const bool full = n_res >= ef && count > 0;
+        worst = full ? unif(bd[count - 1]) : INFINITY;
+        worst_lo = (WK && full) ? uni(bl[count - 1]) : 0u;
     }
     __device__ __forceinline__ int first_result() const {
         for (uint32_t base = 0; base < count; base += 64) {
@@ -538,7 +600,7 @@ struct LdsBeam {
         }
         return -1;
     }
-    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate) const {
+    __device__ __forceinline__ uint32_t write_results(uint32_t k, uint32_t *out_ids, float *out_key, bool negate, double *out64 = nullptr) const {
         uint32_t nout = 0;
         for (uint32_t base = 0; base < count && nout < k; base += 64) {
             const uint32_t i = base + (uint32_t)kdb_lane();
@@ -547,13 +609,20 @@ struct LdsBeam {
             const uint32_t p = nout + kdb_mbcnt(m);
             if (f && p < k) {
                 out_ids[p] = bi[i] & KDB_ID_MASK;
-                out_key[p] = negate ? -bd[i] : bd[i];
+                if constexpr (WK) {
+                    const double dv = kdb_i8_key_double(bd[i], bl[i]);
+                    if (out64) out64[p] = dv;
+                    else out_key[p] = (float)dv;
+                } else {
+                    out_key[p] = negate ? -bd[i] : bd[i];
+                }
             }
             nout += (uint32_t)__builtin_popcountll(m);
         }
         return nout > k ? k : nout;
     }
 };
+using LdsBeam = LdsBeamT<false>;
 
 // ------------------------------------------------------------------------------------------------
 // Visited set (the reference's BitSet, bitset.go).  Two exact implementations:
@@ -678,48 +747,56 @@ struct VisHash { // hybrid: LDS hash set that migrates into the wave's HBM bitse
 // be expanded (farther than the worst of a full result set -- worst only shrinks) are discarded first; only if more
 // than nr_cap candidates are still pending is the farthest one dropped, and that is counted (kdb_counters.n_dropped).
 // ------------------------------------------------------------------------------------------------
-struct NrList {
+template <bool WK = false>
+struct NrListT {
     float *d;
+    uint32_t *l; // low key words (WK)
     uint32_t *id;
     uint32_t cap, count, dropped;
     __device__ __forceinline__ void bind(const WaveLds &s) {
         d = s.nr_d;
+        l = s.nr_lo;
         id = s.nr_id;
         cap = s.nr_cap;
         count = 0;
         dropped = 0;
     }
-    static __device__ __forceinline__ unsigned long long pack(float key, uint32_t idv) {
-        uint32_t u = __float_as_uint(key);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving
-        return ((unsigned long long)u << 32) | idv;
-    }
     // position of the extreme (distance, id) pair (smallest, or largest when MAX); count > 0
     template <bool MAX>
-    __device__ __forceinline__ uint32_t extreme(float &dd, uint32_t &idv) const {
+    __device__ __forceinline__ uint32_t extreme(float &dd, uint32_t &dlo, uint32_t &idv) const {
         const uint32_t lane = (uint32_t)kdb_lane();
-        unsigned long long best = MAX ? 0ull : ~0ull;
-        uint32_t pos = 0;
+        // keys are never NaN; a non-negative key's bits order like the key, a negative one's (f32 cosine: -dot) reversed
+        auto ord = [](float key) {
+            const uint32_t u = __float_as_uint(key);
+            return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        };
+        uint32_t bk = MAX ? 0u : 0xffffffffu, bl_ = MAX ? 0u : 0xffffffffu, bi_ = MAX ? 0u : 0xffffffffu, pos = 0;
+        bool have = false;
+        auto better = [](uint32_t k1, uint32_t l1, uint32_t i1, uint32_t k2, uint32_t l2, uint32_t i2) { // (k1,l1,i1) beyond (k2,l2,i2)
+            if (k1 != k2) return MAX ? k1 > k2 : k1 < k2;
+            if (WK && l1 != l2) return MAX ? l1 > l2 : l1 < l2;
+            return MAX ? i1 > i2 : i1 < i2;
+        };
         for (uint32_t i = lane; i < count; i += 64) {
-            const unsigned long long e = pack(d[i], id[i]);
-            if (MAX ? e >= best : e <= best) {
-                best = e;
-                pos = i;
+            const uint32_t k1 = ord(d[i]), l1 = WK ? l[i] : 0u, i1 = id[i];
+            if (!have || better(k1, l1, i1, bk, bl_, bi_)) {
+                bk = k1; bl_ = l1; bi_ = i1; pos = i; have = true;
             }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t hi = (uint32_t)__shfl_xor((int)(best >> 32), o, 64);
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(best & 0xffffffffu), o, 64);
+            const uint32_t ok = (uint32_t)__shfl_xor((int)bk, o, 64);
+            const uint32_t ol = WK ? (uint32_t)__shfl_xor((int)bl_, o, 64) : 0u;
+            const uint32_t oi = (uint32_t)__shfl_xor((int)bi_, o, 64);
             const uint32_t op = (uint32_t)__shfl_xor((int)pos, o, 64);
-            const unsigned long long e = ((unsigned long long)hi << 32) | lo;
-            if (MAX ? e > best : e < best) {
-                best = e;
-                pos = op;
+            const bool oh = __shfl_xor((int)have, o, 64) != 0;
+            if (oh && (!have || better(ok, ol, oi, bk, bl_, bi_))) {
+                bk = ok; bl_ = ol; bi_ = oi; pos = op; have = true;
             }
         }
         pos = uni(pos);
         dd = unif(d[pos]);
+        dlo = WK ? uni(l[pos]) : 0u;
         idv = uni(id[pos]);
         return pos;
     }
@@ -727,12 +804,13 @@ struct NrList {
         if (kdb_lane() == 0) {
             d[pos] = d[count - 1];
             id[pos] = id[count - 1];
+            if (WK) l[pos] = l[count - 1];
         }
         count--;
         wave_lds_fence();
     }
     // worst / full: the result set's current worst distance and whether it holds ef entries
-    __device__ __forceinline__ void push(float dd, uint32_t idv, float worst, bool full) {
+    __device__ __forceinline__ void push(float dd, uint32_t dlo, uint32_t idv, float worst, uint32_t worst_lo, bool full) {
         if (count == cap) {
             if (full) { // discard what can never be expanded any more
                 const uint32_t lane = (uint32_t)kdb_lane();
@@ -740,13 +818,20 @@ struct NrList {
                 for (uint32_t base = 0; base < count; base += 64) {
                     const uint32_t i = base + lane;
                     float e = 0.f;
-                    uint32_t x = 0;
-                    const bool keep = i < count && (e = d[i], x = id[i], !(e > worst));
+                    uint32_t x = 0, el = 0;
+                    bool keep = false;
+                    if (i < count) {
+                        e = d[i];
+                        x = id[i];
+                        if (WK) el = l[i];
+                        keep = !key_lt<WK>(worst, worst_lo, e, el); // !(e > worst)
+                    }
                     const unsigned long long m = __ballot(keep);
                     wave_lds_fence();
                     if (keep) {
                         d[w + kdb_mbcnt(m)] = e;
                         id[w + kdb_mbcnt(m)] = x;
+                        if (WK) l[w + kdb_mbcnt(m)] = el;
                     }
                     w += (uint32_t)__builtin_popcountll(m);
                     wave_lds_fence();
@@ -757,20 +842,22 @@ struct NrList {
                 dropped++;
                 if (cap == 0) return;
                 float md;
-                uint32_t mid;
-                const uint32_t mp = extreme<true>(md, mid);
-                if (!(dd < md || (dd == md && idv < mid))) return;
+                uint32_t ml, mid;
+                const uint32_t mp = extreme<true>(md, ml, mid);
+                if (!(key_lt<WK>(dd, dlo, md, ml) || (key_eq<WK>(dd, dlo, md, ml) && idv < mid))) return;
                 remove(mp);
             }
         }
         if (kdb_lane() == 0) {
             d[count] = dd;
             id[count] = idv;
+            if (WK) l[count] = dlo;
         }
         count++;
         wave_lds_fence();
     }
 };
+using NrList = NrListT<false>;
 
 struct QCtr {
     uint32_t n_dist, n_hops, n_dropped;
@@ -791,7 +878,8 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr) {
     const int lane = kdb_lane();
     b.reset(ef);
-    NrList nr;
+    constexpr bool WK = BeamT::kWide; // int8: 64-bit distance keys (the reference orders float64 distances)
+    NrListT<WK> nr;
     nr.bind(s);
     vis.begin_layer(level > 0);
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
@@ -803,10 +891,11 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         (void)vis.test_and_set(ep, lane == 0);
         bool no_result = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
         if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) no_result = true;
+        const uint32_t ep_lo = WK ? uni(s.nb_lo[0]) : 0u;
         if (no_result) {
-            nr.push(unif(s.nb_d[0]), ep, INFINITY, false);
+            nr.push(unif(s.nb_d[0]), ep_lo, ep, INFINITY, 0u, false);
         } else {
-            b.insert(unif(s.nb_d[0]), ep);
+            b.insert(unif(s.nb_d[0]), ep_lo, ep);
             b.n_res++;
             b.trim(ef);
         }
@@ -816,26 +905,27 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         // heap_pop(candidates): the nearest un-expanded beam entry or the nearest traversal-only candidate
         const int idx = b.next();
         float cur_d = INFINITY;
-        uint32_t cur = 0;
+        uint32_t cur = 0, cur_lo = 0;
         if (idx >= 0) {
             uint32_t cur_f;
-            b.get((uint32_t)idx, cur_d, cur_f);
+            b.get((uint32_t)idx, cur_d, cur_lo, cur_f);
             cur = cur_f & KDB_ID_MASK;
         }
         bool from_nr = false;
         uint32_t nr_pos = 0;
         if (nr.count) { // wave-uniform; only indexes with deleted nodes (or a filtered-out entry point) get here
             float nd;
-            uint32_t nid;
-            nr_pos = nr.extreme<false>(nd, nid);
-            if (idx < 0 || nd < cur_d || (nd == cur_d && nid < cur)) {
+            uint32_t nlo, nid;
+            nr_pos = nr.template extreme<false>(nd, nlo, nid);
+            if (idx < 0 || key_lt<WK>(nd, nlo, cur_d, cur_lo) || (key_eq<WK>(nd, nlo, cur_d, cur_lo) && nid < cur)) {
                 from_nr = true;
                 cur_d = nd;
+                cur_lo = nlo;
                 cur = nid;
             }
         }
         if (idx < 0 && !from_nr) break;
-        if (b.n_res >= ef && cur_d > b.worst) break; // :2501-2506 (only a traversal-only candidate can be this far)
+        if (b.n_res >= ef && key_lt<WK>(b.worst, b.worst_lo, cur_d, cur_lo)) break; // :2501-2506 (only a traversal-only candidate can be this far)
         if (from_nr) {
             nr.remove(nr_pos);
         } else {
@@ -866,23 +956,25 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
+        const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
-        unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || my_d < b.worst));
+        unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
         KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); ctr.t_dist += tq2 - tq1;)
         while (pass) { // sequential, in stored order (:2577-2590)
             const uint32_t j = (uint32_t)__builtin_ctzll(pass);
             pass &= pass - 1;
             const float d = readlane_f(my_d, j);
-            if (!(b.n_res < ef || d < b.worst)) continue;
+            const uint32_t dlo = WK ? readlane_u(my_lo, j) : 0u;
+            if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
             const uint32_t id = readlane_u(my_id, j);
             if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
-                nr.push(d, id, b.worst, b.n_res >= ef);
+                nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
             } else {
                 // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
                 // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
                 // (ef <= 64 stays inside one register slot: ef=64 ran 10 % slower than ef=60 before)
                 if (b.n_res >= ef) b.drop_last();
-                b.insert(d, id);
+                b.insert(d, dlo, id);
                 b.n_res++;
                 b.trim(ef);
                 KDB_T(ctr.n_ins++;)

@@ -25,8 +25,8 @@ using namespace kdbcore;
 
 namespace {
 
-template <int BS> struct BeamSel { using type = RegBeam<BS>; };
-template <> struct BeamSel<0> { using type = LdsBeam; };
+template <int BS, bool WK> struct BeamSel { using type = RegBeam<BS, WK>; };
+template <bool WK> struct BeamSel<0, WK> { using type = LdsBeamT<WK>; };
 template <int VIS> struct VisSel { using type = VisBitset; };
 template <> struct VisSel<1> { using type = VisHash; };
 
@@ -66,16 +66,22 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     if (BS == 0) off += (size_t)beam_cap * 4;
     s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
     if (BS == 0) off += (size_t)beam_cap * 4;
+    s.beam_lo = reinterpret_cast<uint32_t *>(smem + off); // int8: the low words of the 64-bit distance keys
+    if (BS == 0 && PREC == KDB_PREC_I8) off += (size_t)beam_cap * 4;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
+    s.nb_lo = PREC == KDB_PREC_I8 ? reinterpret_cast<uint32_t *>(smem + off) : nullptr;
+    if (PREC == KDB_PREC_I8) off += 64 * 4;
     s.ctl = reinterpret_cast<uint32_t *>(smem + off);
     if (WIDE > 1) off += 16;
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
     s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
     off += (size_t)nr_cap * 4;
+    s.nr_lo = reinterpret_cast<uint32_t *>(smem + off);
+    if (PREC == KDB_PREC_I8) off += (size_t)nr_cap * 4;
     s.nr_cap = nr_cap;
     s.marks = reinterpret_cast<uint32_t *>(smem + off); // VIS=0: un-mark list; VIS=1: the hash table
     s.beam_cap = beam_cap;
@@ -88,7 +94,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
     }
     unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
-    typename BeamSel<BS>::type b;
+    typename BeamSel<BS, PREC == KDB_PREC_I8>::type b;
     b.bind(s);
     typename VisSel<VIS>::type vis;
     if constexpr (VIS == 1) {
@@ -183,8 +189,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
                 float bd_;
-                uint32_t bf_;
-                b.get((uint32_t)best, bd_, bf_);
+                uint32_t bl_, bf_;
+                b.get((uint32_t)best, bd_, bl_, bf_);
                 ep = bf_ & KDB_ID_MASK;
             }
         }
@@ -192,12 +198,15 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         if (!failed) {
             search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
             // results, ascending (:2596-2610), first k
+            // raw & 4 (int8 indexes): out_dist is a double array -- the reference's float64 distances, not their float rounding
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
-                                   PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE);
+                                   PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE,
+                                   (PREC == KDB_PREC_I8 && (raw & 4u)) ? reinterpret_cast<double *>(out_dist) + (size_t)qi * k : nullptr);
         }
         for (uint32_t p = nout + (uint32_t)lane; p < k; p += 64) {
             out_ids[(size_t)qi * k + p] = 0u;
-            out_dist[(size_t)qi * k + p] = INFINITY;
+            if (PREC == KDB_PREC_I8 && (raw & 4u)) reinterpret_cast<double *>(out_dist)[(size_t)qi * k + p] = (double)INFINITY;
+            else out_dist[(size_t)qi * k + p] = INFINITY;
         }
         if (lane == 0) {
             out_count[qi] = nout;
@@ -240,6 +249,10 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.nr_d = nullptr;
     s.nr_id = nullptr;
     s.nr_cap = 0;
+    s.nb_lo = nullptr;
+    s.beam_lo = nullptr;
+    s.nr_lo = nullptr;
+    s.ctl = nullptr;
     const int lane = kdb_lane();
     const uint32_t chunks = (C + 31) / 32;
     const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -535,7 +548,8 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     // holds the 2048 nearest pending ones and counts what it had to drop (kdb_counters.n_dropped)
     const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * 8 : 0) + 64 * 8 + (size_t)nr_cap * 8;
+    constexpr bool WK = PREC == KDB_PREC_I8; // 64-bit distance keys: one more word per beam / neighbour / pending entry
+    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * (WK ? 12 : 8) : 0) + 64 * (WK ? 12 : 8) + (size_t)nr_cap * (WK ? 12 : 8);
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
     const uint32_t hsize = (BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;

@@ -22,6 +22,7 @@ L2, COSINE = 0, 1
 F32, F16, I8 = 0, 1, 2
 SEARCH_NEEDS_REFINE = 1
 SEARCH_PREPARED = 2
+SEARCH_DIST_F64 = 8  # int8 indexes: distances come back as the reference's float64 (KDB_SEARCH_DIST_F64)
 
 _ELEM = {F32: np.float32, F16: np.uint16, I8: np.int8}
 
@@ -229,15 +230,16 @@ class HipIndex:
         return (SEARCH_NEEDS_REFINE if self.needs_refine else 0) | (SEARCH_PREPARED if prepared else 0)
 
     def search_batch(self, queries, k: int, ef: int = 0, allow_bits=None, trace: bool = False, prepared=False,
-                     fail_on_drop: bool = False):
+                     fail_on_drop: bool = False, dist64: bool = False):
         """B queries -> (ids [B,k] u32, raw dist [B,k] f32, count [B] u32[, (n_dist[B], n_hops[B])]).
-        fail_on_drop: KDB_SEARCH_FAIL_ON_DROP -- raise KdbError (status -7) when a walk discarded pending deleted candidates"""
+        fail_on_drop: KDB_SEARCH_FAIL_ON_DROP -- raise KdbError (status -7) when a walk discarded pending deleted candidates
+        dist64 (int8 indexes): dist is float64, the reference's own distances (KDB_SEARCH_DIST_F64)"""
         self._live()
         q = np.ascontiguousarray(queries, dtype=np.float32)
         assert q.ndim == 2 and q.shape[1] == self.dim
         B = q.shape[0]
         ids = np.zeros((B, k), dtype=np.uint32)
-        dist = np.full((B, k), np.inf, dtype=np.float32)
+        dist = np.full((B, k), np.inf, dtype=np.float64 if dist64 else np.float32)
         cnt = np.zeros(B, dtype=np.uint32)
         ab = None if allow_bits is None else np.ascontiguousarray(allow_bits, dtype=np.uint64)
         nd = nh = None
@@ -246,7 +248,7 @@ class HipIndex:
             nh = np.zeros(B, dtype=np.uint32)
             check(self.L.kdb_search_set_trace(self.h, _ptr(nd), _ptr(nh), 0), "set_trace")
         try:
-            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared) | (4 if fail_on_drop else 0),
+            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared) | (4 if fail_on_drop else 0) | (SEARCH_DIST_F64 if dist64 else 0),
                                           _ptr(ids), _ptr(dist), _ptr(cnt)), "kdb_search_batch")
         finally:
             if trace:
@@ -265,15 +267,15 @@ class HipIndex:
                                           _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                           C.c_void_p(stream) if stream else None), "kdb_search_batch_dev")
 
-    def flat_scan_batch(self, queries, k: int, allow_bits=None):
+    def flat_scan_batch(self, queries, k: int, allow_bits=None, dist64: bool = False):
         self._live()
         q = np.ascontiguousarray(queries, dtype=np.float32)
         B = q.shape[0]
         ids = np.zeros((B, k), dtype=np.uint32)
-        dist = np.full((B, k), np.inf, dtype=np.float32)
+        dist = np.full((B, k), np.inf, dtype=np.float64 if dist64 else np.float32)
         cnt = np.zeros(B, dtype=np.uint32)
         ab = None if allow_bits is None else np.ascontiguousarray(allow_bits, dtype=np.uint64)
-        check(self.L.kdb_flat_scan_batch(self.h, _ptr(q), B, k, _ptr(ab), self._flags(), _ptr(ids), _ptr(dist),
+        check(self.L.kdb_flat_scan_batch(self.h, _ptr(q), B, k, _ptr(ab), self._flags() | (SEARCH_DIST_F64 if dist64 else 0), _ptr(ids), _ptr(dist),
                                          _ptr(cnt)), "kdb_flat_scan_batch")
         return ids, dist, cnt
 

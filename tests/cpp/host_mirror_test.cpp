@@ -103,6 +103,32 @@ int main() {
         mb.Stop();
         if (!mb.SearchWithScores(q, 5, nullptr, 10).empty()) bad++; // stopped batcher -> []
     }
+    // Compress to int8 (cosine only, hnsw_index.go:219-222): the scores are the float64 distances the reference computes
+    // (KDB_SEARCH_DIST_F64 through the mirror), ascending, and their float rounding is what the plain ABI call returns
+    {
+        kektor::hnsw::Index cosIdx(dim, KDB_METRIC_COSINE, KDB_PREC_F32, 8, 20, n);
+        std::vector<float> Xn(X);
+        for (uint32_t i = 0; i < n; i++) { // stored cosine rows are normalised (hnsw_index.go:3030-3045)
+            double s2 = 0;
+            for (uint32_t j = 0; j < dim; j++) s2 += (double)Xn[(size_t)i * dim + j] * Xn[(size_t)i * dim + j];
+            const float inv = 1.0f / (float)std::sqrt(s2);
+            for (uint32_t j = 0; j < dim; j++) Xn[(size_t)i * dim + j] *= inv;
+        }
+        cosIdx.UploadRows(1, n, Xn.data());
+        cosIdx.Build(n, 3, 256);
+        auto q8 = cosIdx.Compress(KDB_PREC_I8);
+        std::vector<float> qq(X.begin() + 5 * dim, X.begin() + 6 * dim);
+        auto r8 = q8->SearchWithScores(qq, 10, nullptr, 50);
+        std::vector<uint32_t> ids(10), cnt(1);
+        std::vector<float> df(10);
+        if (kdb_search_batch(q8->handle(), qq.data(), 1, 10, 50, nullptr, 0, ids.data(), df.data(), cnt.data())) bad++;
+        if (r8.size() != 10 || cnt[0] != 10) bad++;
+        for (size_t j = 0; j < r8.size() && j < 10; j++) {
+            if (r8[j].DocID != ids[j] || (float)r8[j].Score != df[j]) bad++;
+            if (j && r8[j].Score < r8[j - 1].Score) bad++;
+        }
+        if (!r8.empty() && (r8[0].DocID != 6 || r8[0].Score > 1e-3)) bad++; // row 5 (id 6) finds itself
+    }
     idx.Close();
     if (!idx.SearchWithScores(q, 10, nullptr, 50).empty()) bad++; // closed index returns []
     std::printf(bad ? "FAIL %d\n" : "ok\n", bad);

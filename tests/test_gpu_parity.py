@@ -207,10 +207,19 @@ def test_search_f16_and_int8(oracle, hip):
     idx.upload_norms(orc.norms()[1:], 1)
     idx.set_quantizer(orc.absmax)
     idx.upload_graph_obj(g)
-    ids, dist, cnt = idx.search_batch(Q, 10, 60)
+    # the reference computes AND orders these distances as float64 (hnsw_index.go:2429-2454): the beam carries 64-bit keys,
+    # so ids, float64 distances and the walk's counters are the oracle's bit for bit; without the flag the same doubles
+    # arrive rounded to float
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 60, trace=True, dist64=True)
+    ids32, dist32, cnt32 = idx.search_batch(Q, 10, 60)
+    assert dist.dtype == np.float64 and np.array_equal(ids, ids32) and np.array_equal(dist.astype(np.float32), dist32)
     for b in range(16):
-        oi, od = orc.search(Q[b], 10, ef=60)
-        assert_same_results_tol(ids[b, :int(cnt[b])], dist[b, :int(cnt[b])].astype(np.float64), oi, od)
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=60, counters=True)
+        assert np.array_equal(ids[b, :int(cnt[b])], oi)
+        assert np.array_equal(dist[b, :int(cnt[b])], od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    with pytest.raises(hip.KdbError):  # float64 output is an int8 matter
+        build_pair(O, hip, X[:200], 0)[1].search_batch(Q, 10, 60, dist64=True)
 
 
 @pytest.mark.parametrize("metric", [1, 0])
@@ -289,16 +298,81 @@ def test_flat_scan_int8(oracle, hip, n, dim, k, B):
     idx.set_quantizer(orc.absmax)
     idx.upload_graph_obj(orc.export_graph())
     Q = make_corpus(B, dim, "normal", seed=82)
-    ids, dist, cnt = idx.flat_scan_batch(Q, k)
-    same = 0
+    ids, dist, cnt = idx.flat_scan_batch(Q, k, dist64=True)
+    ids32, dist32, _ = idx.flat_scan_batch(Q, k)
+    assert np.array_equal(ids, ids32) and np.array_equal(dist.astype(np.float32), dist32)
     for b in range(B):
         oi, od = orc.flat_scan(Q[b], k)
         c = int(cnt[b])
         assert c == len(oi) == k
-        assert_same_results_tol(ids[b, :c], dist[b, :c].astype(np.float64), oi, od)
         assert not (set(ids[b, :c].tolist()) & set(deleted))
-        same += int(np.array_equal(ids[b, :c], oi))
-    assert same >= B - 2, f"{same}/{B} id lists identical"  # f32-rounded distances can swap exact near-ties only
+        # finalists are ordered by their float64 distance (64-bit keys), as the reference orders them: exact
+        assert np.array_equal(ids[b, :c], oi), (b, ids[b, :c], oi)
+        assert np.array_equal(dist[b, :c], od)
+
+
+INT8_CASE_ABSMAX = 0.3
+
+
+def int8_collision_corpus(dim=48, seed=5, n_cand=2_000_000, band=160, filler=3000):
+    """int8 rows whose float64 cosine distances to one query are distinct but share float32 values: out of 2M random
+    rows, `band` consecutive ones (in distance) from the middle of the distribution (~1e-7 apart where float32 resolves
+    1.5e-8..3e-8) + filler rows that are farther away.  Rows are multiples of AbsMax/127, so that Quantize
+    (quantizer.go:150-176) reproduces the integers; the query goes through normalize + Quantize like any cosine query."""
+    rng = np.random.default_rng(seed)
+    qf = rng.standard_normal(dim).astype(np.float32)
+    nq = (qf / np.float32(np.sqrt(np.float64((qf.astype(np.float64) ** 2).sum())))).astype(np.float32)
+    q = np.clip(np.round(nq.astype(np.float64) / INT8_CASE_ABSMAX * 127.0), -127, 127).astype(np.int64)  # what the search sees
+    qn = np.float32(np.sqrt(np.float64((q * q).sum())))
+    all_d, all_r = [], []
+    for c0 in range(0, n_cand, 250_000):
+        R = np.clip(q[None, :] + rng.integers(-50, 51, (250_000, dim)), -127, 127).astype(np.int64)
+        dot = R @ q
+        sn = np.sqrt((R * R).sum(1).astype(np.float64)).astype(np.float32)
+        all_d.append(1.0 - dot.astype(np.float64) / (np.float64(qn) * sn.astype(np.float64)))
+        all_r.append(R.astype(np.int8))
+    d = np.concatenate(all_d)
+    R = np.concatenate(all_r)
+    order = np.argsort(d, kind="stable")
+    pick = order[n_cand // 2: n_cand // 2 + band]  # where the candidates are densest
+    far = order[3 * n_cand // 4: 3 * n_cand // 4 + filler]
+    rows = np.concatenate([R[pick], R[far]])
+    rows = rows[rng.permutation(rows.shape[0])]
+    return (rows.astype(np.float64) * (INT8_CASE_ABSMAX / 127.0)).astype(np.float32), qf
+
+
+def test_int8_float64_order_where_floats_collide(oracle, hip):
+    """int8 distances that are distinct as float64 but equal as float32 (hnsw_index.go:2429-2454 computes and orders
+    float64): the exact scan and the walk must return the oracle's order and doubles, and the result lists must really
+    contain such pairs (else the case does not test what it says)"""
+    O = oracle
+    dim, k = 48, 100
+    X, q = int8_collision_corpus(dim)
+    n = X.shape[0]
+    orc = O.OracleIndex(dim, 1, O.I8, 16, 60, seed=7)
+    orc.set_absmax(INT8_CASE_ABSMAX)
+    orc.add_batch(X)
+    idx = hip.HipIndex(dim, 1, O.I8, 16, 60, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_norms(orc.norms()[1:], 1)
+    idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    Q = np.stack([q, q * np.float32(0.5)] + [X[i] for i in range(6)])
+    ids, dist, cnt = idx.flat_scan_batch(Q, k, dist64=True)
+    collisions = 0
+    for b in range(Q.shape[0]):
+        oi, od = orc.flat_scan(Q[b], k)
+        assert np.array_equal(ids[b], oi), (b, np.nonzero(ids[b] != oi))
+        assert np.array_equal(dist[b], od)
+        f = od.astype(np.float32)
+        collisions += int(np.sum((f[1:] == f[:-1]) & (od[1:] != od[:-1])))
+    assert collisions >= 5, f"{collisions} float32 collisions between distinct float64 distances: the case does not test the order"
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, 200, trace=True, dist64=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = orc.search(Q[b], k, ef=200, counters=True)
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], oi) and np.array_equal(dist[b, :c], od), b
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
 def test_bruteforce_f64_reference_semantics(oracle, hip):
