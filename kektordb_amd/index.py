@@ -376,7 +376,8 @@ class HipIndex:
         if q.ndim != 1 or q.shape[0] != self.dim:
             return []  # dimension mismatch is an error of searchInternal: logged, empty slice (:356-359)
         try:
-            ids, dist, cnt = self.search_batch(q[None, :], k, efSearch, allowList)
+            # int8: Score is the reference's float64 distance (hnsw_index.go:2429-2454), not its float rounding
+            ids, dist, cnt = self.search_batch(q[None, :], k, efSearch, allowList, dist64=(self.precision == I8))
         except KdbError:
             return []  # the reference logs and returns an empty slice (:356-359)
         n = int(cnt[0])
