@@ -206,7 +206,10 @@ KDB_API int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries, u
 /* SearchWithScores for B queries.  queries: [B][dim] f32, un-normalised (the library performs the
  * reference's query prep, hnsw_index.go:404-434).  allow_bits: NULL (nil allow-list) or
  * ((count>>6)+1) uint64 words (a zero bitmap is the non-nil EMPTY list -> zero results).
- * Outputs: out_ids/out_dist [B][k], out_count [B].                                               */
+ * Outputs: out_ids/out_dist [B][k], out_count [B].
+ * Host pointers: batches of 8192 queries and more run as four chunks that alternate between two internal
+ * streams, so the copies of one chunk travel under the walk of another (32768 queries: 9.8 -> 8.4 ms including
+ * both copies); the answers are those of one launch.                                               */
 KDB_API int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
                      const uint64_t *allow_bits, uint32_t flags, uint32_t *out_ids, float *out_dist,
                      uint32_t *out_count);

@@ -272,6 +272,8 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     } while (0)
     const size_t n1 = (size_t)idx->cap + 1;
     KDB_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    KDB_TRY(hipStreamCreateWithFlags(&idx->stream2, hipStreamNonBlocking));
+    KDB_TRY(hipEventCreateWithFlags(&idx->ev_io, hipEventDisableTiming));
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         KDB_TRY(hipEventCreate(&idx->ring_ev0[i]));
         KDB_TRY(hipEventCreate(&idx->ring_ev1[i]));
@@ -335,6 +337,8 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
         if (idx->ring_ev1[i]) (void)hipEventDestroy(idx->ring_ev1[i]);
     }
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    if (idx->stream2) (void)hipStreamDestroy(idx->stream2);
+    if (idx->ev_io) (void)hipEventDestroy(idx->ev_io);
     delete idx;
 }
 
@@ -874,6 +878,69 @@ static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint
     return KDB_OK;
 }
 
+// Host-pointer search of a large batch in chunks that alternate between two streams (and the two scratch lanes): the
+// H2D copy of chunk c+1 and the D2H copy of chunk c-1 run under the walk of chunk c, and the waves that idle at the end of
+// one chunk's launch start on the next.  SURVEY 8d counts the copies into the QPS of this entry point.
+static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef, const uint64_t *allow_bits,
+                                uint32_t flags, uint32_t *out_ids, float *out_dist, uint32_t *out_count, uint32_t chunk) {
+    const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
+    const size_t dim = idx->desc.dim;
+    const size_t qbytes = (size_t)B * dim * 4;
+    const size_t aw = allow_bits ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ids_bytes = al((size_t)B * k * 4), dst_bytes = al((size_t)B * k * dist_bytes), cnt_bytes = al((size_t)B * 4);
+    int rc = ensure_iobuf(idx, al(qbytes) + al(aw) + ids_bytes + dst_bytes + cnt_bytes + 1024);
+    if (rc) return rc;
+    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
+    float *d_q = reinterpret_cast<float *>(p);
+    uint64_t *d_allow = allow_bits ? reinterpret_cast<uint64_t *>(p + al(qbytes)) : nullptr;
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + al(qbytes) + al(aw));
+    unsigned char *d_dist = p + al(qbytes) + al(aw) + ids_bytes;
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_dist + dst_bytes);
+    if (allow_bits) {
+        KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, idx->stream));
+        KDB_HIP(hipEventRecord(idx->ev_io, idx->stream));
+        KDB_HIP(hipStreamWaitEvent(idx->stream2, idx->ev_io, 0));
+    }
+    // copies from / to pageable host memory hold the calling thread until they are done: the results of chunk c-1 are
+    // fetched AFTER chunk c has been queued, so the device always has the next walk in its queue
+    auto fetch = [&](uint32_t b0, uint32_t nb, hipStream_t s) -> int {
+        KDB_HIP(hipMemcpyAsync(out_ids + (size_t)b0 * k, d_ids + (size_t)b0 * k, (size_t)nb * k * 4, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char *>(out_dist) + (size_t)b0 * k * dist_bytes, d_dist + (size_t)b0 * k * dist_bytes,
+                               (size_t)nb * k * dist_bytes, hipMemcpyDeviceToHost, s));
+        KDB_HIP(hipMemcpyAsync(out_count + b0, d_cnt + b0, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+        return KDB_OK;
+    };
+    uint32_t c = 0, prev_b0 = 0, prev_nb = 0;
+    hipStream_t prev_s = nullptr;
+    for (uint32_t b0 = 0; b0 < B; b0 += chunk, c++) {
+        const uint32_t nb = B - b0 < chunk ? B - b0 : chunk;
+        hipStream_t s = (c & 1u) ? idx->stream2 : idx->stream;
+        {
+            KdbLaneGuard lane(idx, s);
+            if (lane.rc) return lane.rc;
+            KDB_HIP(hipMemcpyAsync(d_q + (size_t)b0 * dim, queries + (size_t)b0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, s));
+            rc = search_dev_locked(idx, d_q + (size_t)b0 * dim, nb, k, ef, d_allow, flags, d_ids + (size_t)b0 * k,
+                                   reinterpret_cast<float *>(d_dist + (size_t)b0 * k * dist_bytes), d_cnt + b0, s);
+            if (rc) return rc;
+        }
+        if (prev_s) {
+            rc = fetch(prev_b0, prev_nb, prev_s);
+            if (rc) return rc;
+        }
+        prev_b0 = b0;
+        prev_nb = nb;
+        prev_s = s;
+    }
+    if (prev_s) {
+        rc = fetch(prev_b0, prev_nb, prev_s);
+        if (rc) return rc;
+    }
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    KDB_HIP(hipStreamSynchronize(idx->stream2));
+    return KDB_OK;
+}
+
 extern "C" int kdb_search_batch_multi_dev(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
                                           const uint64_t *d_allow_lists, uint32_t G, uint64_t words_per_list,
                                           const uint32_t *d_allow_of_query, uint32_t flags, uint32_t *d_out_ids,
@@ -918,6 +985,12 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
+    static const uint32_t chunk_min = [] { const char *e = getenv("KDB_HOST_CHUNK_MIN"); return e ? (uint32_t)atoi(e) : 8192u; }();
+    if (B >= chunk_min && chunk_min > 0 && !idx->trace_ndist && !(flags & KDB_SEARCH_FAIL_ON_DROP)) {
+        uint32_t chunk = ((B + 3u) / 4u + 255u) & ~255u; // four chunks, not below 4096 queries each
+        if (chunk < 4096u) chunk = 4096u;
+        return search_staged_chunks(idx, queries, B, k, ef, allow_bits, flags, out_ids, out_dist, out_count, chunk);
+    }
     KdbLaneGuard lane(idx, idx->stream);
     if (lane.rc) return lane.rc;
     int rc = with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,

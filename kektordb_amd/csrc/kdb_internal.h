@@ -70,6 +70,8 @@ struct kdb_index {
     size_t elem = 4;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // second stream of the host-pointer entry points: chunks of a large batch alternate (copies of one chunk under the walk of the other)
+    hipEvent_t ev_io = nullptr;    // the allow list has reached the device (stream -> stream2)
     // device buffers
     void *d_rows = nullptr;
     float *d_norms = nullptr;

@@ -375,6 +375,52 @@ def test_int8_float64_order_where_floats_collide(oracle, hip):
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
+def test_host_batch_in_chunks_equals_one_launch(oracle, hip):
+    """kdb_search_batch with host buffers runs batches >= 8192 in chunks on two streams (copies under the walk): the
+    answers equal those of the device-resident single launch, with and without an allow list, and the oracle's on a
+    sample; int8 with float64 distances goes the same way"""
+    import torch
+    O = oracle
+    n, dim, k, ef, B = 3000, 64, 10, 40, 9000
+    X = make_corpus(n, dim, "normal", seed=61)
+    orc, idx = build_pair(O, hip, X, 1)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    rng = np.random.default_rng(9)
+    Q = (X[rng.integers(0, n, B)] + 0.1 * rng.standard_normal((B, dim))).astype(np.float32)
+    allow = np.zeros((n >> 6) + 1, dtype=np.uint64)
+    for i in range(1, n + 1, 3):
+        allow[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    dev = torch.device("cuda:0")
+    for al in (None, allow):
+        ids, dist, cnt = idx.search_batch(Q, k, ef, allow_bits=al)
+        oi = torch.zeros((B, k), dtype=torch.int32, device=dev); od = torch.zeros((B, k), device=dev); oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+        d_al = None if al is None else torch.from_numpy(al.view(np.int64)).to(dev)
+        idx.search_batch_dev(torch.from_numpy(Q).to(dev), k, ef, oi, od, oc, d_al)
+        idx.sync()
+        assert np.array_equal(ids, oi.cpu().numpy().view(np.uint32))
+        assert np.array_equal(dist, od.cpu().numpy()) and np.array_equal(cnt, oc.cpu().numpy().view(np.uint32))
+        for b in list(range(0, B, 997)) + [B - 1]:
+            wi, wd = orc.search(Q[b], k, allow=al, ef=ef)
+            c = int(cnt[b])
+            assert np.array_equal(ids[b, :c], wi) and np.array_equal(raw_to_score(idx, dist[b, :c]), wd), b
+    # int8, float64 distances, chunked
+    o8 = O.OracleIndex(dim, 1, O.I8, 16, 60, seed=7)
+    o8.set_absmax(float(np.quantile(np.abs(X / np.linalg.norm(X, axis=1, keepdims=True)), 0.999)))
+    o8.add_batch(X)
+    i8 = hip.HipIndex(dim, 1, O.I8, 16, 60, capacity=n + 8)
+    i8.upload_rows(o8.rows()[1:], 1)
+    i8.upload_norms(o8.norms()[1:], 1)
+    i8.set_quantizer(o8.absmax)
+    i8.upload_graph_obj(o8.export_graph())
+    ids, dist, cnt = i8.search_batch(Q, k, ef, dist64=True)
+    ids1, dist1, cnt1 = i8.search_batch(Q[:5000], k, ef, dist64=True)  # below the chunking threshold: one launch
+    assert np.array_equal(ids[:5000], ids1) and np.array_equal(dist[:5000], dist1) and np.array_equal(cnt[:5000], cnt1)
+    for b in list(range(0, B, 1499)) + [B - 1]:
+        wi, wd = o8.search(Q[b], k, ef=ef)
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], wi) and np.array_equal(dist[b, :c], wd), b
+
+
 def test_bruteforce_f64_reference_semantics(oracle, hip):
     # BruteForceIndex (vector_index.go:104-162) scores squared L2 in f64: the f32 GPU scan must agree
     # within the stated tolerance
