@@ -1,4 +1,5 @@
 #!/bin/bash
+# two builds interleaved on one box: the big-tile flat scan at 8192 / 1024 queries and config 3, after the parity tests
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 cd $R && timeout 900 python -m pytest tests/test_gpu_flat_big.py -x -q 2>&1 | tail -3
