@@ -1582,7 +1582,7 @@ static int kdb_flat_big_min() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("KDB_FLAT_BIG_MIN");
-        v = e ? atoi(e) : 257;
+        v = e ? atoi(e) : 33;
         if (v < 1) v = 1;
     }
     return v;
@@ -1656,12 +1656,22 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
     const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
                          (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
-    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u;
+    // which kernel (measured at 1M x 768, scripts/flat_probe.py): the streaming kernel re-reads the rows once per 16 queries
+    // and wins up to 32 queries (0.47 ms at 32); the big-tile kernel (flat_scan_big.cuh: 256 queries x 256 rows per
+    // workgroup; rows must be whole 128-byte slabs, >= 3 of them, in a 1- or 2-byte encoding: int8 rows, float16 rows, or the
+    // half-precision ranking copy of float32 rows) wins from 65 queries on (128 queries 0.92 vs 1.20 ms for the 128 x 128
+    // tile kernel, 256 queries 1.10 vs 1.81 ms; k=100: 1.30 vs 3.66 ms) and between 33 and 64 queries when the lists are
+    // short (k=10, 48 queries: 0.69 vs 1.04 ms; k=100, 64 queries: 1.12 vs 0.94 ms)
+    const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : v.ld * 2u;
+    const bool rank16_ok = v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) && idx->max_norm2 > 0.f &&
+                           idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
+    const bool big_ok = B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u && rowb >= 3u * FB_SLAB &&
+                        (v.precision == KDB_PREC_I8 || v.precision == KDB_PREC_F16 || (rank16_ok && idx->d_rows16 != nullptr));
+    const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u && !(big_ok && B > 32u && kl <= 48u);
     // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly
     // (only when the library normalised the queries itself and the rows are far from the f16 range limit)
     // (small batches rank on the half-precision copy of the rows, when the index keeps one: half the HBM bytes)
-    const bool rank16 = (!small || idx->d_rows16) && v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) &&
-                        idx->max_norm2 > 0.f && idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
+    const bool rank16 = (!small || idx->d_rows16) && rank16_ok;
 
     // ---- scan list: identity, or the compacted ids of the rows that are live and allowed.  Nothing on this path
     //      waits for the device: the number of rows to scan stays in HBM and every kernel derives the stripe
@@ -1687,12 +1697,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
     // buffered mode: kl entries + room for max(kl, 64) appends between two compactions (<= 320 in all)
     const uint32_t cap = (small || kl <= (uint32_t)FS_LDS_KL) ? kl : kl + (kl > 64u ? kl : 64u);
-    // ---- large batches rank with the big-tile kernel (flat_scan_big.cuh): 256 queries x 256 rows per workgroup, LDS-DMA
-    //      staging, one workgroup per CU.  Rows must be whole 128-byte slabs (>= 3 of them) in a 1- or 2-byte encoding:
-    //      int8 rows, float16 rows, or the half-precision ranking copy of float32 rows.
-    const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : v.ld * 2u;
-    const bool big = !small && B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u && rowb >= 3u * FB_SLAB &&
-                     (v.precision == KDB_PREC_I8 || v.precision == KDB_PREC_F16 || (rank16 && idx->d_rows16 != nullptr));
+    const bool big = !small && big_ok;
     uint32_t fb_nqt = 0, fb_nqg = 1, fb_nqx = 1, fb_spx = 1, want_big = 1;
     if (big) {
         fb_nqt = (B + FB_T - 1) / FB_T;                 // <= 32 (batches above 8192 queries are split)
