@@ -322,7 +322,8 @@ def main():
         for name, fn in (("batch_sweep", lambda: batch_sweep(idx, Q, k, ef, dev)),
                          ("pcie_inclusive", lambda: pcie_inclusive(idx, Q, k, ef)),
                          ("flat_scan_leg", lambda: flat_leg(idx, Q, k, n, dim, a.flat_batch, dev)),
-                         ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev))):
+                         ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev)),
+                         ("baseline_configs_2_and_4", lambda: big_configs_leg(K, dev))):
             try:
                 res[name] = fn()
             except Exception as e:  # never lose the headline
@@ -511,6 +512,80 @@ def iid_leg(K, n, dim, k, a, dev):
                                 "qps": round(B / t, 1)}
     idx.Close()
     return res
+
+
+def big_configs_leg(K, dev, rows=10_000_000, nq=1024):
+    """BASELINE configs[2] (10M x 768 L2 k=100, exact flat scan) and configs[4] (10M x 1536 cosine, category filter at
+    1 % selectivity -> exact scan over the allowed rows) at FULL size, 1024 queries resident in HBM: time only -- their
+    parity tests (oracle, shard identity, subset property) are tests/test_gpu_configs.py.  Side legs, never `value`."""
+    from kektordb_amd.index import dense_bitset
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    out = {}
+
+    def rows_of(n, dim, normalize, centers=None, chunk=1_000_000):
+        X = torch.empty((n, dim), device=dev)
+        for s in range(0, n, chunk):
+            e = min(n, s + chunk)
+            if centers is None:
+                X[s:e] = torch.randn((e - s, dim), device=dev, generator=g)
+            else:
+                lab = torch.randint(0, centers.shape[0], (e - s,), device=dev, generator=g)
+                X[s:e] = centers[lab] + 0.3 * torch.randn((e - s, dim), device=dev, generator=g)
+            if normalize:
+                X[s:e] /= X[s:e].norm(dim=1, keepdim=True)
+        return X
+
+    def timed_scan(idx, Q, k, d_allow=None, reps=3):
+        o = outs(Q.shape[0], k, dev)
+        idx.flat_scan_batch_dev(Q, k, *o, d_allow=d_allow)
+        idx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx.flat_scan_batch_dev(Q, k, *o, d_allow=d_allow)
+        idx.sync()
+        wall = (time.perf_counter() - t0) / reps
+        kms = float(np.mean([x["kernel_ms"] for x in idx.launch_stats(reps)]))
+        return wall, kms, o
+
+    # configs[2]: iid N(0,1) rows, not normalised (SURVEY 8d C3)
+    n, dim, k = rows, 768, 100
+    X = rows_of(n, dim, False)
+    Q = torch.randn((nq, dim), device=dev, generator=g)
+    idx = K.HipIndex(dim, K.L2, K.F32, 16, 200, capacity=n)
+    idx.upload_rows(X, 1)
+    idx.set_count(n)
+    del X
+    wall, kms, o = timed_scan(idx, Q, k)
+    out["configs[2]"] = {"workload": f"{n}x{dim} L2 k={k}, exact flat scan, {nq} queries", "ms_per_batch": round(wall * 1e3, 2),
+                         "ranking_kernel_ms": round(kms, 2), "qps": round(nq / wall, 1),
+                         "ranking_tflops": round(2.0 * nq * n * dim / kms / 1e9, 1),
+                         "sorted": bool((o[1][:, 1:] >= o[1][:, :-1]).all().item()),
+                         "note": "HNSW over these rows (GPU build 56 s) is in DESIGN 6; not built inside the bench"}
+    idx.Close()
+    del idx
+    torch.cuda.empty_cache()
+    # configs[4]: clustered unit rows, 100 categories, all queries share one category filter (1 % of the rows)
+    dim, k = 1536, 10
+    cent = torch.randn((4096, dim), device=dev, generator=g)
+    X = rows_of(n, dim, True, centers=cent)
+    Q = rows_of(nq, dim, True, centers=cent)
+    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 200, capacity=n)
+    idx.upload_rows(X, 1)
+    idx.set_count(n)
+    del X
+    cat = torch.randint(0, 100, (n,), device=dev, generator=g)
+    ids = (torch.nonzero(cat == 7).flatten() + 1).cpu().numpy()
+    ab = torch.from_numpy(dense_bitset(ids, n).view(np.int64)).to(dev)
+    wall, kms, o = timed_scan(idx, Q, k, d_allow=ab)
+    got = o[0].cpu().numpy().view(np.uint32)
+    out["configs[4]"] = {"workload": f"{n}x{dim} cosine k={k}, 1 % category filter shared by {nq} queries -> exact scan over {ids.size} allowed rows",
+                         "ms_per_batch": round(wall * 1e3, 2), "ranking_kernel_ms": round(kms, 2), "qps": round(nq / wall, 1),
+                         "answers_inside_filter": bool(np.isin(got[got > 0], ids).all())}
+    idx.Close()
+    del idx
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(idx, Q, k, ef, n, dim, a):
