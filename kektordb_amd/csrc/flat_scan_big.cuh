@@ -19,8 +19,14 @@
 //   * selection: the score tile never leaves the registers.  Lane (j, h) of a wave holds, for query j of each of its two
 //     32-query columns, the keys of 64 rows.  A 16-register block is looked at only when its minimum beats the
 //     query's threshold; survivors are APPENDED (LDS atomic on the list length) to the query's list in HBM scratch,
-//     which has room for kl + FB_SLACK + 256 entries: a tile cannot overflow it, and after every tile whole waves
-//     compact the lists that grew past kl + FB_SLACK down to their kl best (fs_compact_wave), tightening the threshold.
+//     which has room for kl + slack + period * 256 entries: `period` tiles cannot overflow it, and every `period` tiles
+//     whole waves compact the lists that grew past kl + slack down to their kl best (fs_compact_wave), tightening the
+//     threshold;
+//   * thresholds are shared between the stripes of a query: after a compaction a stripe publishes the r-th smallest key
+//     of its list, r = ceil(kl / n_stripes); the largest of the published keys bounds the kl-th best key of the whole
+//     corpus (every stripe holds r rows at or below its own), so every workgroup lowers its thresholds to it.  A list may
+//     then hold fewer than its stripe's kl best; the stripe hands over the threshold it ended with (part_thr) and the
+//     merge treats its list as complete only below that.
 // The keys are ranking keys only (f16 products summed in the MFMA's order, ||x||^2 - 2 q.x, -dot/||x||): the merge
 // kernel re-scores the finalists in the order of the graph search, exactly as for the other scan kernels.
 
