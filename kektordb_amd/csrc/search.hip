@@ -579,8 +579,16 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     if constexpr (BS == 2) {
         // latency mode: a batch that leaves most of the chip idle gives every query four waves (one HBM round trip per
         // hop instead of three); same walk, same results, same counters
-        static const uint32_t wide_max = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? (uint32_t)atoi(e) : 128u; }();
-        if (hsize && B <= wide_max) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>, hsize, 4u);
+        // (as long as every query gets its own resident workgroup: 512 at 768-d float32; measured 1M x 768, ef=60, one box:
+        // 64 queries 0.554 -> 0.511 ms, 256 queries 0.650 -> 0.611 ms, 512 queries 0.665 -> 0.625 ms)
+        static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
+        if (hsize) {
+            auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
+            const size_t wlds = lds1 + 16;
+            if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+            const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
+            if (B <= wide_max) return launch(wk, hsize, 4u);
+        }
     }
     if constexpr (BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);

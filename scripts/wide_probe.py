@@ -20,7 +20,7 @@ idx.upload_rows(X, 1); del X
 idx.build(n, batch=16384, ef_construction=200, seed=1)
 print("KDB_WIDE_MAX_B =", os.environ.get("KDB_WIDE_MAX_B"))
 sig = []
-for B in ((a.only,) if a.only else (1, 8, 32, 64, 128, 256)):
+for B in ((a.only,) if a.only else (1, 8, 32, 64, 128, 256, 384, 512)):
     q = Q[:B].contiguous()
     oi = torch.zeros((B, k), dtype=torch.int32, device=dev); od = torch.zeros((B, k), device=dev); oc = torch.zeros((B,), dtype=torch.int32, device=dev)
     for _ in range(3 if a.reps > 1 else 0): idx.search_batch_dev(q, k, ef, oi, od, oc)
