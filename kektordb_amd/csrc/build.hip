@@ -82,6 +82,7 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
+    s.spec = 0u;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;

@@ -42,9 +42,11 @@ struct WaveLds {
     uint32_t *nb_lo;   // [64]   int8 only: low word of the 64-bit distance key (kdb_i8_key)
     uint32_t *beam_lo; // [cap]  int8 + LdsBeam
     uint32_t *nr_lo;   // [nr_cap] int8
-    uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit, [1] query norm bits
+    uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit / speculative hop, [1] query norm bits, [2] node
+    uint32_t spec;     // latency mode, few queries: the helper waves fetch ALL neighbours of a level-0 hop beside the visited test
 };
 constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;
+constexpr uint32_t KDB_COOP_SPEC = 0xfffffffeu;
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
 // told they are uniform
@@ -309,13 +311,36 @@ __device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32
         __syncthreads(); // ... distances back in nb_d
     }
 }
+// Speculative hop (few queries in flight, level 0): while wave 0 fetches node `cur`'s neighbour list and tests it against
+// the visited set, the helper waves fetch the same list and evaluate ALL its rows -- helper h (1..WIDE-1) the slots
+// [(h-1)*c, h*c), c = ceil(deg0 / (WIDE-1)) -- into nb_d[slot].  Rows that turn out to be visited already are read for
+// nothing (4x the row bytes of the hop: affordable only while the batch leaves HBM idle), but the row round trip no longer
+// waits for the visited test and the compaction; wave 0 then inserts the fresh slots in stored order, as before.
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void coop_spec_share(const KdbView &v, const WaveLds &s, uint32_t cur, float qnorm, uint32_t wave) {
+    const uint32_t lane = (uint32_t)kdb_lane();
+    const uint32_t chunk = (v.deg0 + (uint32_t)WIDE - 2u) / ((uint32_t)WIDE - 1u);
+    const uint32_t lo = (wave - 1u) * chunk;
+    if (lo >= v.deg0) return;
+    const uint32_t cnt = v.deg0 - lo < chunk ? v.deg0 - lo : chunk;
+    uint32_t nb = lane < cnt ? v.adj0[(size_t)cur * v.deg0 + lo + lane] : 0u;
+    if (nb > v.count) nb = 0u; // row 0 is all zero
+    if (lane < cnt) s.nb_id[lo + lane] = nb;
+    wave_lds_fence();
+    WaveLds s2 = s;
+    s2.nb_id = s.nb_id + lo;
+    s2.nb_d = s.nb_d + lo;
+    if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
+    compute_dists<PREC, METRIC, NCH>(v, s2, cnt, qnorm);
+}
 template <int PREC, int METRIC, int NCH, int WIDE>
 __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
     for (;;) {
         __syncthreads();
         const uint32_t n = uni(s.ctl[0]);
         if (n == KDB_COOP_EXIT) return;
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[1])), wave);
+        if (n == KDB_COOP_SPEC) coop_spec_share<PREC, METRIC, NCH, WIDE>(v, s, uni(s.ctl[2]), __uint_as_float(uni(s.ctl[1])), wave);
+        else coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[1])), wave);
         __syncthreads();
     }
 }
@@ -937,6 +962,18 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter();)
         const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
                                          : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
+        bool spec_hop = false;
+        if constexpr (WIDE > 1) {
+            if (s.spec && level == 0) { // the helper waves start on the rows now (coop_spec_share)
+                spec_hop = true;
+                if (lane == 0) {
+                    s.ctl[0] = KDB_COOP_SPEC;
+                    s.ctl[1] = __float_as_uint(qnorm);
+                    s.ctl[2] = cur;
+                }
+                __syncthreads();
+            }
+        }
         uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
         // visited test-and-set (:2539-2542)
         bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
@@ -944,6 +981,35 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         const unsigned long long m = __ballot(fresh);
         const uint32_t n = (uint32_t)__builtin_popcountll(m);
         KDB_T(ctr.t_adj += __builtin_readcyclecounter() - tq0;)
+        if constexpr (WIDE > 1) {
+            if (spec_hop) { // distances of ALL slots are on their way: nb_d[slot]; the fresh ones are inserted in stored order
+                const uint32_t delw_s = (fresh && v.has_deleted) ? v.deleted[nb >> 5] : 0u;
+                __syncthreads();
+                if (n == 0) continue;
+                ctr.n_dist += n;
+                const bool nr_s = ((delw_s >> (nb & 31)) & 1u) != 0;
+                const float d_s = fresh ? s.nb_d[lane] : INFINITY;
+                const uint32_t lo_s = (WK && fresh) ? s.nb_lo[lane] : 0u;
+                unsigned long long pass = __ballot(fresh && (b.n_res < ef || key_lt<WK>(d_s, lo_s, b.worst, b.worst_lo)));
+                while (pass) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(pass);
+                    pass &= pass - 1;
+                    const float d = readlane_f(d_s, j);
+                    const uint32_t dlo = WK ? readlane_u(lo_s, j) : 0u;
+                    if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
+                    const uint32_t id = readlane_u(nb, j);
+                    if (readlane_u((uint32_t)nr_s, j) != 0) {
+                        nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
+                    } else {
+                        if (b.n_res >= ef) b.drop_last();
+                        b.insert(d, dlo, id);
+                        b.n_res++;
+                        b.trim(ef);
+                    }
+                }
+                continue;
+            }
+        }
         if (n == 0) continue;
         if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
         wave_lds_fence();

@@ -76,6 +76,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     if (PREC == KDB_PREC_I8) off += 64 * 4;
     s.ctl = reinterpret_cast<uint32_t *>(smem + off);
     if (WIDE > 1) off += 16;
+    s.spec = (WIDE > 1 && (raw & 8u)) ? 1u : 0u;
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
     s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
@@ -253,6 +254,7 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
+    s.spec = 0u;
     const int lane = kdb_lane();
     const uint32_t chunks = (C + 31) / 32;
     const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -559,7 +561,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t ncu = (uint32_t)idx->n_cu;
-    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
+    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u, uint32_t raw_extra = 0u) -> int {
         const size_t lds = lds1 + (waves > 1u ? 16u : 0u);
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
@@ -570,7 +572,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw | raw_extra, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
@@ -587,7 +589,12 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
             const size_t wlds = lds1 + 16;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
-            if (B <= wide_max) return launch(wk, hsize, 4u);
+            // 16..256 queries: the helper waves fetch every neighbour's row beside the visited test (coop_spec_share; measured
+            // on one box, 1M x 768, ef=60: 32 / 64 / 128 / 256 queries 0.515 / 0.515 / 0.528 / 0.616 -> 0.471 / 0.476 / 0.493 /
+            // 0.591 ms; a single short walk loses 13 %, 384+ queries run into the HBM bandwidth the extra rows cost)
+            static const uint32_t spec_max = [] { const char *e = getenv("KDB_WIDE_SPEC_MAX_B"); return e ? (uint32_t)atoi(e) : 256u; }();
+            static const uint32_t spec_min = [] { const char *e = getenv("KDB_WIDE_SPEC_MIN_B"); return e ? (uint32_t)atoi(e) : 16u; }();
+            if (B <= wide_max) return launch(wk, hsize, 4u, (B >= spec_min && B <= spec_max) ? 8u : 0u);
         }
     }
     if constexpr (BS == 2 || BS == 4) {
