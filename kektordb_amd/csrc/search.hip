@@ -14,7 +14,9 @@
 //     fills; large ef uses the bitset (atomicOr test-and-set, upper layers un-mark what they marked);
 //   * the query is prepared inside the kernel (normalise in the reference's order, f16 round trip) straight from the
 //     caller's buffer; queries are pulled from an atomic work counter by persistent waves;
-//   * one allow list per batch or one per query; its entry point (hnsw_index.go:437-447) is chosen on the device.
+//   * one allow list per batch or one per query; its entry point (hnsw_index.go:437-447) is chosen on the device;
+//   * small batches (every query gets its own resident workgroup) run four waves per query: wave 0 walks, all four
+//     evaluate the rows of a hop (dists() / coop_spec_share() in kdb_search_core.cuh) -- same walk, same counters.
 #include "kdb_search_core.cuh"
 #include <map>
 #include <mutex>
