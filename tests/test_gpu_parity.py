@@ -375,6 +375,28 @@ def test_int8_float64_order_where_floats_collide(oracle, hip):
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
+@pytest.mark.parametrize("metric,dim", [(1, 128), (0, 96), (1, 768)])
+def test_search_same_answers_in_every_batch_mode(oracle, hip, metric, dim):
+    """one wave per query (large batches), four waves per query, four waves with the helpers fetching every neighbour's
+    row (16..256 queries): a query's ids, distance bits and n_dist / n_hops do not depend on the batch it arrives in"""
+    O = oracle
+    n = 3000 if dim < 768 else 1200
+    X = make_corpus(n, dim, "normal", seed=71)
+    orc, idx = build_pair(O, hip, X, metric)
+    Q = make_corpus(700, dim, "normal", seed=72)
+    k, ef = 10, 48
+    ref_ids, ref_d, ref_c, (ref_nd, ref_nh) = idx.search_batch(Q, k, ef, trace=True)  # 700 queries: one wave per query
+    for B in (1, 15, 16, 17, 64, 200, 256, 257, 512, 513):
+        ids, d, c, (nd, nh) = idx.search_batch(Q[:B], k, ef, trace=True)
+        assert np.array_equal(ids, ref_ids[:B]) and np.array_equal(d, ref_d[:B]) and np.array_equal(c, ref_c[:B]), B
+        assert np.array_equal(nd, ref_nd[:B]) and np.array_equal(nh, ref_nh[:B]), B
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    for b in (0, 5, 699):
+        wi, wd, (ond, onh) = orc.search(Q[b], k, ef=ef, counters=True)
+        c = int(ref_c[b])
+        assert np.array_equal(ref_ids[b, :c], wi) and (int(ref_nd[b]), int(ref_nh[b])) == (ond, onh)
+
+
 def test_host_batch_in_chunks_equals_one_launch(oracle, hip):
     """kdb_search_batch with host buffers runs batches >= 8192 in chunks on two streams (copies under the walk): the
     answers equal those of the device-resident single launch, with and without an allow list, and the oracle's on a
