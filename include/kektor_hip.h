@@ -255,8 +255,9 @@ KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint3
  * float32 one, rows never leaving HBM.  int8: Quantizer.Train (quantizer.go:49-135: strided sample, 99.9th percentile of
  * |v|, found exactly by a radix select), Quantize and the stored norms for every row; float16: RNE conversion.  The new
  * index keeps the float32 index's GRAPH (ids, links, deleted bits) unless KDB_COMPRESS_REBUILD_GRAPH asks the GPU builder
- * to re-insert every row with the new precision's distances, which is what the reference's AddBatch loop does (float16
- * only).  The source is left as it is; the caller owns *out (kdb_index_destroy).                                   */
+ * to re-insert every row with the new precision's distances (float16 squared L2; int8: the float64 cosine distance over
+ * the quantised rows and stored norms), which is what the reference's AddBatch loop does (core.go:1236-1283).  The
+ * source is left as it is; the caller owns *out (kdb_index_destroy).                                               */
 #define KDB_COMPRESS_REBUILD_GRAPH 1u
 KDB_API int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t flags, kdb_index **out);
 KDB_API int kdb_index_get_quantizer(kdb_index *idx, float *abs_max);
@@ -267,11 +268,12 @@ KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_para
 /* TEST HOOK -- selectNeighbors (hnsw_index.go:2629-2701) exactly as the GPU builder runs it (build_select_kernel's
  * workgroup routine), on caller-supplied candidate lists: list t holds cand_cnt[t] <= stride <= 320 entries at
  * cand_ids / cand_keys + t*stride, ids of rows already uploaded, keys = distance of the candidate to the centre in the
- * library's ordering form (squared L2; MINUS the dot product for cosine), ASCENDING.  out_ids: [n_lists][maxm], 0-filled
- * behind out_cnt[t].  maxm <= 64.  Host pointers.  Exists so that the parity suite can hand identical lists to this and
- * to the oracle's select_neighbors; the shim has no use for it.                                                  */
+ * library's ordering form, ASCENDING: FLOATS for float32 / float16 indexes (squared L2; MINUS the dot product for cosine),
+ * DOUBLES for int8 indexes (the reference's float64 cosine distance, hnsw_index.go:317-336).  out_ids: [n_lists][maxm],
+ * 0-filled behind out_cnt[t].  maxm <= 64.  Host pointers.  Exists so that the parity suite can hand identical lists to
+ * this and to the oracle's select_neighbors; the shim has no use for it.                                          */
 KDB_API int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *cand_ids,
-                                      const float *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
+                                      const void *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
                                       uint32_t *out_cnt);
 
 /* Shard merge: G per-shard results for B queries -> global top-k.  in_ids/in_dist: [G][B][k],

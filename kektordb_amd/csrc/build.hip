@@ -17,6 +17,11 @@
 // Levels are drawn on the host as randomLevel() does (:2616-2625): floor(-ln U / ln m), capped at
 // currentMax+1, from a seeded splitmix64 stream (the reference uses the auto-seeded global RNG).
 //
+// Distances: float32 / float16 rows order their candidates by float keys (squared L2, minus the dot product); int8 rows
+// (cosine only) by the reference's float64 distance 1 - dot / (|a| |b|) (hnsw_index.go:317-336 node<->node, :2406-2454
+// query<->node): the i32 dot is exact in any order, so every int8 distance -- and with it every link decision -- is the
+// oracle's bit for bit.  The key type KT (float / double) is a template parameter of everything below.
+//
 // selectNeighbors on the GPU: candidates are visited in blocks of 32; the block's rows and the rows
 // selected so far are staged through LDS in K-chunks, every (candidate, selected) and
 // (candidate, earlier candidate) distance of the block is accumulated by the 256 threads, then one
@@ -40,21 +45,25 @@ constexpr int PR_MAXC = 320;          // max candidates per prune task (efC <= 2
 constexpr uint32_t RCAP = 16;         // reverse requests kept per (target, level) per batch
 constexpr uint32_t UP_FLAG = 0x80000000u;
 
-struct BuildView {
+template <int PREC> struct BKey { using T = float; };
+template <> struct BKey<KDB_PREC_I8> { using T = double; }; // the reference's float64 cosine distance
+
+template <typename KT>
+struct BuildViewT {
     uint32_t *adj0;      // writable graph
     uint32_t *adj_up;
-    float *adj0_key;     // distance (key) of every stored link to its owner
-    float *adj_up_key;
+    KT *adj0_key;        // distance (key) of every stored link to its owner
+    KT *adj_up_key;
     uint32_t *rev0_cnt;  // [(cap+1)]
     uint32_t *revup_cnt; // [up slots]
     uint32_t *rev0_id;   // [(cap+1) * RCAP]
-    float *rev0_key;
+    KT *rev0_key;
     uint32_t *revup_id;  // [up slots * RCAP]
-    float *revup_key;
+    KT *revup_key;
     uint32_t *touched;   // touched (target, level) codes
     uint32_t *n_touched;
     uint32_t *cand_id;   // [tasks * efc]
-    float *cand_key;
+    KT *cand_key;
     uint32_t *cand_cnt;  // [tasks]
     uint32_t *up_task;   // [batch] first upper task of a batch node
     uint32_t efc;
@@ -66,19 +75,19 @@ struct BuildView {
 // ---- phase 1 ------------------------------------------------------------------------------------
 template <int METRIC, int BS, int PREC>
 __global__ void __launch_bounds__(64)
-build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
+build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool I8 = PREC == KDB_PREC_I8;
     WaveLds s;
     size_t off = 0;
     s.q = reinterpret_cast<float *>(smem + off);
-    off += (size_t)v.ld * 4;
+    off += I8 ? (size_t)v.ld : (size_t)v.ld * 4; // int8: the packed row itself (ld is a multiple of 16)
     s.beam_d = nullptr;
     s.beam_id = nullptr;
     s.beam_cap = 0;
     s.nr_d = nullptr; // construction never meets a deleted node or a filter
     s.nr_id = nullptr;
     s.nr_cap = 0;
-    s.nb_lo = nullptr; // (int8 graphs are never built: Compress keeps the float32 graph)
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
@@ -88,6 +97,8 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
+    s.nb_lo = I8 ? reinterpret_cast<uint32_t *>(smem + off) : nullptr; // int8: low words of the 64-bit distance keys
+    if (I8) off += 64 * 4;
     s.marks = reinterpret_cast<uint32_t *>(smem + off);
     const int lane = kdb_lane();
     VisBitset vis;
@@ -102,7 +113,14 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         const uint32_t node = bv.first + bi;
         const int L = (int)v.levels[node];
         vis.begin_query();
-        if (PREC == KDB_PREC_F16) { // the node's own f16 row, widened (exactly) to the f32 query the search keeps in LDS
+        float qnorm = 1.f;
+        if constexpr (I8) { // the node's own int8 row is the query (:1805-1813); its norm as distFn takes it (:2411-2418: 0 -> 1)
+            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const int8_t *>(v.rows) + (size_t)node * v.ld);
+            uint4 *dst = reinterpret_cast<uint4 *>(s.q);
+            for (uint32_t i = (uint32_t)lane; i < (v.ld >> 4); i += 64) dst[i] = src[i];
+            qnorm = v.norms[node];
+            if (qnorm == 0.f) qnorm = 1.f;
+        } else if (PREC == KDB_PREC_F16) { // the node's own f16 row, widened (exactly) to the f32 query the search keeps in LDS
             const uint16_t *src = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)node * v.ld;
             for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = (float)__builtin_bit_cast(_Float16, src[i]);
         } else {
@@ -112,16 +130,19 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
         }
         __threadfence_block();
         wave_lds_fence();
-        RegBeam<BS> b;
-        QCtr ctr{0, 0, 0};
+        RegBeam<BS, I8> b;
+        QCtr ctr{};
         uint32_t ep = v.entry;
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;
-            search_layer<PREC, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, 1.f, ctr);
+            search_layer<PREC, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, qnorm, ctr);
             if (insert) {
                 const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
-                const uint32_t nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc,
-                                                    bv.cand_key + (size_t)task * bv.efc, false);
+                uint32_t nc;
+                if constexpr (I8)
+                    nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc, nullptr, false, bv.cand_key + (size_t)task * bv.efc);
+                else
+                    nc = b.write_results(bv.efc, bv.cand_id + (size_t)task * bv.efc, bv.cand_key + (size_t)task * bv.efc, false);
                 if (lane == 0) bv.cand_cnt[task] = nc;
             }
             if (b.count > 0) { // nearest (:786-788 / :1849)
@@ -135,42 +156,61 @@ build_search_kernel(KdbView v, BuildView bv, uint32_t beam_cap, uint32_t *visite
 }
 
 // ---- selectNeighbors on a workgroup ---------------------------------------------------------------
-struct PruneLds {
+template <typename KT>
+struct PruneLdsT {
     uint32_t *c_id;    // [PR_MAXC] candidates ascending by (key,id)
-    float *c_key;      // [PR_MAXC]
+    KT *c_key;         // [PR_MAXC]
     uint32_t *s_id;    // [PR_MAXSEL]
-    float *s_key;      // [PR_MAXSEL]
+    KT *s_key;         // [PR_MAXSEL]
     uint16_t *disc;    // [PR_MAXC] discarded candidate indices, in order
-    float *rows;       // [(PR_BLK + PR_MAXSEL) * PR_STRIDE]
-    float *m1;         // [PR_BLK][PR_MAXSEL]
-    float *m2;         // [PR_BLK][PR_BLK]
+    float *rows;       // [(PR_BLK + PR_MAXSEL) * PR_STRIDE] 4-byte words: f32 values, or four packed int8
+    KT *m1;            // [PR_BLK][PR_MAXSEL]
+    KT *m2;            // [PR_BLK][PR_BLK]
     uint32_t *misc;    // [8]: 0 n_sel, 1 n_disc
 };
 
-__device__ __forceinline__ void prune_carve(unsigned char *smem, PruneLds &p) {
+template <typename KT>
+__host__ __device__ constexpr size_t prune_lds_bytes() {
+    return (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 + (size_t)PR_BLK * PR_MAXSEL * sizeof(KT) + (size_t)PR_BLK * PR_BLK * sizeof(KT) +
+           (size_t)PR_MAXC * sizeof(KT) + PR_MAXSEL * sizeof(KT) + (size_t)PR_MAXC * 4 + PR_MAXSEL * 4 + 32 + (size_t)PR_MAXC * 2 + 32;
+}
+
+template <typename KT>
+__device__ __forceinline__ void prune_carve(unsigned char *smem, PruneLdsT<KT> &p) {
     size_t off = 0;
     p.rows = reinterpret_cast<float *>(smem + off);
     off += (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4;
-    p.m1 = reinterpret_cast<float *>(smem + off);
-    off += (size_t)PR_BLK * PR_MAXSEL * 4;
-    p.m2 = reinterpret_cast<float *>(smem + off);
-    off += (size_t)PR_BLK * PR_BLK * 4;
+    p.m1 = reinterpret_cast<KT *>(smem + off); // (8-byte keys first: the tile is a multiple of 16 bytes)
+    off += (size_t)PR_BLK * PR_MAXSEL * sizeof(KT);
+    p.m2 = reinterpret_cast<KT *>(smem + off);
+    off += (size_t)PR_BLK * PR_BLK * sizeof(KT);
+    p.c_key = reinterpret_cast<KT *>(smem + off);
+    off += (size_t)PR_MAXC * sizeof(KT);
+    p.s_key = reinterpret_cast<KT *>(smem + off);
+    off += PR_MAXSEL * sizeof(KT);
     p.c_id = reinterpret_cast<uint32_t *>(smem + off);
     off += (size_t)PR_MAXC * 4;
-    p.c_key = reinterpret_cast<float *>(smem + off);
-    off += (size_t)PR_MAXC * 4;
     p.s_id = reinterpret_cast<uint32_t *>(smem + off);
-    off += PR_MAXSEL * 4;
-    p.s_key = reinterpret_cast<float *>(smem + off);
     off += PR_MAXSEL * 4;
     p.misc = reinterpret_cast<uint32_t *>(smem + off);
     off += 32;
     p.disc = reinterpret_cast<uint16_t *>(smem + off);
 }
 
+// int8 cosine distance between two stored rows (distanceBetweenNodes, hnsw_index.go:317-336): float64
+__device__ __forceinline__ double i8_pair_distance(int dot, float n1, float n2) {
+    if (n1 == 0.f || n2 == 0.f) return 1.0;
+    double sim = (double)dot / ((double)n1 * (double)n2);
+    if (sim > 1.0) sim = 1.0;
+    if (sim < -1.0) sim = -1.0;
+    return 1.0 - sim;
+}
+
 // candidates c_id/c_key[0..n) sorted ascending -> s_id/s_key[0..n_sel). Whole workgroup (256 threads).
 template <int METRIC, int PREC>
-__device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_t n, uint32_t maxm) {
+__device__ void select_neighbors_wg(const KdbView &v, const PruneLdsT<typename BKey<PREC>::T> &p, uint32_t n, uint32_t maxm) {
+    using KT = typename BKey<PREC>::T;
+    constexpr bool I8 = PREC == KDB_PREC_I8;
     const int tid = (int)threadIdx.x;
     if (tid == 0) {
         p.misc[0] = 0;
@@ -188,16 +228,20 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
     }
     const float *rows = reinterpret_cast<const float *>(v.rows);
     const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows); // PREC == F16: widened (exactly) into the f32 LDS tile
+    const uint32_t *rows8w = reinterpret_cast<const uint32_t *>(v.rows); // PREC == I8: four packed int8 per tile word
+    const uint32_t W = I8 ? v.ld >> 2 : v.ld;                            // row length in tile words
     for (uint32_t b0 = 0; b0 < n; b0 += PR_BLK) {
         const uint32_t nb = n - b0 < PR_BLK ? n - b0 : PR_BLK;
         const uint32_t ns = p.misc[0];
         const uint32_t p1 = nb * ns, p2 = nb * (nb - 1) / 2, np = p1 + p2;
         float acc[PR_U];
+        int iacc[PR_U]; // int8: exact i32 dots
         uint32_t ra[PR_U], rb[PR_U];
 #pragma unroll
         for (int u = 0; u < PR_U; u++) {
             const uint32_t q = (uint32_t)tid + 256u * (uint32_t)u;
             acc[u] = 0.f;
+            iacc[u] = 0;
             ra[u] = 0;
             rb[u] = 0;
             if (q < p1) {
@@ -212,7 +256,7 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
                 rb[u] = t - i * (i - 1) / 2;
             }
         }
-        for (uint32_t kc = 0; kc < v.ld; kc += PR_KC) {
+        for (uint32_t kc = 0; kc < W; kc += PR_KC) {
             __syncthreads();
             const uint32_t nrow = nb + ns; // staged rows: block candidates then selected
             for (uint32_t e = (uint32_t)tid; e < nrow * (PR_KC / 4); e += 256) {
@@ -220,8 +264,10 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
                 const uint32_t id = r < nb ? p.c_id[b0 + r] : p.s_id[r - nb];
                 const uint32_t lr = r < nb ? r : PR_BLK + (r - nb);
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kc + c4 * 4 < v.ld) {
-                    if (PREC == KDB_PREC_F16) {
+                if (kc + c4 * 4 < W) {
+                    if (I8) {
+                        x = *reinterpret_cast<const float4 *>(rows8w + (size_t)id * W + kc + c4 * 4); // 16 int8, bits untouched
+                    } else if (PREC == KDB_PREC_F16) {
                         const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)id * v.ld + kc + c4 * 4);
                         x = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
                                         (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
@@ -240,6 +286,19 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
                 const float4 *a4 = reinterpret_cast<const float4 *>(p.rows + (size_t)ra[u] * PR_STRIDE);
                 const float4 *b4 = reinterpret_cast<const float4 *>(p.rows + (size_t)rb[u] * PR_STRIDE);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                if constexpr (I8) {
+                    int d = iacc[u];
+#pragma unroll 8
+                    for (int c = 0; c < PR_KC / 4; c++) {
+                        const int4 x = reinterpret_cast<const int4 *>(a4)[c], y = reinterpret_cast<const int4 *>(b4)[c];
+                        d = __builtin_amdgcn_sdot4(x.x, y.x, d, false);
+                        d = __builtin_amdgcn_sdot4(x.y, y.y, d, false);
+                        d = __builtin_amdgcn_sdot4(x.z, y.z, d, false);
+                        d = __builtin_amdgcn_sdot4(x.w, y.w, d, false);
+                    }
+                    iacc[u] = d;
+                    continue;
+                }
 #pragma unroll 8
                 for (int c = 0; c < PR_KC / 4; c++) {
                     const float4 x = a4[c], y = b4[c];
@@ -263,7 +322,13 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
         for (int u = 0; u < PR_U; u++) {
             const uint32_t q = (uint32_t)tid + 256u * (uint32_t)u;
             if (q >= np) continue;
-            const float key = METRIC == KDB_METRIC_COSINE ? -acc[u] : acc[u];
+            KT key;
+            if constexpr (I8) {
+                const uint32_t ida = p.c_id[b0 + ra[u]], idb = q < p1 ? p.s_id[rb[u] - PR_BLK] : p.c_id[b0 + rb[u]];
+                key = i8_pair_distance(iacc[u], v.norms[ida], v.norms[idb]);
+            } else {
+                key = METRIC == KDB_METRIC_COSINE ? -acc[u] : acc[u];
+            }
             if (q < p1) p.m1[ra[u] * PR_MAXSEL + (rb[u] - PR_BLK)] = key;
             else p.m2[ra[u] * PR_BLK + rb[u]] = key;
         }
@@ -272,7 +337,7 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
             uint32_t nsel = ns, ndisc = p.misc[1];
             unsigned selmask = 0; // block candidates kept so far
             for (uint32_t i = 0; i < nb && nsel < maxm; i++) {
-                const float ek = p.c_key[b0 + i];
+                const KT ek = p.c_key[b0 + i];
                 bool rej = false;
                 if ((uint32_t)tid < ns) rej = p.m1[i * PR_MAXSEL + (uint32_t)tid] < ek;
                 if ((uint32_t)tid < i && ((selmask >> tid) & 1u)) rej = rej || (p.m2[i * PR_BLK + (uint32_t)tid] < ek);
@@ -310,16 +375,18 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLds &p, uint32_
     __syncthreads();
 }
 
-__device__ __forceinline__ bool key_before(float k1, uint32_t i1, float k2, uint32_t i2) {
+template <typename KT>
+__device__ __forceinline__ bool key_before(KT k1, uint32_t i1, KT k2, uint32_t i2) {
     return (k1 < k2) || (k1 == k2 && i1 < i2);
 }
 
 // ---- phase 2: new node keeps selectNeighbors(cands); emits reverse requests ---------------------------
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-build_select_kernel(KdbView v, BuildView bv) {
+build_select_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv) {
+    using KT = typename BKey<PREC>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PruneLds p;
+    PruneLdsT<KT> p;
     prune_carve(smem, p);
     const int tid = (int)threadIdx.x;
     const uint32_t task = blockIdx.x;
@@ -351,7 +418,7 @@ build_select_kernel(KdbView v, BuildView bv) {
     select_neighbors_wg<METRIC, PREC>(v, p, n, maxm);
     const uint32_t nsel = p.misc[0];
     uint32_t *adj;
-    float *akey;
+    KT *akey;
     uint32_t slot_up = 0;
     if (level == 0) {
         adj = bv.adj0 + (size_t)node * v.deg0;
@@ -363,13 +430,13 @@ build_select_kernel(KdbView v, BuildView bv) {
     }
     if ((uint32_t)tid < maxm) {
         adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
-        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : 0.f;
+        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : (KT)0;
     }
     if ((uint32_t)tid < nsel) { // reverse link requests (:1883-1889)
         const uint32_t t = p.s_id[tid];
         uint32_t *cnt;
         uint32_t *rid;
-        float *rkey;
+        KT *rkey;
         uint32_t code;
         if (level == 0) {
             cnt = bv.rev0_cnt + t;
@@ -395,15 +462,16 @@ build_select_kernel(KdbView v, BuildView bv) {
 // ---- phase 3: per-target commit -----------------------------------------------------------------------
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
+build_reverse_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t n_touched) {
+    using KT = typename BKey<PREC>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PruneLds p;
+    PruneLdsT<KT> p;
     prune_carve(smem, p);
     const int tid = (int)threadIdx.x;
     if (blockIdx.x >= n_touched) return;
     const uint32_t code = bv.touched[blockIdx.x];
     uint32_t *adj, *cnt, *rid;
-    float *akey, *rkey;
+    KT *akey, *rkey;
     uint32_t maxm;
     if (code & UP_FLAG) {
         const uint32_t ts = code & ~UP_FLAG;
@@ -436,7 +504,7 @@ build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
     const uint32_t n = ne + nr;
     // gather E then R; requesters ordered by id so the result does not depend on atomic order
     uint32_t my_id = 0;
-    float my_key = 0.f;
+    KT my_key = 0;
     if ((uint32_t)tid < ne) {
         my_id = adj[tid];
         my_key = akey[tid];
@@ -455,7 +523,7 @@ build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
     }
     // prune: union sorted by distance to the target (:2019-2033), then selectNeighbors
     uint32_t *sh_id = reinterpret_cast<uint32_t *>(p.m1);      // m1/m2 are free until select_neighbors_wg
-    float *sh_key = p.m2;
+    KT *sh_key = p.m2;
     if ((uint32_t)tid < n) {
         sh_id[tid] = my_id;
         sh_key[tid] = my_key;
@@ -472,17 +540,17 @@ build_reverse_kernel(KdbView v, BuildView bv, uint32_t n_touched) {
     const uint32_t nsel = p.misc[0];
     if ((uint32_t)tid < maxm) {
         adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
-        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : 0.f;
+        akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : (KT)0;
     }
 }
 
 // ---- test hook: selectNeighbors on caller-supplied candidate lists (kdb_test_select_neighbors) -----------------------
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
-select_probe_kernel(KdbView v, const uint32_t *cand_id, const float *cand_key, const uint32_t *cand_cnt, uint32_t stride,
+select_probe_kernel(KdbView v, const uint32_t *cand_id, const typename BKey<PREC>::T *cand_key, const uint32_t *cand_cnt, uint32_t stride,
                     uint32_t maxm, uint32_t *out_id, uint32_t *out_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PruneLds p;
+    PruneLdsT<typename BKey<PREC>::T> p;
     prune_carve(smem, p);
     const int tid = (int)threadIdx.x;
     const uint32_t task = blockIdx.x;
@@ -514,6 +582,8 @@ int occupancy_blocks(K kern, int threads, size_t lds) {
 
 template <int METRIC, int PREC>
 int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
+    using KT = typename BKey<PREC>::T;
+    constexpr size_t KB = sizeof(KT);
     hipStream_t s = idx->stream;
     const uint32_t efc = bp && bp->ef_construction ? bp->ef_construction : idx->desc.ef_construction;
     if (efc > 256 || efc < 1) {
@@ -560,12 +630,12 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     const size_t max_tasks = (size_t)max_batch * 2 + 64; // level-0 tasks + upper tasks (<< batch)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    const size_t o_adj0k = take(n1 * idx->deg0 * 4), o_adjupk = take((slots * idx->deg_up + 4) * 4);
+    const size_t o_adj0k = take(n1 * idx->deg0 * KB), o_adjupk = take((slots * idx->deg_up + 4) * KB);
     const size_t o_r0c = take(n1 * 4), o_ruc = take((slots + 1) * 4);
-    const size_t o_r0i = take(n1 * RCAP * 4), o_r0k = take(n1 * RCAP * 4);
-    const size_t o_rui = take((slots + 1) * RCAP * 4), o_ruk = take((slots + 1) * RCAP * 4);
+    const size_t o_r0i = take(n1 * RCAP * 4), o_r0k = take(n1 * RCAP * KB);
+    const size_t o_rui = take((slots + 1) * RCAP * 4), o_ruk = take((slots + 1) * RCAP * KB);
     const size_t o_touch = take(((size_t)max_tasks * PR_MAXSEL + 64) * 4), o_ntouch = take(256);
-    const size_t o_cid = take(max_tasks * efc * 4), o_ckey = take(max_tasks * efc * 4), o_ccnt = take(max_tasks * 4);
+    const size_t o_cid = take(max_tasks * efc * 4), o_ckey = take(max_tasks * efc * KB), o_ccnt = take(max_tasks * 4);
     const size_t o_uptask = take((size_t)max_batch * 4 + 64);
     if (idx->build_bytes < off) {
         if (idx->d_build) KDB_HIP(hipFree(idx->d_build));
@@ -577,34 +647,37 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     unsigned char *w = reinterpret_cast<unsigned char *>(idx->d_build);
     KDB_HIP(hipMemsetAsync(w + o_r0c, 0, n1 * 4, s));
     KDB_HIP(hipMemsetAsync(w + o_ruc, 0, (slots + 1) * 4, s));
-    BuildView bv;
+    BuildViewT<KT> bv;
     bv.adj0 = idx->d_adj0;
     bv.adj_up = idx->d_adj_up;
-    bv.adj0_key = reinterpret_cast<float *>(w + o_adj0k);
-    bv.adj_up_key = reinterpret_cast<float *>(w + o_adjupk);
+    bv.adj0_key = reinterpret_cast<KT *>(w + o_adj0k);
+    bv.adj_up_key = reinterpret_cast<KT *>(w + o_adjupk);
     bv.rev0_cnt = reinterpret_cast<uint32_t *>(w + o_r0c);
     bv.revup_cnt = reinterpret_cast<uint32_t *>(w + o_ruc);
     bv.rev0_id = reinterpret_cast<uint32_t *>(w + o_r0i);
-    bv.rev0_key = reinterpret_cast<float *>(w + o_r0k);
+    bv.rev0_key = reinterpret_cast<KT *>(w + o_r0k);
     bv.revup_id = reinterpret_cast<uint32_t *>(w + o_rui);
-    bv.revup_key = reinterpret_cast<float *>(w + o_ruk);
+    bv.revup_key = reinterpret_cast<KT *>(w + o_ruk);
     bv.touched = reinterpret_cast<uint32_t *>(w + o_touch);
     bv.n_touched = reinterpret_cast<uint32_t *>(w + o_ntouch);
     bv.cand_id = reinterpret_cast<uint32_t *>(w + o_cid);
-    bv.cand_key = reinterpret_cast<float *>(w + o_ckey);
+    bv.cand_key = reinterpret_cast<KT *>(w + o_ckey);
     bv.cand_cnt = reinterpret_cast<uint32_t *>(w + o_ccnt);
     bv.up_task = reinterpret_cast<uint32_t *>(w + o_uptask);
     bv.efc = efc;
 
     // ---- launch geometry
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
-    const size_t lds_search = (size_t)idx->ld * 4 + 64 * 8 + KDB_UP_MARK_CAP * 4;
-    const size_t lds_prune = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
-                             (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
+    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4;
+    const size_t lds_prune = prune_lds_bytes<KT>();
     const int bs = kdb_beam_slots(efc);
     auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
     auto kselect = build_select_kernel<METRIC, PREC>;
     auto krev = build_reverse_kernel<METRIC, PREC>;
+    if (lds_prune > 64 * 1024) {
+        KDB_HIP(hipFuncSetAttribute((const void *)kselect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prune));
+        KDB_HIP(hipFuncSetAttribute((const void *)krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prune));
+    }
     if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
     const uint32_t slots_vis = (uint32_t)idx->n_cu * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
     int rc = kdb_ensure_visited(idx, slots_vis, idx->stream);
@@ -677,38 +750,32 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
 
 } // namespace
 
-int kdb_select_probe(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *d_ids, const float *d_keys,
+// d_keys: float keys for float32 / float16 indexes, DOUBLE distances for int8 indexes (the reference's float64)
+int kdb_select_probe(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *d_ids, const void *d_keys,
                      const uint32_t *d_cnt, uint32_t maxm, uint32_t *d_out_ids, uint32_t *d_out_cnt, hipStream_t s) {
     if (maxm == 0 || maxm > PR_MAXSEL || stride > PR_MAXC) {
         kdb_set_error("select probe: maxm must be 1..%d and lists at most %d long", PR_MAXSEL, PR_MAXC);
         return KDB_ERR_INVALID;
     }
-    if (idx->desc.precision == KDB_PREC_I8) {
-        kdb_set_error("select probe: float32 and float16 rows only (as the GPU builder)");
-        return KDB_ERR_UNSUPPORTED;
-    }
-    const size_t lds = (size_t)PR_MAXC * 8 + PR_MAXSEL * 8 + PR_MAXC * 2 + (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4 +
-                       (size_t)PR_BLK * PR_MAXSEL * 4 + (size_t)PR_BLK * PR_BLK * 4 + 64;
     const KdbView v = kdb_make_view(idx);
-    auto go = [&](auto kern) -> int {
+    auto go = [&](auto kern, auto *keys, size_t lds) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_lists), dim3(256), lds, s, v, d_ids, d_keys, d_cnt, stride, maxm, d_out_ids, d_out_cnt);
+        hipLaunchKernelGGL(kern, dim3(n_lists), dim3(256), lds, s, v, d_ids, keys, d_cnt, stride, maxm, d_out_ids, d_out_cnt);
         KDB_HIP(hipGetLastError());
         return KDB_OK;
     };
-    if (idx->desc.precision == KDB_PREC_F16) return go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
-    return idx->desc.metric == KDB_METRIC_COSINE ? go(select_probe_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>)
-                                                 : go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+    const float *kf = reinterpret_cast<const float *>(d_keys);
+    if (idx->desc.precision == KDB_PREC_I8)
+        return go(select_probe_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, reinterpret_cast<const double *>(d_keys), prune_lds_bytes<double>());
+    if (idx->desc.precision == KDB_PREC_F16) return go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F16>, kf, prune_lds_bytes<float>());
+    return idx->desc.metric == KDB_METRIC_COSINE ? go(select_probe_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, kf, prune_lds_bytes<float>())
+                                                 : go(select_probe_kernel<KDB_METRIC_L2, KDB_PREC_F32>, kf, prune_lds_bytes<float>());
 }
 
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
     if (count == 0 || count > idx->cap) {
         kdb_set_error("build: count %u outside 1..%u", count, idx->cap);
         return KDB_ERR_INVALID;
-    }
-    if (idx->desc.precision == KDB_PREC_I8) { // the reference never builds an int8 graph from scratch: Compress keeps the f32 graph
-        kdb_set_error("build: GPU construction supports float32 and float16 rows (int8 indexes keep the graph they were compressed from)");
-        return KDB_ERR_UNSUPPORTED;
     }
     if (idx->deg0 > PR_MAXSEL) {
         kdb_set_error("build: mMax0 %u exceeds %d", idx->deg0, PR_MAXSEL);
@@ -719,6 +786,7 @@ int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
     KDB_HIP(hipDeviceSynchronize());
     int rc;
     if (idx->desc.precision == KDB_PREC_F16) rc = build_impl<KDB_METRIC_L2, KDB_PREC_F16>(idx, count, p); // f16 is euclidean only
+    else if (idx->desc.precision == KDB_PREC_I8) rc = build_impl<KDB_METRIC_COSINE, KDB_PREC_I8>(idx, count, p); // int8 is cosine only: rows, norms and AbsMax must be in place
     else rc = idx->desc.metric == KDB_METRIC_COSINE ? build_impl<KDB_METRIC_COSINE, KDB_PREC_F32>(idx, count, p)
                                                     : build_impl<KDB_METRIC_L2, KDB_PREC_F32>(idx, count, p);
     if (rc != KDB_OK) { // a half-linked graph must not answer searches: the handle is back to "rows without a graph"

@@ -12,10 +12,11 @@
 //   * Quantize (quantizer.go:150-176: v / AbsMax * 127, clipped to +-127, rounded half away from zero) and the stored norms
 //     (computeInt8Norm: sqrt of the exact integer sum of squares, as f32) for every row, one wave per 4 rows;
 //   * float16: RNE conversion (float16.Fromfloat32);
-//   * the graph: float16 can be rebuilt by the GPU builder with float16 distances (KDB_COMPRESS_REBUILD_GRAPH), which is
-//     what the reference's re-insertion amounts to; by default -- and always for int8, for which the builder has no distance
-//     path -- the float32 graph is KEPT (same ids, same links): a documented divergence that costs nothing in recall against
-//     a rebuilt graph (scripts/quant_probe.py) and makes Compress a 20 ms operation at 1M x 768 instead of a rebuild.
+//   * the graph: KDB_COMPRESS_REBUILD_GRAPH makes the GPU builder re-insert every row with the NEW precision's distances
+//     (float16 squared L2; int8: i32 dot, stored norms, float64 scaling -- hnsw_index.go:317-336), which is what the
+//     reference's re-insertion amounts to; by default the float32 graph is KEPT (same ids, same links): a documented
+//     divergence that makes Compress a 20 ms operation at 1M x 768 instead of a rebuild (recall of a kept against a
+//     rebuilt graph: tests/test_gpu_compress.py, scripts/quant_probe.py).
 #include "kdb_device.cuh"
 #include <math.h>
 #include <string.h>
@@ -88,10 +89,6 @@ extern "C" int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t f
     if (precision != KDB_PREC_F16 && precision != KDB_PREC_I8) {
         kdb_set_error("compress: the new precision must be float16 or int8");
         return KDB_ERR_INVALID;
-    }
-    if (precision == KDB_PREC_I8 && (flags & KDB_COMPRESS_REBUILD_GRAPH)) {
-        kdb_set_error("compress: the GPU builder has no int8 distance path; int8 keeps the float32 graph");
-        return KDB_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> lk(src->mu);
     if (src->count == 0) {
@@ -217,13 +214,14 @@ extern "C" int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t f
     }
     KDB_TRYC(hipStreamSynchronize(s));
 #undef KDB_TRYC
-    if (flags & KDB_COMPRESS_REBUILD_GRAPH) { // float16: re-insertion with the new precision's distances, on the GPU
+    if (flags & KDB_COMPRESS_REBUILD_GRAPH) { // re-insertion with the new precision's distances, on the GPU
         kdb_build_params bp{};
         bp.seed = 1;
-        std::lock_guard<std::mutex> lk2(dst->mu);
-        KdbLaneGuard lane(dst, dst->stream);
-        if (lane.rc) return fail(lane.rc);
-        rc = kdb_build_graph(dst, n, &bp);
+        { // the lock and the scratch lane are released BEFORE a failure destroys dst (they live inside it)
+            std::lock_guard<std::mutex> lk2(dst->mu);
+            KdbLaneGuard lane(dst, dst->stream);
+            rc = lane.rc ? lane.rc : kdb_build_graph(dst, n, &bp);
+        }
         if (rc) return fail(rc);
     }
     *out = dst;

@@ -911,6 +911,14 @@ static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B
         KDB_HIP(hipMemcpyAsync(out_count + b0, d_cnt + b0, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
         return KDB_OK;
     };
+    // every exit -- the error paths too -- waits for both streams: queued copies read and write the CALLER's host buffers
+    struct SyncBoth {
+        kdb_index *i;
+        ~SyncBoth() {
+            (void)hipStreamSynchronize(i->stream);
+            (void)hipStreamSynchronize(i->stream2);
+        }
+    } sync_both{idx};
     uint32_t c = 0, prev_b0 = 0, prev_nb = 0;
     hipStream_t prev_s = nullptr;
     for (uint32_t b0 = 0; b0 < B; b0 += chunk, c++) {
@@ -1195,7 +1203,7 @@ extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_p
 
 // test hook (see kektor_hip.h): host buffers in, selections out
 extern "C" int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *cand_ids,
-                                         const float *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
+                                         const void *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,
                                          uint32_t *out_cnt) {
     KDB_CHECK_IDX(idx);
     if (n_lists == 0) return KDB_OK;
@@ -1221,16 +1229,17 @@ extern "C" int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint3
     if (lane.rc) return lane.rc;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nb = (size_t)n_lists * stride * 4;
-    int rc = kdb_ensure_scratch(idx, 2 * al(nb) + al((size_t)n_lists * 4) * 2 + al((size_t)n_lists * maxm * 4) + 256);
+    const size_t kb = (size_t)n_lists * stride * (idx->desc.precision == KDB_PREC_I8 ? 8 : 4); // int8: float64 distances
+    int rc = kdb_ensure_scratch(idx, al(nb) + al(kb) + al((size_t)n_lists * 4) * 2 + al((size_t)n_lists * maxm * 4) + 256);
     if (rc) return rc;
     unsigned char *b = reinterpret_cast<unsigned char *>(idx->d_scratch);
-    uint32_t *d_ids = reinterpret_cast<uint32_t *>(b);
-    float *d_keys = reinterpret_cast<float *>(b + al(nb));
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(b + 2 * al(nb));
-    uint32_t *d_ocnt = reinterpret_cast<uint32_t *>(b + 2 * al(nb) + al((size_t)n_lists * 4));
-    uint32_t *d_oid = reinterpret_cast<uint32_t *>(b + 2 * al(nb) + 2 * al((size_t)n_lists * 4));
+    void *d_keys = b; // (8-byte keys first)
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(b + al(kb));
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(b + al(kb) + al(nb));
+    uint32_t *d_ocnt = reinterpret_cast<uint32_t *>(b + al(kb) + al(nb) + al((size_t)n_lists * 4));
+    uint32_t *d_oid = reinterpret_cast<uint32_t *>(b + al(kb) + al(nb) + 2 * al((size_t)n_lists * 4));
     KDB_HIP(hipMemcpyAsync(d_ids, cand_ids, nb, hipMemcpyHostToDevice, s));
-    KDB_HIP(hipMemcpyAsync(d_keys, cand_keys, nb, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_keys, cand_keys, kb, hipMemcpyHostToDevice, s));
     KDB_HIP(hipMemcpyAsync(d_cnt, cand_cnt, (size_t)n_lists * 4, hipMemcpyHostToDevice, s));
     rc = kdb_select_probe(idx, n_lists, stride, d_ids, d_keys, d_cnt, maxm, d_oid, d_ocnt, s);
     if (rc) return rc;

@@ -19,6 +19,7 @@
 //     evaluate the rows of a hop (dists() / coop_spec_share() in kdb_search_core.cuh) -- same walk, same counters.
 #include "kdb_search_core.cuh"
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -246,13 +247,16 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
+    off += 64 * 4;
     s.beam_d = nullptr;
     s.beam_id = nullptr;
     s.marks = nullptr;
     s.nr_d = nullptr;
     s.nr_id = nullptr;
     s.nr_cap = 0;
-    s.nb_lo = nullptr;
+    // int8: the low word of the 64-bit key, so that the float handed back is the ROUNDED float64 distance -- the value the
+    // search and the exact scan report for the same (query, row) -- not its truncation
+    s.nb_lo = PREC == KDB_PREC_I8 ? reinterpret_cast<uint32_t *>(smem + off) : nullptr;
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
@@ -286,6 +290,7 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     compute_dists<PREC, METRIC>(v, s, n, qnorm);
     if ((uint32_t)lane < n) {
         float key = s.nb_d[lane];
+        if constexpr (PREC == KDB_PREC_I8) key = (float)kdb_i8_key_double(key, s.nb_lo[lane]);
         float raw = (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) ? -key : key;
         out[(size_t)b * C + c0 + lane] = id == 0 ? INFINITY : raw;
     }
@@ -486,8 +491,10 @@ __global__ void row_norms_kernel(KdbView v, float *norms, uint32_t first, uint32
 template <typename K>
 int occupancy_blocks(K kern, int threads, size_t lds) {
     static std::mutex mu;
-    static std::map<std::pair<const void *, size_t>, int> cache;
-    const std::pair<const void *, size_t> key(reinterpret_cast<const void *>(kern), lds);
+    static std::map<std::tuple<const void *, size_t, int, int>, int> cache; // occupancy is a per-device, per-block-size fact
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::tuple<const void *, size_t, int, int> key(reinterpret_cast<const void *>(kern), lds, dev, threads);
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -670,7 +677,7 @@ template <int PREC, int METRIC>
 static int launch_distance_t(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, const uint32_t *d_ids,
                              uint32_t C, float *d_out, hipStream_t s) {
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
-    const size_t lds = qb + 64 * 8;
+    const size_t lds = qb + 64 * (PREC == KDB_PREC_I8 ? 12 : 8);
     const uint32_t chunks = (C + 31) / 32;
     hipLaunchKernelGGL((distance_tile_kernel<PREC, METRIC>), dim3(B * chunks), dim3(64), lds, s, v, d_q, d_qnorm, B, d_ids, C, d_out);
     KDB_HIP(hipGetLastError());

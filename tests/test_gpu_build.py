@@ -130,6 +130,61 @@ def test_build_f16(oracle, hip):
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
+def test_build_int8(oracle, hip):
+    """int8 index (cosine only, hnsw_index.go:219-222): the GPU builder searches, selects and re-prunes with the reference's
+    int8 distance -- exact i32 dot, stored norms, float64 scaling (hnsw_index.go:317-336, :2406-2454).  The oracle searching
+    the GPU-built graph over the same int8 rows / norms returns exactly what the HIP search returns (ids, float64 distances,
+    walk counters), and the graph is as good as the one built from the float32 rows of the same vectors."""
+    import ctypes as C
+    O = oracle
+    OL = O.lib()
+    n, dim, k = 5000, 96, 10
+    XQ = make_corpus(n + 60, dim, "clustered", seed=41).astype(np.float32)
+    XQ /= np.linalg.norm(XQ, axis=1, keepdims=True)
+    X, Q = np.ascontiguousarray(XQ[:n]), np.ascontiguousarray(XQ[n:])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    absmax = float(OL.orc_quantizer_train(p(X), n, dim))
+    r8 = np.zeros((n + 1, dim), np.int8)
+    norms = np.zeros(n + 1, np.float32)
+    for i in range(n):
+        OL.orc_quantize(p(X[i]), dim, C.c_float(absmax), p(r8[i + 1]))
+        norms[i + 1] = OL.orc_int8_norm(p(r8[i + 1]), dim)
+    idx = hip.HipIndex(dim, hip.COSINE, hip.I8, 16, 100, capacity=n)
+    idx.upload_rows(r8[1:], 1)
+    idx.upload_norms(norms[1:], 1)
+    idx.set_quantizer(absmax)
+    idx.build(n, batch=1024, ef_construction=100, seed=5)
+    g = as_graph(idx.download_graph())
+    assert g.count == n and g.max_level >= 1
+    deg0 = np.diff(g.offsets[0][:n + 2].astype(np.int64))
+    assert deg0.max() <= 32 and (deg0[1:] > 0).mean() > 0.999
+    nb0 = g.neighbors[0]
+    owner = np.repeat(np.arange(n + 1), deg0)
+    assert not np.any(owner == nb0) and nb0.min() >= 1 and nb0.max() <= n
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, 100, trace=True, dist64=True)
+    fi, fd, fc = idx.flat_scan_batch(Q, k)
+    rec = np.mean([len(set(ids[b].tolist()) & set(fi[b].tolist())) / k for b in range(Q.shape[0])])
+    assert rec >= 0.90, rec
+    from oracle.oracle import Graph
+    og = Graph(g.count, g.levels, g.max_level, g.entry, g.offsets, g.neighbors, g.deleted_bits)
+    orc = O.OracleIndex.from_graph(dim, O.COSINE, O.I8, 16, 100, r8, og, norms=norms, absmax=absmax)
+    for b in range(30):
+        oi, od, (ond, onh) = orc.search(Q[b], k, ef=100, counters=True)
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], oi)
+        assert np.array_equal(dist[b, :c], od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    # A/B: the same vectors as a float32 index, built by the same builder
+    f = hip.HipIndex(dim, hip.COSINE, hip.F32, 16, 100, capacity=n)
+    f.upload_rows(X, 1)
+    f.build(n, batch=1024, ef_construction=100, seed=5)
+    xi, _, _ = f.flat_scan_batch(Q, k)                       # exact float32 answer
+    gi, _, _ = f.search_batch(Q, k, 100)
+    rec_f32 = np.mean([len(set(gi[b].tolist()) & set(xi[b].tolist())) / k for b in range(Q.shape[0])])
+    rec_i8 = np.mean([len(set(ids[b].tolist()) & set(xi[b].tolist())) / k for b in range(Q.shape[0])])
+    assert rec_i8 >= rec_f32 - 0.08, (rec_i8, rec_f32)       # the quantisation loss, not a worse graph
+
+
 @pytest.mark.parametrize("metric", [0, 1])
 def test_incremental_refresh_matches_full_upload(oracle, hip, metric):
     """The mirror refresh a shim does after writers touched a few nodes: new rows + append_nodes + patch_adjacency of
@@ -190,9 +245,18 @@ def test_incremental_refresh_matches_full_upload(oracle, hip, metric):
         idx.patch_adjacency(0, [1], [list(range(1, 40))])   # longer than mMax0 = 16
 
 
-@pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1)])
+def i8_distance(rows8, norms, a, b):
+    """distanceBetweenNodes for int8 rows (hnsw_index.go:317-336) in numpy float64: exact i32 dot, float32 norms"""
+    dot = rows8[b].astype(np.int64) @ rows8[a].astype(np.int64)
+    na, nb = np.float64(norms[a]), np.float64(norms[b])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sim = np.clip(dot.astype(np.float64) / (na * nb), -1.0, 1.0)
+    return np.where((na == 0) | (nb == 0), 1.0, 1.0 - sim)
+
+
+@pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1), (1, 2)])
 def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
-    """a13: identical candidate lists -> identical selections.  The GPU builder's selectNeighbors (build_select_kernel's
+    """a13: identical candidate lists -> identical selections (int8: no exception, its distances are exact).  The GPU builder's selectNeighbors (build_select_kernel's
     workgroup routine, through the kdb_test_select_neighbors hook) against the oracle's select_neighbors
     (hnsw_index.go:2629-2701): lists shorter than m (returned as they are), lists that fill m on the heuristic alone, lists
     that need the back-fill from the discarded, 32-candidate block boundaries, m = 16 and 32.  Candidate distances to the
@@ -212,12 +276,16 @@ def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
     idx = hip.HipIndex(dim, metric, prec, 16, 64, capacity=n + 8)
     idx.upload_rows(rows[1:], 1)
     idx.set_count(n)
-    stored = rows[1:].astype(np.float32) if prec == O.F16 else rows[1:]
+    if prec == O.I8:   # int8: every distance is an exact i32 dot scaled in float64 -> selections must be IDENTICAL
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+        norms = orc.norms()
+    stored = rows[1:].astype(np.float32) if prec != O.F32 else rows[1:]
     lens = [5, 16, 31, 32, 33, 64, 100, 200, 300, 17, 90, 257]
     n_lists = len(lens) * 4
     stride = 320
     cand = np.zeros((n_lists, stride), np.uint32)
-    keys = np.zeros((n_lists, stride), np.float32)
+    keys = np.zeros((n_lists, stride), np.float64 if prec == O.I8 else np.float32)
     cnt = np.zeros(n_lists, np.uint32)
     centres, dists = [], []
     for t in range(n_lists):
@@ -229,6 +297,13 @@ def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
             pool = np.argsort(d)[1:L + 1] + 1
         else:
             pool = rng.choice(np.setdiff1d(np.arange(1, n + 1), [c]), L, replace=False)
+        if prec == O.I8:
+            key = i8_distance(rows, norms, c, pool)
+            order = np.lexsort((pool, key))
+            cand[t, :L], keys[t, :L], cnt[t] = pool[order], key[order], L
+            centres.append(c)
+            dists.append(key[order])
+            continue
         q = stored[c - 1]
         raw = idx.distance_batch(q[None, :], pool[None, :].astype(np.uint32), prepared=True)[0]  # L2 sum / dot, wave order
         key = raw if metric == 0 else -raw
@@ -244,6 +319,7 @@ def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
             g = got[t, :int(gc[t])]
             if np.array_equal(g, want):
                 continue
+            assert prec != O.I8, (m, t, g, want)
             # a difference is acceptable only next to a rounding-level tie between a pair distance and a centre distance
             P = stored[cand[t, :L].astype(np.int64) - 1].astype(np.float64)
             pd = ((P[:, None, :] - P[None, :, :]) ** 2).sum(2) if metric == 0 else 1.0 - P @ P.T

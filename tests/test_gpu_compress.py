@@ -55,9 +55,33 @@ def test_compress_to_int8(oracle, hip, n):
         xi, xd = orc.flat_scan(Q[b], k)
         assert_same_results_tol(fi[b, :int(fc[b])], fd[b, :int(fc[b])].astype(np.float64), xi, xd)
     with pytest.raises(hip.KdbError):
-        src.Compress(hip.I8, rebuild_graph=True)     # the builder has no int8 distance path
-    with pytest.raises(hip.KdbError):
         dst.Compress(hip.F16)                        # only float32 indexes are compressed
+    # the reference's flow: AddBatch re-inserts every vector under the NEW precision (core.go:1236-1283) -> a graph built
+    # with int8 distances.  Same rows / norms / AbsMax as the kept-graph index; the oracle searching the REBUILT graph over
+    # them returns what the HIP search returns, bit for bit (ids, float64 distances, walk counters).
+    reb = src.Compress(hip.I8, rebuild_graph=True)
+    assert np.float32(reb.quantizer_absmax()).view(np.uint32) == np.float32(want_absmax).view(np.uint32)
+    assert np.array_equal(reb.download_rows(1, n), want8)
+    rc, re_, rml, rlv, roffs, rnbrs = reb.download_graph()
+    assert rc == n and rml >= 1
+    assert not all(np.array_equal(a, b) for a, b in zip(rnbrs, nbrs)), "the graph was not rebuilt"
+    rg = O.Graph(rc, rlv, rml, re_, roffs, rnbrs, np.zeros((rc >> 6) + 1, dtype=np.uint64))
+    rorc = O.OracleIndex.from_graph(dim, O.COSINE, O.I8, 16, 60, r1, rg, norms=norms, absmax=want_absmax)
+    rids, rdist, rcnt, (nd, nh) = reb.search_batch(Q, k, 80, trace=True, dist64=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = rorc.search(Q[b], k, ef=80, counters=True)
+        cb = int(rcnt[b])
+        assert np.array_equal(rids[b, :cb], oi) and np.array_equal(rdist[b, :cb], od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    # recall A/B against the exact int8 answer: the rebuilt graph is not worse than the kept float32 graph
+    Q2 = make_corpus(200, dim, "normal", seed=103)
+    xi, _, _ = dst.flat_scan_batch(Q2, k)
+    rec = []
+    for ix in (dst, reb):
+        gi, _, _ = ix.search_batch(Q2, k, 80)
+        rec.append(np.mean([len(set(gi[b].tolist()) & set(xi[b].tolist())) / k for b in range(Q2.shape[0])]))
+    assert rec[1] >= rec[0] - 0.03, rec
+    print("int8 recall@10 at ef=80 (kept float32 graph, graph rebuilt with int8 distances):", rec)
 
 
 @pytest.mark.parametrize("rebuild", [False, True])

@@ -81,6 +81,31 @@ def test_distance_tile_bit_exact(oracle, hip, metric, dim):
         np.testing.assert_allclose(raw_to_score(idx, got[0][ids[0] != 0]), want, rtol=REL, atol=ABS)
 
 
+@pytest.mark.parametrize("dim", [128, 100, 768])
+def test_distance_tile_int8(oracle, hip, dim):
+    """kdb_distance_batch on an int8 index hands back the float ROUNDING of the reference's float64 distance -- the value
+    the search and the exact scan report for the same (query, row) -- not its truncation."""
+    O = oracle
+    X = make_corpus(500, dim, "normal", seed=4)
+    orc, idx = build_pair(O, hip, X, 1, precision=O.I8, efc=40)
+    rng = np.random.default_rng(2)
+    Q = rng.standard_normal((7, dim)).astype(np.float32)
+    ids = rng.integers(0, 501, size=(7, 70)).astype(np.uint32)
+    got = idx.distance_batch(Q, ids)
+    n_inexact = 0
+    for b in range(7):
+        live = ids[b] != 0
+        want = orc.distances(Q[b], ids[b][live])                       # float64, hnsw_index.go:2429-2454
+        assert np.array_equal(got[b][live], want.astype(np.float32)), (dim, b)
+        assert np.all(np.isinf(got[b][~live]))
+        n_inexact += int(np.sum(want.astype(np.float32).astype(np.float64) != want))
+    assert n_inexact > 0   # the test data does exercise the rounding
+    sid, sd, sc = idx.search_batch(Q, 10, 64)
+    for b in range(7):     # the same pair has the same float from the search
+        d = idx.distance_batch(Q[b:b + 1], sid[b:b + 1, :int(sc[b])])
+        assert np.array_equal(d[0], sd[b, :int(sc[b])])
+
+
 @pytest.mark.parametrize("metric,law,n,dim,ef", [
     (1, "uniform", 3000, 128, 0), (1, "uniform", 3000, 128, 64), (0, "uniform", 3000, 64, 100),
     (1, "clustered", 4000, 96, 200), (0, "normal", 2000, 40, 10), (1, "normal", 1500, 768, 50),
