@@ -1987,26 +1987,6 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     }
     const uint32_t T = (uint32_t)(tiles.size() / 3);
     uint32_t stripes_max = FS_MAX_MERGE / kl;
-    // stripes per group: T*want workgroups should fill whole rounds of the resident slots (LDS decides how many
-    // workgroups share a CU); the fewest stripes that fill >= 90 % of their rounds win (every stripe pays a start-up)
-    const uint32_t per_cu = (uint32_t)(160u * 1024u / lds_s) > 0 ? (uint32_t)(160u * 1024u / lds_s) : 1u;
-    const uint32_t slots = (uint32_t)idx->n_cu * (per_cu > 2 ? 2u : per_cu);
-    uint32_t want = 1;
-    {
-        double best = 0.0;
-        const uint32_t lim = stripes_max < 64u ? stripes_max : 64u;
-        for (uint32_t w = 1; w <= lim; w++) {
-            const uint64_t blocks = (uint64_t)w * T;
-            if (blocks > 4ull * slots && w > 1) break;
-            const uint64_t rounds = (blocks + slots - 1) / slots;
-            const double fill = (double)blocks / (double)(rounds * slots);
-            if (fill > best + 1e-9) { best = fill; want = w; }
-            if (fill >= 0.9) { want = w; break; }
-        }
-    }
-    const uint32_t min_tiles = 4;
-    const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
-    const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint32_t nwords = (v.count >> 5) + 1u;
     const dim3 ggrid((nwords + 255) / 256, G);
@@ -2027,6 +2007,36 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         if (total == 0) total = 1;
     }
     if (total > (uint64_t)G * v.count) total = (uint64_t)G * v.count;
+    // Stripes per group.  Workgroup b runs on XCD b % 8 (the dispatcher deals workgroups round-robin) and serves stripe
+    // (b/8/T)*8 + b%8, so that the tiles of one stripe share an L2: XCD x owns the stripes s = x (mod 8) and therefore
+    // T * ceil-ish(want/8) workgroups for its n_cu/8 CUs.  Round 2 sized `want` as if the chip were one pool of slots: with
+    // 105 tiles it picked 9 stripes, which gave XCD 0 twice the work of the others (config 5 ran at 2.85 TB/s).  Now the
+    // estimated time -- rounds of the BUSIEST XCD x (rows of a stripe + a start-up allowance for the open threshold of a
+    // stripe's first tiles) -- is minimised over the stripe counts the merge can take.
+    const uint32_t per_cu = (uint32_t)(160u * 1024u / lds_s) > 0 ? (uint32_t)(160u * 1024u / lds_s) : 1u;
+    const uint32_t slots_x = ((uint32_t)idx->n_cu / 8u > 0 ? (uint32_t)idx->n_cu / 8u : 1u) * (per_cu > 2 ? 2u : per_cu);
+    uint32_t want = 1;
+    {
+        const double rows_g = (double)total / (double)G; // rows per group (the caller's bound, or counted)
+        const double startup = 3.0 * FS_TR;
+        double best = 1e300;
+        const uint32_t lim = stripes_max < 64u ? stripes_max : 64u;
+        for (uint32_t w = 1; w <= lim; w++) {
+            if ((double)w * 4.0 * FS_TR > rows_g && w > 1) break; // a stripe is at least min_tiles tiles
+            const uint64_t on_x = (uint64_t)T * ((w + 7u) / 8u);  // workgroups of the busiest XCD
+            const uint64_t rounds = (on_x + slots_x - 1) / slots_x;
+            const double t = (double)rounds * (rows_g / (double)w + startup);
+            if (t < best * 0.98) { best = t; want = w; } // the fewest stripes within 2 % of the best
+        }
+        if (const char *e = getenv("KDB_GROUP_STRIPES")) { // measurement knob
+            const uint32_t w = (uint32_t)atoi(e);
+            if (w >= 1 && w <= stripes_max) want = w;
+        }
+    }
+    const uint32_t min_tiles = 4;
+    const uint32_t n_qtiles = (B + FS_TQ - 1) / FS_TQ;
+    const size_t n_part = (size_t)want * n_qtiles * FS_TQ;
+
     const size_t ids_bytes = al((size_t)total * 4 + 1024);
     const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
     const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + part_bytes + 4096;

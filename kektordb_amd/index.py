@@ -94,7 +94,7 @@ class HipIndex:
     def Compress(self, precision: int, rebuild_graph: bool = False) -> "HipIndex":
         """DB.Compress (pkg/core/core.go:1128-1290) on the device: a NEW index of `precision` (F16 / I8) from this
         float32 one -- quantizer trained and rows converted in HBM; the graph is kept, or rebuilt by the GPU builder
-        (float16 only) when rebuild_graph is set."""
+        with the new precision's distances (what the reference's AddBatch re-insertion does) when rebuild_graph is set."""
         self._live()
         h = C.c_void_p()
         check(self.L.kdb_index_compress(self.h, int(precision), 1 if rebuild_graph else 0, C.byref(h)), "kdb_index_compress")
@@ -187,10 +187,11 @@ class HipIndex:
         check(self.L.kdb_index_build(self.h, int(count), C.byref(p)), "kdb_index_build")
 
     def test_select_neighbors(self, cand_ids, cand_keys, cand_cnt, maxm: int):
-        """TEST HOOK: the GPU builder's selectNeighbors on caller-supplied lists ([n_lists, stride] ids / ascending keys)"""
+        """TEST HOOK: the GPU builder's selectNeighbors on caller-supplied lists ([n_lists, stride] ids / ascending keys;
+        keys are float32 ordering keys, or -- int8 indexes -- the float64 distances)"""
         self._live()
         ids = np.ascontiguousarray(cand_ids, dtype=np.uint32)
-        keys = np.ascontiguousarray(cand_keys, dtype=np.float32)
+        keys = np.ascontiguousarray(cand_keys, dtype=np.float64 if self.precision == I8 else np.float32)
         cnt = np.ascontiguousarray(cand_cnt, dtype=np.uint32)
         n_lists, stride = ids.shape
         out = np.zeros((n_lists, maxm), dtype=np.uint32)
