@@ -43,7 +43,7 @@ class Cluster:
         q = np.ascontiguousarray(queries, dtype=np.float32)
         B = q.shape[0]
         ids = np.zeros((B, k), dtype=np.uint32)
-        dist = np.zeros((B, k), dtype=np.float32)
+        dist = np.zeros((B, k), dtype=np.float64 if (flags & 8) else np.float32)  # KDB_SEARCH_DIST_F64 (int8 shards)
         cnt = np.zeros(B, dtype=np.uint32)
         ab = None if allow_bits is None else np.ascontiguousarray(allow_bits, dtype=np.uint64)
         args = [self.h, _ptr(q), B, k] + ([ef] if ef is not None else []) + [_ptr(ab), 0 if ab is None else ab.size, flags,

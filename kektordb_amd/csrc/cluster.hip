@@ -9,8 +9,23 @@
 //      block ids[B][k] | raw distances[B][k] | count[B] straight into its slot of that device's send buffer
 //      (shards_per_device consecutive slots);
 //   3. ONE ncclAllGather (grouped over the devices of this process): every device ends up with all G blocks;
-//   4. device 0 merges G*k candidates per query (merge_topk_kernel: total order (key, global id), global id = id_base[g] +
-//      local id) and the answers go back in one D2H copy.
+//   4. the call's ROOT device merges G*k candidates per query (merge_topk_kernel: total order (key, global id), global id =
+//      id_base[g] + local id) and the answers go back in one D2H copy.
+// Calls of several threads overlap (round 3).  A cluster keeps KDB_CLANES = 2 lanes: per device a stream, query / send /
+// receive buffers and allow-list slices of its own; a call takes the next lane (and holds it to its end), enqueues under one
+// short lock and then waits -- outside that lock -- for ONE event on its root device's stream: the copy of the answers is
+// the last operation of the call, and everything else of the call precedes it through stream order and events.  So while
+// call i is in its all-gather / merge / D2H, call i+1 (other lane) is already walking the shards (every kdb_index keeps two
+// scratch sets for exactly this).  The collectives of BOTH lanes go through ONE communicator and ONE collective stream per
+// device, in the order the calls were enqueued -- the same order on every device, which is what RCCL needs to be
+// deadlock-free; events tie a lane's streams to it (queries ready -> broadcast -> walks -> all-gather -> merge).
+// Why all-gather and not a gather to the root: north_star names it; on point-to-point xGMI every peer has its own link, so
+// delivering a 0.7 MB block to seven peers takes the time of delivering it to one; and it makes every device a possible root:
+// lane 0 merges on device 0, lane 1 on device 1 (when there is one), so consecutive calls do not queue behind one device's
+// merge and PCIe link.
+// int8 shards exchange and merge their distances as the reference's float64 (hnsw_index.go:2429-2454 computes and orders
+// doubles): block = dist64[B][k] | ids[B][k] | count[B]; KDB_SEARCH_DIST_F64 hands the doubles to the caller, without it they
+// are rounded to float on the way out -- the ORDER is the float64 order either way.
 // RCCL is resolved at run time (dlopen librccl.so.1): the library carries no link-time dependency on it, and a process that
 // never creates a cluster never loads it.  With one device the collective calls still run (one rank), so the 1-GPU box of
 // the test rig exercises the same code as an 8-GPU node.
@@ -68,18 +83,35 @@ Rccl &rccl() {
         }                                                                                                   \
     } while (0)
 
+constexpr int KDB_CLANES = 2;
+
+struct LaneDev { // one lane's resources on one device
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_ready = nullptr;  // this lane's inputs of the next collective are ready (recorded on `stream`)
+    hipEvent_t ev_coll = nullptr;   // the collective has delivered (recorded on the device's collective stream)
+    float *d_q = nullptr;           // [B][dim] queries
+    size_t q_bytes = 0;
+    uint32_t *d_send = nullptr;     // [spd][L] this device's packed blocks
+    uint32_t *d_recv = nullptr;     // [n_dev][spd][L] everybody's
+    size_t send_bytes = 0, recv_bytes = 0;
+    std::vector<uint64_t *> d_allow; // per local shard: local allow bitset (or empty)
+    std::vector<size_t> allow_bytes;
+    uint32_t *d_bases = nullptr;    // [G] (root devices only)
+    uint32_t *d_out = nullptr;      // merged ids | dist | count (root devices only)
+    size_t out_bytes = 0;
+};
+
 struct DevSlot {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
     ncclComm_t comm = nullptr;
-    float *d_q = nullptr;          // [B][dim] queries
-    size_t q_bytes = 0;
-    uint32_t *d_send = nullptr;    // [spd][L] this device's packed blocks
-    uint32_t *d_recv = nullptr;    // [n_dev][spd][L] everybody's
-    size_t send_words = 0, recv_words = 0;
-    std::vector<uint64_t *> d_allow; // per local shard: local allow bitset (or empty)
-    std::vector<size_t> allow_words;
+    hipStream_t coll = nullptr;     // every collective of this device, of either lane, in enqueue order
+    LaneDev lane[KDB_CLANES];
+};
+
+struct Lane {
+    std::mutex mu;                  // held by the call that uses the lane, from its first enqueue to its last wait
+    uint32_t root = 0;              // index into devs: where this lane's calls merge
+    hipEvent_t done = nullptr;      // on the root's lane stream: the answers have reached the caller's buffers
 };
 
 } // namespace
@@ -90,28 +122,34 @@ struct kdb_cluster {
     std::vector<DevSlot> devs;
     uint32_t spd = 1;                // shards per device
     uint32_t dim = 0, metric = 0, precision = 0;
-    uint32_t *d_bases = nullptr;     // [G] on device 0
-    uint32_t *d_out = nullptr;       // merged ids | dist | count on device 0
-    size_t out_words = 0;
-    std::mutex mu;
+    Lane lanes[KDB_CLANES];
+    std::mutex enq;                  // enqueue order = collective order on every device
+    uint64_t seq = 0;                // under enq_pick
+    std::mutex enq_pick;
 };
 
 extern "C" void kdb_cluster_destroy(kdb_cluster *c) {
     if (!c) return;
     for (DevSlot &d : c->devs) {
         (void)hipSetDevice(d.device);
-        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        (void)hipDeviceSynchronize();
         if (d.comm && rccl().ok) (void)rccl().CommDestroy(d.comm);
-        for (void *p : {(void *)d.d_q, (void *)d.d_send, (void *)d.d_recv})
-            if (p) (void)hipFree(p);
-        for (uint64_t *p : d.d_allow)
-            if (p) (void)hipFree(p);
-        if (d.ev) (void)hipEventDestroy(d.ev);
-        if (d.stream) (void)hipStreamDestroy(d.stream);
+        for (LaneDev &l : d.lane) {
+            for (void *p : {(void *)l.d_q, (void *)l.d_send, (void *)l.d_recv, (void *)l.d_bases, (void *)l.d_out})
+                if (p) (void)hipFree(p);
+            for (uint64_t *p : l.d_allow)
+                if (p) (void)hipFree(p);
+            if (l.ev_ready) (void)hipEventDestroy(l.ev_ready);
+            if (l.ev_coll) (void)hipEventDestroy(l.ev_coll);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+        }
+        if (d.coll) (void)hipStreamDestroy(d.coll);
     }
-    if (!c->devs.empty()) (void)hipSetDevice(c->devs[0].device);
-    if (c->d_bases) (void)hipFree(c->d_bases);
-    if (c->d_out) (void)hipFree(c->d_out);
+    for (Lane &l : c->lanes)
+        if (l.done) {
+            if (!c->devs.empty()) (void)hipSetDevice(c->devs[l.root].device);
+            (void)hipEventDestroy(l.done);
+        }
     delete c;
 }
 
@@ -186,18 +224,29 @@ extern "C" int kdb_cluster_create(kdb_index *const *shards, const uint32_t *id_b
         DevSlot &d = c->devs[i];
         d.device = dev_of[i];
         d.comm = comms[i];
-        d.d_allow.assign(c->spd, nullptr);
-        d.allow_words.assign(c->spd, 0);
-        if (hipSetDevice(d.device) != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) {
+        bool ok = hipSetDevice(d.device) == hipSuccess && hipStreamCreateWithFlags(&d.coll, hipStreamNonBlocking) == hipSuccess;
+        for (LaneDev &l : d.lane) {
+            l.d_allow.assign(c->spd, nullptr);
+            l.allow_bytes.assign(c->spd, 0);
+            ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&l.ev_ready, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&l.ev_coll, hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) {
             kdb_set_error("cluster_create: stream / event creation failed on device %d", d.device);
             return fail(KDB_ERR_HIP);
         }
     }
-    if (hipSetDevice(c->devs[0].device) != hipSuccess || hipMalloc(&c->d_bases, (size_t)n_shards * 4) != hipSuccess ||
-        hipMemcpy(c->d_bases, id_base, (size_t)n_shards * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        kdb_set_error("cluster_create: id base upload failed");
-        return fail(KDB_ERR_HIP);
+    for (int li = 0; li < KDB_CLANES; li++) { // lane li merges on device li (mod the number of devices)
+        Lane &l = c->lanes[li];
+        l.root = (uint32_t)li % (uint32_t)c->devs.size();
+        LaneDev &r = c->devs[l.root].lane[li];
+        if (hipSetDevice(c->devs[l.root].device) != hipSuccess || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess ||
+            hipMalloc(&r.d_bases, (size_t)n_shards * 4) != hipSuccess ||
+            hipMemcpy(r.d_bases, id_base, (size_t)n_shards * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            kdb_set_error("cluster_create: id base upload failed");
+            return fail(KDB_ERR_HIP);
+        }
     }
     *out = c;
     return KDB_OK;
@@ -233,6 +282,110 @@ static void slice_allow(const uint64_t *g, size_t g_words, uint32_t base, uint32
     out.back() &= last == 63u ? ~0ull : ((2ull << last) - 1ull);
 }
 
+// everything of one call that is queued on the devices; the caller then waits for lane.done
+static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                           const uint64_t *allow_bits, size_t allow_words, uint32_t flags, uint32_t *out_ids, void *out_dist,
+                           uint32_t *out_count, std::vector<std::vector<uint64_t>> &host_bits) {
+    Lane &lane = c->lanes[li];
+    const uint32_t G = (uint32_t)c->shards.size(), nd = (uint32_t)c->devs.size(), spd = c->spd;
+    const bool i8 = c->precision == KDB_PREC_I8; // distances travel as float64
+    const bool out64 = (flags & KDB_SEARCH_DIST_F64) != 0;
+    const size_t bk = (size_t)B * k;
+    // packed block in 32-bit words: float shards ids | dist | count; int8 shards dist64 | ids | count (8-byte aligned blocks)
+    const size_t L = i8 ? ((3 * bk + B + 1) & ~(size_t)1) : 2 * bk + B;
+    const size_t o_ids = i8 ? 2 * bk : 0, o_dist = i8 ? 0 : bk, o_cnt = i8 ? 3 * bk : 2 * bk;
+    const size_t qbytes = (size_t)B * c->dim * 4;
+    int rc;
+    for (uint32_t i = 0; i < nd; i++) {
+        LaneDev &d = c->devs[i].lane[li];
+        KDB_HIP(hipSetDevice(c->devs[i].device));
+        if ((rc = ensure_bytes((void **)&d.d_q, &d.q_bytes, qbytes))) return rc;
+        if ((rc = ensure_bytes((void **)&d.d_send, &d.send_bytes, (size_t)spd * L * 4))) return rc;
+        if ((rc = ensure_bytes((void **)&d.d_recv, &d.recv_bytes, (size_t)G * L * 4))) return rc;
+    }
+    DevSlot &rdev = c->devs[lane.root];
+    LaneDev &root = rdev.lane[li];
+    // 1. queries: H2D to the root, RCCL broadcast to the others (collective stream; the lanes' streams wait for it)
+    KDB_HIP(hipSetDevice(rdev.device));
+    KDB_HIP(hipMemcpyAsync(root.d_q, queries, qbytes, hipMemcpyHostToDevice, root.stream));
+    if (nd > 1) {
+        KDB_HIP(hipEventRecord(root.ev_ready, root.stream));
+        KDB_HIP(hipStreamWaitEvent(rdev.coll, root.ev_ready, 0));
+        KDB_NCCL(rccl().GroupStart());
+        for (uint32_t i = 0; i < nd; i++) {
+            KDB_HIP(hipSetDevice(c->devs[i].device));
+            LaneDev &d = c->devs[i].lane[li];
+            KDB_NCCL(rccl().Broadcast(d.d_q, d.d_q, qbytes / 4, KDB_NCCL_INT32, (int)lane.root, c->devs[i].comm, c->devs[i].coll)); // in place at the root
+        }
+        KDB_NCCL(rccl().GroupEnd());
+        for (uint32_t i = 0; i < nd; i++) {
+            KDB_HIP(hipSetDevice(c->devs[i].device));
+            LaneDev &d = c->devs[i].lane[li];
+            KDB_HIP(hipEventRecord(d.ev_coll, c->devs[i].coll));
+            KDB_HIP(hipStreamWaitEvent(d.stream, d.ev_coll, 0));
+        }
+    }
+    // 2. every shard searches on its device, into its slot of the send buffer (no host wait anywhere in this loop: the
+    //    sliced allow lists stay alive in host_bits until the call's final wait)
+    if (allow_bits) host_bits.resize(G);
+    const uint32_t sflags = i8 ? (flags | KDB_SEARCH_DIST_F64) : flags;
+    for (uint32_t g = 0; g < G; g++) {
+        LaneDev &d = c->devs[g / spd].lane[li];
+        const uint32_t ls = g % spd;
+        kdb_index *idx = c->shards[g];
+        KDB_HIP(hipSetDevice(c->devs[g / spd].device));
+        const uint64_t *d_allow = nullptr;
+        if (allow_bits) {
+            slice_allow(allow_bits, allow_words, c->id_base[g], idx->count, host_bits[g]);
+            if ((rc = ensure_bytes((void **)&d.d_allow[ls], &d.allow_bytes[ls], host_bits[g].size() * 8))) return rc;
+            KDB_HIP(hipMemcpyAsync(d.d_allow[ls], host_bits[g].data(), host_bits[g].size() * 8, hipMemcpyHostToDevice, d.stream));
+            d_allow = d.d_allow[ls];
+        }
+        uint32_t *blk = d.d_send + (size_t)ls * L;
+        rc = flat ? kdb_flat_scan_batch_dev(idx, d.d_q, B, k, d_allow, sflags, blk + o_ids, reinterpret_cast<float *>(blk + o_dist), blk + o_cnt, d.stream)
+                  : kdb_search_batch_dev(idx, d.d_q, B, k, ef, d_allow, sflags, blk + o_ids, reinterpret_cast<float *>(blk + o_dist), blk + o_cnt, d.stream);
+        if (rc) return rc;
+    }
+    // 3. the one exchange step: all-gather of the packed blocks over xGMI (collective stream, behind the walks)
+    for (uint32_t i = 0; i < nd; i++) {
+        KDB_HIP(hipSetDevice(c->devs[i].device));
+        LaneDev &d = c->devs[i].lane[li];
+        KDB_HIP(hipEventRecord(d.ev_ready, d.stream));
+        KDB_HIP(hipStreamWaitEvent(c->devs[i].coll, d.ev_ready, 0));
+    }
+    KDB_NCCL(rccl().GroupStart());
+    for (uint32_t i = 0; i < nd; i++) {
+        KDB_HIP(hipSetDevice(c->devs[i].device));
+        LaneDev &d = c->devs[i].lane[li];
+        KDB_NCCL(rccl().AllGather(d.d_send, d.d_recv, (size_t)spd * L, KDB_NCCL_INT32, c->devs[i].comm, c->devs[i].coll));
+    }
+    KDB_NCCL(rccl().GroupEnd());
+    // 4. merge on the root, answers home
+    KDB_HIP(hipSetDevice(rdev.device));
+    KDB_HIP(hipEventRecord(root.ev_coll, rdev.coll));
+    KDB_HIP(hipStreamWaitEvent(root.stream, root.ev_coll, 0));
+    const size_t dist_b = out64 ? 8 : 4;
+    if ((rc = ensure_bytes((void **)&root.d_out, &root.out_bytes, bk * 8 + bk * 4 + (size_t)B * 4 + 16))) return rc;
+    unsigned char *ob = reinterpret_cast<unsigned char *>(root.d_out);
+    void *m_dist = ob; // (8-byte distances first)
+    uint32_t *m_ids = reinterpret_cast<uint32_t *>(ob + bk * 8);
+    uint32_t *m_cnt = m_ids + bk;
+    if (i8) {
+        rc = kdb_launch_merge_topk_f64(G, B, k, root.d_recv + o_ids, reinterpret_cast<const double *>(root.d_recv + o_dist), root.d_recv + o_cnt,
+                                       L, L / 2, L, root.d_bases, m_ids, m_dist, out64 ? 1 : 0, m_cnt, root.stream);
+    } else {
+        const int negate = c->metric == KDB_METRIC_COSINE && c->precision == KDB_PREC_F32;
+        rc = kdb_launch_merge_topk(negate, G, B, k, root.d_recv + o_ids, reinterpret_cast<const float *>(root.d_recv + o_dist),
+                                   root.d_recv + o_cnt, L, L, root.d_bases, m_ids, reinterpret_cast<float *>(m_dist), m_cnt, root.stream);
+    }
+    if (rc) return rc;
+    KDB_HIP(hipMemcpyAsync(out_ids, m_ids, bk * 4, hipMemcpyDeviceToHost, root.stream));
+    KDB_HIP(hipMemcpyAsync(out_dist, m_dist, bk * dist_b, hipMemcpyDeviceToHost, root.stream));
+    KDB_HIP(hipMemcpyAsync(out_count, m_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, root.stream));
+    KDB_HIP(hipEventRecord(lane.done, root.stream));
+    return KDB_OK;
+}
+
 static int sharded_call(kdb_cluster *c, bool flat, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
                         const uint64_t *allow_bits, size_t allow_words, uint32_t flags, uint32_t *out_ids, float *out_dist,
                         uint32_t *out_count) {
@@ -245,97 +398,36 @@ static int sharded_call(kdb_cluster *c, bool flat, const float *queries, uint32_
         kdb_set_error("sharded search: null buffer or k == 0");
         return KDB_ERR_INVALID;
     }
-    if (flags & KDB_SEARCH_DIST_F64) { // the exchange block and the merge carry float distances
-        kdb_set_error("sharded search: KDB_SEARCH_DIST_F64 is a single-index option");
+    if ((flags & KDB_SEARCH_DIST_F64) && c->precision != KDB_PREC_I8) {
+        kdb_set_error("sharded search: KDB_SEARCH_DIST_F64 applies to int8 shards (the other precisions compute float32 distances)");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(c->mu);
-    const uint32_t G = (uint32_t)c->shards.size(), nd = (uint32_t)c->devs.size(), spd = c->spd;
-    const size_t L = 2ull * B * k + B; // packed block, 32-bit words
-    const size_t qbytes = (size_t)B * c->dim * 4;
+    int li;
+    {
+        std::lock_guard<std::mutex> pk(c->enq_pick);
+        li = (int)(c->seq++ % KDB_CLANES);
+    }
+    Lane &lane = c->lanes[li];
+    std::lock_guard<std::mutex> hold(lane.mu); // the lane's buffers belong to this call until its answers are home
+    std::vector<std::vector<uint64_t>> host_bits;
     int rc;
-    for (uint32_t i = 0; i < nd; i++) {
-        DevSlot &d = c->devs[i];
-        KDB_HIP(hipSetDevice(d.device));
-        if ((rc = ensure_bytes((void **)&d.d_q, &d.q_bytes, qbytes))) return rc;
-        size_t sb = d.send_words * 4, rb = d.recv_words * 4;
-        if ((rc = ensure_bytes((void **)&d.d_send, &sb, (size_t)spd * L * 4))) return rc;
-        if ((rc = ensure_bytes((void **)&d.d_recv, &rb, (size_t)G * L * 4))) return rc;
-        d.send_words = sb / 4;
-        d.recv_words = rb / 4;
-    }
-    // 1. queries: H2D to device 0, RCCL broadcast to the others
     {
-        DevSlot &d0 = c->devs[0];
-        KDB_HIP(hipSetDevice(d0.device));
-        KDB_HIP(hipMemcpyAsync(d0.d_q, queries, qbytes, hipMemcpyHostToDevice, d0.stream));
-        if (nd > 1) {
-            KDB_NCCL(rccl().GroupStart());
-            for (uint32_t i = 0; i < nd; i++) {
-                DevSlot &d = c->devs[i];
-                KDB_HIP(hipSetDevice(d.device));
-                KDB_NCCL(rccl().Broadcast(d.d_q, d.d_q, qbytes / 4, KDB_NCCL_INT32, 0, d.comm, d.stream)); // in place at the root
-            }
-            KDB_NCCL(rccl().GroupEnd());
+        std::lock_guard<std::mutex> lk(c->enq);
+        rc = sharded_enqueue(c, li, flat, queries, B, k, ef, allow_bits, allow_words, flags, out_ids, out_dist, out_count, host_bits);
+    }
+    if (rc != KDB_OK) { // whatever was queued still reads the caller's and this frame's buffers: drain before returning
+        for (DevSlot &d : c->devs) {
+            (void)hipSetDevice(d.device);
+            (void)hipStreamSynchronize(d.lane[li].stream);
+            (void)hipStreamSynchronize(d.coll);
         }
+        return rc;
     }
-    // 2. every shard searches on its device, into its slot of the send buffer
-    std::vector<uint64_t> host_bits;
-    for (uint32_t g = 0; g < G; g++) {
-        DevSlot &d = c->devs[g / spd];
-        const uint32_t li = g % spd;
-        kdb_index *idx = c->shards[g];
-        KDB_HIP(hipSetDevice(d.device));
-        const uint64_t *d_allow = nullptr;
-        if (allow_bits) {
-            slice_allow(allow_bits, allow_words, c->id_base[g], idx->count, host_bits);
-            size_t have = d.allow_words[li] * 8;
-            if ((rc = ensure_bytes((void **)&d.d_allow[li], &have, host_bits.size() * 8))) return rc;
-            d.allow_words[li] = have / 8;
-            // (pageable source: the copy has consumed host_bits when the call returns)
-            KDB_HIP(hipMemcpyAsync(d.d_allow[li], host_bits.data(), host_bits.size() * 8, hipMemcpyHostToDevice, d.stream));
-            KDB_HIP(hipStreamSynchronize(d.stream));
-            d_allow = d.d_allow[li];
-        }
-        uint32_t *blk = d.d_send + (size_t)li * L;
-        uint32_t *b_ids = blk;
-        float *b_dist = reinterpret_cast<float *>(blk + (size_t)B * k);
-        uint32_t *b_cnt = blk + 2 * (size_t)B * k;
-        rc = flat ? kdb_flat_scan_batch_dev(idx, d.d_q, B, k, d_allow, flags, b_ids, b_dist, b_cnt, d.stream)
-                  : kdb_search_batch_dev(idx, d.d_q, B, k, ef, d_allow, flags, b_ids, b_dist, b_cnt, d.stream);
-        if (rc) return rc;
-    }
-    // 3. the one exchange step: all-gather of the packed blocks over xGMI
-    KDB_NCCL(rccl().GroupStart());
-    for (uint32_t i = 0; i < nd; i++) {
-        DevSlot &d = c->devs[i];
-        KDB_HIP(hipSetDevice(d.device));
-        KDB_NCCL(rccl().AllGather(d.d_send, d.d_recv, (size_t)spd * L, KDB_NCCL_INT32, d.comm, d.stream));
-    }
-    KDB_NCCL(rccl().GroupEnd());
-    // 4. merge on device 0, answers home
-    DevSlot &d0 = c->devs[0];
-    KDB_HIP(hipSetDevice(d0.device));
-    {
-        size_t ob = c->out_words * 4;
-        if ((rc = ensure_bytes((void **)&c->d_out, &ob, L * 4))) return rc;
-        c->out_words = ob / 4;
-    }
-    uint32_t *m_ids = c->d_out;
-    float *m_dist = reinterpret_cast<float *>(c->d_out + (size_t)B * k);
-    uint32_t *m_cnt = c->d_out + 2 * (size_t)B * k;
-    const int negate = c->metric == KDB_METRIC_COSINE && c->precision == KDB_PREC_F32;
-    const size_t bk = (size_t)B * k;
-    rc = kdb_launch_merge_topk(negate, G, B, k, d0.d_recv, reinterpret_cast<const float *>(d0.d_recv + bk), d0.d_recv + 2 * bk, L, L,
-                               c->d_bases, m_ids, m_dist, m_cnt, d0.stream);
-    if (rc) return rc;
-    KDB_HIP(hipMemcpyAsync(out_ids, m_ids, bk * 4, hipMemcpyDeviceToHost, d0.stream));
-    KDB_HIP(hipMemcpyAsync(out_dist, m_dist, bk * 4, hipMemcpyDeviceToHost, d0.stream));
-    KDB_HIP(hipMemcpyAsync(out_count, m_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, d0.stream));
-    for (uint32_t i = 0; i < nd; i++) { // every device's part of the call is over before the caller's buffers are reused
-        KDB_HIP(hipSetDevice(c->devs[i].device));
-        KDB_HIP(hipStreamSynchronize(c->devs[i].stream));
-    }
+    // ONE wait, on the root's stream: the D2H copies are the call's last operations and every other piece of it precedes
+    // them (walks -> all-gather -> merge).  The other devices' collective kernels of this call may still be delivering
+    // blocks into THEIR receive buffers; the lane's next call orders itself behind them through the collective stream.
+    KDB_HIP(hipSetDevice(c->devs[lane.root].device));
+    KDB_HIP(hipEventSynchronize(lane.done));
     return KDB_OK;
 }
 

@@ -1528,10 +1528,14 @@ group_fill_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words
 // negate = 1 when larger raw values are nearer (dot products of the f32 cosine path).
 // Shard g's ids/distances start at g*stride_e and its counts at g*stride_c (32-bit words): separate [G][B][k]
 // arrays use (B*k, B); the packed block one all-gather delivers uses (L, L) with L = 2*B*k + B.
+// DT: the distances of the per-shard lists (float; double for int8 shards, whose distances the reference computes AND orders
+// as float64, hnsw_index.go:2429-2454 -- two distinct doubles may round to one float, and a merge over floats would then
+// rank them by id).  OT: what the caller receives.  Strides: ids / counts in 32-bit words, distances in DT elements.
+template <typename DT, typename OT>
 __global__ void __launch_bounds__(64)
-merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const float *in_dist,
-                  const uint32_t *in_count, size_t stride_e, size_t stride_c, const uint32_t *id_base,
-                  uint32_t *out_ids, float *out_dist, uint32_t *out_count) {
+merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const DT *in_dist,
+                  const uint32_t *in_count, size_t stride_i, size_t stride_d, size_t stride_c, const uint32_t *id_base,
+                  uint32_t *out_ids, OT *out_dist, uint32_t *out_count) {
     const uint32_t q = blockIdx.x;
     const int lane = kdb_lane();
     uint32_t total = 0;
@@ -1546,30 +1550,30 @@ merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t
         uint32_t cg = in_count[g * stride_c + q];
         if (cg > k) cg = k;
         if (i >= cg) continue;
-        const size_t off = g * stride_e + (size_t)q * k + i;
-        const float d = in_dist[off];
-        const uint32_t id = in_ids[off] + (id_base ? id_base[g] : 0u);
-        const float key = negate ? -d : d;
+        const DT d = in_dist[g * stride_d + (size_t)q * k + i];
+        const uint32_t id = in_ids[g * stride_i + (size_t)q * k + i] + (id_base ? id_base[g] : 0u);
+        const DT key = negate ? -d : d;
         uint32_t rank = 0;
         for (uint32_t g2 = 0; g2 < G; g2++) {
             uint32_t c2 = in_count[g2 * stride_c + q];
             if (c2 > k) c2 = k;
-            const size_t o2 = g2 * stride_e + (size_t)q * k;
+            const size_t oi = g2 * stride_i + (size_t)q * k, od = g2 * stride_d + (size_t)q * k;
             const uint32_t b2 = id_base ? id_base[g2] : 0u;
             for (uint32_t j = 0; j < c2; j++) {
-                const float d2 = in_dist[o2 + j];
-                const float key2 = negate ? -d2 : d2;
-                rank += fs_better(key2, in_ids[o2 + j] + b2, key, id) ? 1u : 0u;
+                const DT d2 = in_dist[od + j];
+                const DT key2 = negate ? -d2 : d2;
+                const uint32_t id2 = in_ids[oi + j] + b2;
+                rank += (key2 < key || (key2 == key && id2 < id)) ? 1u : 0u;
             }
         }
         if (rank < k) {
             out_ids[(size_t)q * k + rank] = id;
-            out_dist[(size_t)q * k + rank] = d;
+            out_dist[(size_t)q * k + rank] = (OT)d;
         }
     }
     for (uint32_t i = nout + (uint32_t)lane; i < k; i += 64) {
         out_ids[(size_t)q * k + i] = 0u;
-        out_dist[(size_t)q * k + i] = INFINITY;
+        out_dist[(size_t)q * k + i] = (OT)INFINITY;
     }
     if (lane == 0) out_count[q] = nout;
 }
@@ -1605,9 +1609,25 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
                           const uint32_t *d_id_base, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
                           hipStream_t s) {
     if (B == 0) return KDB_OK;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, s, negate, G, B, k, d_in_ids, d_in_dist, d_in_count,
-                       stride_e ? stride_e : (size_t)B * k, stride_c ? stride_c : (size_t)B, d_id_base, d_out_ids, d_out_dist,
-                       d_out_count);
+    const size_t se = stride_e ? stride_e : (size_t)B * k;
+    hipLaunchKernelGGL((merge_topk_kernel<float, float>), dim3(B), dim3(64), 0, s, negate, G, B, k, d_in_ids, d_in_dist, d_in_count,
+                       se, se, stride_c ? stride_c : (size_t)B, d_id_base, d_out_ids, d_out_dist, d_out_count);
+    KDB_HIP(hipGetLastError());
+    return KDB_OK;
+}
+
+// int8 shards: float64 distances in, float64 (out64) or their float rounding out; the ORDER is the float64 order either way
+int kdb_launch_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids, const double *d_in_dist,
+                              const uint32_t *d_in_count, size_t stride_i, size_t stride_d, size_t stride_c,
+                              const uint32_t *d_id_base, uint32_t *d_out_ids, void *d_out_dist, int out64, uint32_t *d_out_count,
+                              hipStream_t s) {
+    if (B == 0) return KDB_OK;
+    if (out64)
+        hipLaunchKernelGGL((merge_topk_kernel<double, double>), dim3(B), dim3(64), 0, s, 0, G, B, k, d_in_ids, d_in_dist, d_in_count,
+                           stride_i, stride_d, stride_c, d_id_base, d_out_ids, reinterpret_cast<double *>(d_out_dist), d_out_count);
+    else
+        hipLaunchKernelGGL((merge_topk_kernel<double, float>), dim3(B), dim3(64), 0, s, 0, G, B, k, d_in_ids, d_in_dist, d_in_count,
+                           stride_i, stride_d, stride_c, d_id_base, d_out_ids, reinterpret_cast<float *>(d_out_dist), d_out_count);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }

@@ -189,6 +189,10 @@ int kdb_launch_merge_topk(int negate, uint32_t G, uint32_t B, uint32_t k, const 
                           const float *d_in_dist, const uint32_t *d_in_count, size_t stride_e, size_t stride_c,
                           const uint32_t *d_id_base, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
                           hipStream_t s);
+int kdb_launch_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids, const double *d_in_dist,
+                              const uint32_t *d_in_count, size_t stride_i, size_t stride_d, size_t stride_c,
+                              const uint32_t *d_id_base, uint32_t *d_out_ids, void *d_out_dist, int out64, uint32_t *d_out_count,
+                              hipStream_t s);
 // build.hip
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p);
 int kdb_select_probe(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *d_ids, const void *d_keys,

@@ -84,6 +84,111 @@ def test_sharded_search_through_the_abi(oracle, hip, metric, layout):
     cl.close()
 
 
+def test_sharded_int8_merges_float64_distances(oracle, hip):
+    """int8 shards: the reference computes AND orders its distances as float64 (hnsw_index.go:2429-2454).  The exchange
+    block and the merge carry doubles, so two candidates of DIFFERENT shards whose distances are distinct doubles but one
+    float come out in the float64 order -- not by id, which is what a merge over floats would do.  Corpus: the
+    float-collision rows of test_int8_float64_order_where_floats_collide, dealt alternately to two shards."""
+    from test_gpu_parity import int8_collision_corpus, INT8_CASE_ABSMAX
+    O = oracle
+    dim, k = 48, 100
+    X, q = int8_collision_corpus(dim)
+    n = X.shape[0]
+    half = n // 2
+    parts = [X[:half], X[half:]]
+    bases = [0, half]
+    shards, orcs = [], []
+    for g, P in enumerate(parts):
+        orc = O.OracleIndex(dim, 1, O.I8, 16, 60, seed=7 + g)
+        orc.set_absmax(INT8_CASE_ABSMAX)
+        orc.add_batch(P)
+        idx = hip.HipIndex(dim, 1, O.I8, 16, 60, capacity=P.shape[0] + 8)
+        idx.upload_rows(orc.rows()[1:], 1)
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+        idx.upload_graph_obj(orc.export_graph())
+        shards.append(idx)
+        orcs.append(orc)
+    cl = hip.Cluster(shards, bases)
+    Q = np.stack([q, q * np.float32(0.5)] + [X[i] for i in range(6)])
+    F64 = 8
+    cross = 0
+    for name, call, ocall in (("scan", lambda fl: cl.flat_scan_batch(Q, k, flags=fl), lambda o, b: o.flat_scan(Q[b], k)),
+                              ("walk", lambda fl: cl.search_batch(Q, k, 200, flags=fl), lambda o, b: o.search(Q[b], k, ef=200))):
+        ids, dist, cnt = call(F64)
+        ids32, dist32, cnt32 = call(0)
+        assert dist.dtype == np.float64 and dist32.dtype == np.float32
+        for b in range(Q.shape[0]):
+            wi, wd = _merge([ocall(o, b) for o in orcs], bases, k)
+            c = int(cnt[b])
+            assert c == len(wi)
+            assert np.array_equal(ids[b, :c], wi), (name, b, np.nonzero(ids[b, :c] != wi))
+            assert np.array_equal(dist[b, :c], wd), (name, b)
+            # without the flag: the same order, the doubles rounded to float
+            assert np.array_equal(ids32[b, :c], wi) and np.array_equal(dist32[b, :c], wd.astype(np.float32)), (name, b)
+            f = wd.astype(np.float32)
+            shard_of = (wi > half).astype(int)
+            tie = (f[1:] == f[:-1]) & (wd[1:] != wd[:-1])
+            cross += int(np.sum(tie & (shard_of[1:] != shard_of[:-1]) & (wi[1:] < wi[:-1])))
+    assert cross >= 1, "no float32 collision between distinct doubles of different shards in id-descending order: the case does not test the merge"
+    with pytest.raises(hip.KdbError):
+        f32 = hip.HipIndex(16, 0, 0, 8, 20, capacity=64)
+        hip.Cluster([f32], [0]).search_batch(np.zeros((1, 16), np.float32), 1, 10, flags=F64)   # float64 distances are an int8 option
+    cl.close()
+
+
+def test_sharded_calls_of_two_threads_overlap_and_agree(oracle, hip):
+    """two lanes per cluster: the calls of concurrent callers share nothing but the devices.  Eight threads, each with its own
+    batches, against the answers of the same calls made one after the other; and two callers in flight finish a fixed
+    amount of work sooner than one (the walks of one call run under the exchange / merge / copies of the other)."""
+    import threading
+    import time
+    O = oracle
+    n, dim, k, ef = 6000, 96, 10, 64
+    X = make_corpus(n, dim, "normal", seed=95)
+    shards, orcs, bases = _shards(hip, O, X, 1, [0, 0])
+    cl = hip.Cluster(shards, bases)
+    batches = [make_corpus(40 + 13 * t, dim, "normal", seed=200 + t) for t in range(8)]
+    want = [cl.search_batch(Qb, k, ef) for Qb in batches]
+    got = [None] * len(batches)
+    errs = []
+
+    def work(t):
+        try:
+            for _ in range(5):
+                got[t] = cl.search_batch(batches[t], k, ef)
+        except Exception as e:  # noqa
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(len(batches))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for t in range(len(batches)):
+        for a, b in zip(got[t], want[t]):
+            assert np.array_equal(a, b), t
+    # throughput: 2048-query batches, one caller vs two callers in flight
+    Qb = make_corpus(2048, dim, "normal", seed=300)
+    cl.search_batch(Qb, k, ef)
+    reps = 12
+
+    def run(nthreads):
+        def loop():
+            for _ in range(reps // nthreads):
+                cl.search_batch(Qb, k, ef)
+        th = [threading.Thread(target=loop) for _ in range(nthreads)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        return time.perf_counter() - t0
+
+    t1 = min(run(1) for _ in range(3))
+    t2 = min(run(2) for _ in range(3))
+    print(f"cluster, {reps} batches of 2048 queries over two shards: one caller {t1 * 1e3:.1f} ms, two callers {t2 * 1e3:.1f} ms")
+    assert t2 < t1 * 1.05   # never slower; on an idle box two callers overlap (printed)
+    cl.close()
+
+
 def test_cluster_argument_validation(hip):
     a = hip.HipIndex(16, 0, 0, 8, 20, capacity=64)
     b = hip.HipIndex(32, 0, 0, 8, 20, capacity=64)

@@ -56,16 +56,17 @@ def _np(o):
     return o[0].cpu().numpy().view(np.uint32), o[1].cpu().numpy(), o[2].cpu().numpy().view(np.uint32)
 
 
-def _oracle_over_rows(O, rows, ids_of_row, metric, dim, queries, k):
+def _oracle_over_rows(O, rows, ids_of_row, metric, dim, queries, k, arith=None):
     """exact answers of the oracle over `rows` (m x dim, stored form); row i carries the global id ids_of_row[i]
-    (ascending).  Returns per query (ids, f64 distances) under the total order (distance, global id)."""
+    (ascending).  Returns per query (ids, f64 distances) under the total order (distance, global id).
+    arith: accumulation order (default: the GPU's own, ARITH_HIP_WAVE)."""
     m = rows.shape[0]
     r1 = np.zeros((m + 1, dim), dtype=np.float32)
     r1[1:] = rows
     og = O.Graph(m, np.zeros(m + 1, np.uint8), 0, 1, [np.zeros(m + 2, np.uint64)], [np.zeros(1, np.uint32)],
                  np.zeros((m >> 6) + 1, np.uint64))
     orc = O.OracleIndex.from_graph(dim, metric, O.F32, 16, 200, r1, og)
-    orc.set_arith(O.ARITH_HIP_WAVE)
+    orc.set_arith(O.ARITH_HIP_WAVE if arith is None else arith)
     with cf.ThreadPoolExecutor(16) as ex:
         res = list(ex.map(lambda q: orc.flat_scan(q, k), queries))
     return [(ids_of_row[li.astype(np.int64) - 1], d) for li, d in res]
@@ -129,12 +130,26 @@ def test_config3_flat_scan_10m_l2_k100(oracle, hip):
         oi, od = _merge_exact(parts[b], k)
         assert np.array_equal(fi[b], oi), (b, fi[b][:8], oi[:8])
         assert np.array_equal(fd[b].astype(np.float64), od), b
+    # arithmetic parity at full size: the same scan in the reference's AVX2 order (lib.rs:34-71, what its -tags rust build
+    # runs for 768-d rows) -- distances within 1e-4 relative, ids equal except between near-ties
+    from test_gpu_parity import assert_same_results_tol
+    nr = 4
+    parts = [[] for _ in range(nr)]
+    for s in range(0, n, CHUNK):
+        rows = idx.download_rows(s + 1, CHUNK)
+        res = _oracle_over_rows(O, rows, np.arange(s + 1, s + CHUNK + 1, dtype=np.uint32), O.L2, dim, qh[:nr], k, arith=O.ARITH_RUST)
+        for b in range(nr):
+            parts[b].append(res[b])
+    for b in range(nr):
+        oi, od = _merge_exact(parts[b], k)
+        assert_same_results_tol(fi[b], fd[b].astype(np.float64), oi, od)
     print(f"config 3: 10M x 768 L2 k=100, {B} queries: scan kernel {ms:.1f} ms")
 
 
 def test_config5_prefilter_10m_1536(oracle, hip):
     import torch
     from kektordb_amd.index import dense_bitset
+    from test_gpu_parity import assert_same_results_tol
     O = oracle
     n, dim, k, B, ncat = 10_000_000, 1536, 10, 1024, 100
     dev = torch.device("cuda:0")
@@ -176,6 +191,10 @@ def test_config5_prefilter_10m_1536(oracle, hip):
             assert np.array_equal(gi[b], oi), (c, b, gi[b], oi)
             assert np.array_equal(1.0 - gd[b].astype(np.float64), od), (c, b)
             checked += 1
+        for arith in (O.ARITH_GO, O.ARITH_RUST):   # the reference's own accumulation orders: tolerance + tie-aware ids
+            res = _oracle_over_rows(O, stash[c].cpu().numpy(), allowed[c], O.COSINE, dim, Qs[sel].cpu().numpy(), k, arith=arith)
+            for t, b in enumerate(sel):
+                assert_same_results_tol(gi[b], 1.0 - gd[b].astype(np.float64), res[t][0], res[t][1])
     assert checked >= 12
     # one list shared by a whole batch: 1024 queries over the ~100k rows of one category (big-tile kernel, gathered rows)
     c0 = int(cats[0])
@@ -250,4 +269,10 @@ def test_config4_one_shard_12m5(oracle, hip):
         assert np.array_equal(ids[b, :int(cn[b])], oi_)
         assert np.array_equal(1.0 - dist[b, :int(cn[b])].astype(np.float64), od_)
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    from test_gpu_parity import assert_same_results_tol
+    for arith in (O.ARITH_GO, O.ARITH_RUST):   # the reference's accumulation orders: tolerance + tie-aware id parity
+        orc.set_arith(arith)
+        for b in range(8):
+            oi_, od_ = orc.search(q8[b], k, ef=ef)
+            assert_same_results_tol(ids[b, :int(cn[b])], 1.0 - dist[b, :int(cn[b])].astype(np.float64), oi_, od_)
     print(f"config 4 shard: 12.5M x 768, {B} queries ef={ef}: search kernel {c['kernel_ms']:.2f} ms, recall@10 {rec:.3f}")

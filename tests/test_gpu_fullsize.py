@@ -67,17 +67,26 @@ def test_config1_full_size_properties(oracle, hip):
     idx.sync()
     assert np.mean(si.cpu().numpy()[:, 0] == np.arange(1, B + 1)) > 0.97
     assert np.all(np.abs(1.0 - sd.cpu().numpy()[:, 0][si.cpu().numpy()[:, 0] == np.arange(1, B + 1)]) < 1e-5)
-    # bit-exact parity with the oracle on the same graph + rows (16 queries at full size)
+    # bit-exact parity with the oracle on the same graph + rows (64 walks at full size: ids, distance bits, counters), and --
+    # for the same walks -- tolerance + tie-aware parity against the reference's own accumulation orders (scalar Go loop /
+    # BLAS-style Sdot, and the AVX2 order of its -tags rust build)
     c, e, ml, levels, offs, nbrs = idx.download_graph()
     rows = np.zeros((n + 1, dim), dtype=np.float32)
     rows[1:] = X.cpu().numpy()
     og = O.Graph(c, levels, ml, e, offs, nbrs, np.zeros((c >> 6) + 1, dtype=np.uint64))
     orc = O.OracleIndex.from_graph(dim, O.COSINE, O.F32, 16, 200, rows, og)
     orc.set_arith(O.ARITH_HIP_WAVE)
-    q16 = Q[:16].cpu().numpy()
-    ids, dist, cnt, (nd, nh) = idx.search_batch(q16, k, 64, trace=True)
-    for b in range(16):
-        oi_, od_, (ond, onh) = orc.search(q16[b], k, ef=64, counters=True)
+    from test_gpu_parity import assert_same_results_tol
+    NW = 64
+    qw = Q[:NW].cpu().numpy()
+    ids, dist, cnt, (nd, nh) = idx.search_batch(qw, k, 64, trace=True)
+    for b in range(NW):
+        oi_, od_, (ond, onh) = orc.search(qw[b], k, ef=64, counters=True)
         assert np.array_equal(ids[b, :int(cnt[b])], oi_)
         assert np.array_equal(1.0 - dist[b, :int(cnt[b])].astype(np.float64), od_)
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
+    for arith in (O.ARITH_GO, O.ARITH_RUST):
+        orc.set_arith(arith)
+        for b in range(NW):
+            oi_, od_ = orc.search(qw[b], k, ef=64)
+            assert_same_results_tol(ids[b, :int(cnt[b])], 1.0 - dist[b, :int(cnt[b])].astype(np.float64), oi_, od_)
