@@ -1437,33 +1437,47 @@ compact_ids_kernel(const uint32_t *deleted, const uint32_t *allow, const uint32_
 }
 
 // ---- grouped scan: one id list per allow list, all lists compacted by three launches, nothing read back ----------
-// (a) rows that survive every list
-__global__ void __launch_bounds__(256)
-group_count_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t *g_n) {
-    const uint32_t g = blockIdx.y;
-    const uint32_t *allow = lists + (size_t)g * words32;
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t nwords = (count >> 5) + 1u;
-    uint32_t m = 0;
-    if (w < nwords) {
-        m = ~deleted[w] & allow[w];
-        if (w == 0) m &= ~1u;
-        const uint32_t last = count & 31u;
-        if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
-    }
-    int c = kdb_wave_sum_i(__builtin_popcount(m));
-    if (c && (threadIdx.x & 63u) == 0) atomicAdd(&g_n[g], (uint32_t)c);
+// Every list is cut into FG_NB chunks of whole 256-word slabs; workgroup (b, g) owns chunk b of list g in all three steps,
+// so no step needs an atomic and every id list comes out ASCENDING.  (Round 2 used one workgroup per 256 words and one
+// atomicAdd per wave / workgroup on the group's counter: 100 lists over 10M ids = 490 k atomics on 100 addresses, 3.8 ms of
+// a 9 ms call -- config 5.)
+constexpr uint32_t FG_NB = 64;
+__device__ __forceinline__ uint32_t fg_words_per_chunk(uint32_t nwords) { return ((nwords + FG_NB - 1u) / FG_NB + 255u) & ~255u; }
+__device__ __forceinline__ uint32_t fg_mask(const uint32_t *deleted, const uint32_t *allow, uint32_t w, uint32_t nwords, uint32_t count) {
+    if (w >= nwords) return 0u;
+    uint32_t m = ~deleted[w] & allow[w];
+    if (w == 0) m &= ~1u; // id 0 does not exist
+    const uint32_t last = count & 31u; // ids above count
+    if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
+    return m;
 }
-// (b) exclusive prefix over the groups (one workgroup); cursors start at the bases; total -> statistics
+// (a) rows of chunk b that survive list g -> cnt[g * FG_NB + b]
 __global__ void __launch_bounds__(256)
-group_prefix_kernel(const uint32_t *g_n, uint32_t G, uint32_t *g_base, uint32_t *g_cursor, unsigned long long *ctr) {
+group_count_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t *cnt) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t g = blockIdx.y, b = blockIdx.x;
+    const uint32_t *allow = lists + (size_t)g * words32;
+    const uint32_t nwords = (count >> 5) + 1u, wpc = fg_words_per_chunk(nwords);
+    int c = 0;
+    for (uint32_t w0 = b * wpc; w0 < (b + 1u) * wpc && w0 < nwords; w0 += 256u)
+        c += __builtin_popcount(fg_mask(deleted, allow, w0 + threadIdx.x, nwords, count));
+    c = kdb_wave_sum_i(c);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = (uint32_t)c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[g * FG_NB + b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// (b) exclusive prefix over all (group, chunk) counts in order (one workgroup): where every chunk writes; per group its
+//     size and its base; total -> statistics
+__global__ void __launch_bounds__(256)
+group_prefix_kernel(const uint32_t *cnt, uint32_t G, uint32_t *chunk_base, uint32_t *g_n, uint32_t *g_base, unsigned long long *ctr) {
     __shared__ uint32_t carry;
     __shared__ uint32_t wsum[4];
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t g0 = 0; g0 < G; g0 += 256) {
-        const uint32_t g = g0 + threadIdx.x;
-        const uint32_t c = g < G ? g_n[g] : 0u;
+    const uint32_t N = G * FG_NB;
+    for (uint32_t i0 = 0; i0 < N; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t c = i < N ? cnt[i] : 0u;
         uint32_t inc = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1473,54 +1487,54 @@ group_prefix_kernel(const uint32_t *g_n, uint32_t G, uint32_t *g_base, uint32_t 
         if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
         __syncthreads();
         uint32_t base = carry + inc - c;
-        for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) base += wsum[i];
-        if (g < G) {
-            g_base[g] = base;
-            g_cursor[g] = base;
+        for (uint32_t j = 0; j < (threadIdx.x >> 6); j++) base += wsum[j];
+        if (i < N) {
+            chunk_base[i] = base;
+            if (i % FG_NB == 0u) g_base[i / FG_NB] = base;
         }
         __syncthreads();
         if (threadIdx.x == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && ctr) ctr[0] = carry;
+    // group sizes: the next group's base minus this one's (the last: total minus base)
+    const uint32_t total = carry;
+    for (uint32_t g = threadIdx.x; g < G; g += 256) {
+        uint32_t n = 0;
+        for (uint32_t b = 0; b < FG_NB; b++) n += cnt[g * FG_NB + b];
+        g_n[g] = n;
+    }
+    if (threadIdx.x == 0 && ctr) ctr[0] = total;
 }
-// (c) fill: as compact_ids_kernel, one atomic per workgroup on the group's cursor
+// (c) fill: chunk b of list g writes its ids, ascending, from chunk_base[g * FG_NB + b]
 __global__ void __launch_bounds__(256)
-group_fill_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, uint32_t *g_cursor,
+group_fill_kernel(const uint32_t *deleted, const uint32_t *lists, uint32_t words32, uint32_t count, const uint32_t *chunk_base,
                   uint32_t *out) {
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t blk_base;
-    const uint32_t g = blockIdx.y;
+    const uint32_t g = blockIdx.y, b = blockIdx.x;
     const uint32_t *allow = lists + (size_t)g * words32;
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t nwords = (count >> 5) + 1u;
-    uint32_t m = 0;
-    if (w < nwords) {
-        m = ~deleted[w] & allow[w];
-        if (w == 0) m &= ~1u;
-        const uint32_t last = count & 31u;
-        if (w == nwords - 1u) m &= last == 31u ? 0xffffffffu : ((2u << last) - 1u);
-    }
-    const uint32_t c = (uint32_t)__builtin_popcount(m);
-    uint32_t inc = c;
+    const uint32_t nwords = (count >> 5) + 1u, wpc = fg_words_per_chunk(nwords);
+    uint32_t run = chunk_base[g * FG_NB + b];
+    for (uint32_t w0 = b * wpc; w0 < (b + 1u) * wpc && w0 < nwords; w0 += 256u) {
+        const uint32_t w = w0 + threadIdx.x;
+        uint32_t m = fg_mask(deleted, allow, w, nwords, count);
+        const uint32_t c = (uint32_t)__builtin_popcount(m);
+        uint32_t inc = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-        if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
-    }
-    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        blk_base = tot ? atomicAdd(&g_cursor[g], tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t pos = blk_base + inc - c;
-    for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) pos += wsum[i];
-    while (m) {
-        const uint32_t bit = (uint32_t)__builtin_ctz(m);
-        m &= m - 1u;
-        out[pos++] = w * 32u + bit;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
+        }
+        __syncthreads(); // wsum of the previous slab has been read by everyone
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t pos = run + inc - c;
+        for (uint32_t j = 0; j < (threadIdx.x >> 6); j++) pos += wsum[j];
+        while (m) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            out[pos++] = w * 32u + bit;
+        }
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -2009,21 +2023,22 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     uint32_t stripes_max = FS_MAX_MERGE / kl;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint32_t nwords = (v.count >> 5) + 1u;
-    const dim3 ggrid((nwords + 255) / 256, G);
+    const dim3 ggrid(FG_NB, G);
+    (void)nwords;
 
     // group sizes first if the caller gave no bound (one 4*G-byte read-back)
-    int rc = kdb_ensure_scratch(idx, al((size_t)G * 4) * 3 + 4096);
+    const size_t chunk_words = (size_t)G * FG_NB;
+    int rc = kdb_ensure_scratch(idx, al(chunk_words * 4) * 2 + al((size_t)G * 4) * 2 + 4096);
     if (rc) return rc;
     uint64_t total = max_total_allowed;
     if (total == 0) {
         uint32_t *d_gn0 = reinterpret_cast<uint32_t *>(idx->d_scratch);
-        KDB_HIP(hipMemsetAsync(d_gn0, 0, (size_t)G * 4, s));
         hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gn0);
         KDB_HIP(hipGetLastError());
-        std::vector<uint32_t> gn(G);
-        KDB_HIP(hipMemcpyAsync(gn.data(), d_gn0, (size_t)G * 4, hipMemcpyDeviceToHost, s));
+        std::vector<uint32_t> gn(chunk_words);
+        KDB_HIP(hipMemcpyAsync(gn.data(), d_gn0, chunk_words * 4, hipMemcpyDeviceToHost, s));
         KDB_HIP(hipStreamSynchronize(s));
-        for (uint32_t g = 0; g < G; g++) total += gn[g];
+        for (uint32_t c : gn) total += c;
         if (total == 0) total = 1;
     }
     if (total > (uint64_t)G * v.count) total = (uint64_t)G * v.count;
@@ -2059,15 +2074,16 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
 
     const size_t ids_bytes = al((size_t)total * 4 + 1024);
     const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
-    const size_t need = ids_bytes + al((size_t)G * 4) * 3 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + part_bytes + 4096;
+    const size_t need = ids_bytes + al((size_t)G * 4) * 2 + al(chunk_words * 4) * 2 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + part_bytes + 4096;
     rc = kdb_ensure_scratch(idx, need);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
     uint32_t *d_gn = reinterpret_cast<uint32_t *>(base + ids_bytes);
     uint32_t *d_gbase = reinterpret_cast<uint32_t *>(base + ids_bytes + al((size_t)G * 4));
-    uint32_t *d_gcur = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4));
-    uint32_t *d_tiles = reinterpret_cast<uint32_t *>(base + ids_bytes + 3 * al((size_t)G * 4));
+    uint32_t *d_ccnt = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4));                  // [G][FG_NB] rows per chunk
+    uint32_t *d_cbase = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4) + al(chunk_words * 4)); // where each chunk writes
+    uint32_t *d_tiles = reinterpret_cast<uint32_t *>(base + ids_bytes + 2 * al((size_t)G * 4) + 2 * al(chunk_words * 4));
     uint32_t *d_qgrp = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_tiles) + al(tiles.size() * 4));
     uint32_t *d_qtile = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qgrp) + al((size_t)B * 4));
     uint32_t *d_qflag = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_qtile) + al((size_t)B * 4));
@@ -2089,10 +2105,9 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     KDB_HIP(hipMemcpyAsync(d_qgrp, qgrp.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     KDB_HIP(hipMemcpyAsync(d_qtile, qtile.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     KDB_HIP(hipMemsetAsync(d_qflag, 0, al((size_t)B * 4) + al(tiles.size() * 4) + 256, s)); // q_flag, tile_flag, count
-    KDB_HIP(hipMemsetAsync(d_gn, 0, (size_t)G * 4, s));
-    hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gn);
-    hipLaunchKernelGGL(group_prefix_kernel, dim3(1), dim3(256), 0, s, d_gn, G, d_gbase, d_gcur, p.ctr);
-    hipLaunchKernelGGL(group_fill_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_gcur, d_ids);
+    hipLaunchKernelGGL(group_count_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_ccnt);
+    hipLaunchKernelGGL(group_prefix_kernel, dim3(1), dim3(256), 0, s, d_ccnt, G, d_cbase, d_gn, d_gbase, p.ctr);
+    hipLaunchKernelGGL(group_fill_kernel, ggrid, dim3(256), 0, s, v.deleted, d_lists, words32, v.count, d_cbase, d_ids);
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipStreamSynchronize(s)); // the host tables (tiles, qgrp) are stack/heap objects of this call
 
