@@ -92,6 +92,8 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
     s.nr_lo = nullptr;
     s.ctl = nullptr;
     s.spec = 0u;
+    s.adj_stage = nullptr;
+    s.adj_cache = nullptr;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
@@ -133,9 +135,10 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
         RegBeam<BS, I8> b;
         QCtr ctr{};
         uint32_t ep = v.entry;
+        EpKnown epk; // the next level's entry point is this level's nearest candidate: its distance is known
         for (int l = v.max_level; l >= 0; l--) {
             const bool insert = l <= L;
-            search_layer<PREC, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, qnorm, ctr);
+            search_layer<PREC, METRIC, 0>(v, s, b, vis, nullptr, ep, l, insert ? bv.efc : 1u, qnorm, ctr, epk);
             if (insert) {
                 const uint32_t task = l == 0 ? bi : bv.nb + bv.up_task[bi] + (uint32_t)(l - 1);
                 uint32_t nc;
@@ -150,6 +153,11 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
                 uint32_t l0, f0;
                 b.get(0, d0, l0, f0);
                 ep = f0 & KDB_ID_MASK;
+                epk.known = true;
+                epk.key = d0;
+                epk.lo = l0;
+            } else {
+                epk.known = false; // (the entry point stays: its distance at this level was computed, but keep it simple)
             }
         }
     }
@@ -670,7 +678,7 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
     const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4;
     const size_t lds_prune = prune_lds_bytes<KT>();
-    const int bs = kdb_beam_slots(efc);
+    const int bs = kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
     auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
     auto kselect = build_select_kernel<METRIC, PREC>;
     auto krev = build_reverse_kernel<METRIC, PREC>;

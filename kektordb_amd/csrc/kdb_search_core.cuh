@@ -44,6 +44,12 @@ struct WaveLds {
     uint32_t *nr_lo;   // [nr_cap] int8
     uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit / speculative hop, [1] query norm bits, [2] node
     uint32_t spec;     // latency mode, few queries: the helper waves fetch ALL neighbours of a level-0 hop beside the visited test
+    // latency mode, level 0: the neighbour list of every row a hop evaluates is fetched BESIDE the row (same id, same round
+    // trip) into adj_stage[j] (j = the row's place in nb_id); wave 0 keeps the lists of the entries that enter the beam in
+    // adj_cache (64 slots, tags in a register, free slots in a scalar mask), so that popping such an entry later needs no
+    // trip to HBM for its list: a hop is ONE dependent round trip (the rows) instead of two.  null = off.
+    uint32_t *adj_stage; // [32][deg0]
+    uint32_t *adj_cache; // [64][deg0]
 };
 constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;
 constexpr uint32_t KDB_COOP_SPEC = 0xfffffffeu;
@@ -79,12 +85,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
-template <int PREC, int METRIC, int NCH = 0>
+// RMAX > 0 caps the rows per 16-lane group and trip (latency mode: a wave's share of a hop is at most 8 rows, and the
+// registers of a third row per group are better spent elsewhere)
+template <int PREC, int METRIC, int NCH = 0, int RMAX = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
     if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 16 && KDB_F32_DUAL) { // 4*R rows per round trip
-        constexpr int R = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : NCH <= 12 ? KDB_F32_ROWS : 2;
+        constexpr int R0 = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : NCH <= 12 ? KDB_F32_ROWS : 2;
+        constexpr int R = (RMAX > 0 && R0 > RMAX) ? RMAX : R0;
         for (uint32_t base = 0; base < n;) {
             const uint32_t left = n - base;
             if (left > 4u * (R - 1) || R == 1) { // wave-uniform: a full-width trip
@@ -281,33 +290,54 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 // search_layer, unchanged); the rows of a hop are split into WIDE contiguous runs, one per wave, so that a hop with 32
 // fresh neighbours is ONE round trip to HBM instead of three.  A row's distance does not depend on which wave or
 // 16-lane group evaluates it (same pieces per lane, same reduction), so results and counters equal the one-wave walk.
-template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave) {
-    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
-    const uint32_t lo = wave * chunk;
-    if (lo >= n) return;
+// rows [lo, lo+cnt) of nb_id (cnt <= 8): their distances, and -- when the hop stages neighbour lists -- their level-0 lists,
+// requested BEFORE the rows so that both travel in the same round trip
+template <int PREC, int METRIC, int NCH>
+__device__ __forceinline__ void dists_and_lists(const KdbView &v, const WaveLds &s, uint32_t lo, uint32_t cnt, float qnorm, bool lists) {
     WaveLds s2 = s;
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
     if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    compute_dists<PREC, METRIC, NCH>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
+    if (!lists) {
+        compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
+        return;
+    }
+    // (the launcher turns the lists on only for deg0 <= 32: a list is P <= 8 pieces of 16 bytes, 8 lists per pass, and a
+    // wave's share of a hop is at most 8 rows)
+    const uint32_t lane = (uint32_t)kdb_lane();
+    const uint32_t P = v.deg0 >> 2;
+    const uint32_t r = lane / P, piece = lane % P;
+    const bool act = r < cnt && r < 8u;
+    uint4 av = make_uint4(0u, 0u, 0u, 0u);
+    if (act) av = reinterpret_cast<const uint4 *>(v.adj0 + (size_t)s2.nb_id[r] * v.deg0)[piece];
+    compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
+    if (act) reinterpret_cast<uint4 *>(s.adj_stage + (size_t)(lo + r) * v.deg0)[piece] = av;
+    wave_lds_fence();
+}
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave, bool lists) {
+    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
+    const uint32_t lo = wave * chunk;
+    if (lo >= n) return;
+    dists_and_lists<PREC, METRIC, NCH>(v, s, lo, n - lo < chunk ? n - lo : chunk, qnorm, lists);
 }
 // wave 0's side (the other waves sit in coop_helper_loop)
+constexpr uint32_t KDB_COOP_LISTS = 0x80000000u; // ctl[0]: row count | this flag = stage the rows' neighbour lists too
 template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
+__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, bool lists = false) {
     if constexpr (WIDE == 1) {
         compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
     } else {
         if (n <= 4u) { // one 16-lane group per row: a single trip anyway
-            compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
+            dists_and_lists<PREC, METRIC, NCH>(v, s, 0u, n, qnorm, lists);
             return;
         }
         if (kdb_lane() == 0) {
-            s.ctl[0] = n;
+            s.ctl[0] = n | (lists ? KDB_COOP_LISTS : 0u);
             s.ctl[1] = __float_as_uint(qnorm);
         }
         __syncthreads(); // rows posted (nb_id, the query) ...
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u, lists);
         __syncthreads(); // ... distances back in nb_d
     }
 }
@@ -331,7 +361,7 @@ __device__ __forceinline__ void coop_spec_share(const KdbView &v, const WaveLds 
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
     if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    compute_dists<PREC, METRIC, NCH>(v, s2, cnt, qnorm);
+    compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
 }
 template <int PREC, int METRIC, int NCH, int WIDE>
 __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
@@ -340,7 +370,7 @@ __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds
         const uint32_t n = uni(s.ctl[0]);
         if (n == KDB_COOP_EXIT) return;
         if (n == KDB_COOP_SPEC) coop_spec_share<PREC, METRIC, NCH, WIDE>(v, s, uni(s.ctl[2]), __uint_as_float(uni(s.ctl[1])), wave);
-        else coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[1])), wave);
+        else coop_share<PREC, METRIC, NCH, WIDE>(v, s, n & ~KDB_COOP_LISTS, __uint_as_float(uni(s.ctl[1])), wave, (n & KDB_COOP_LISTS) != 0u);
         __syncthreads();
     }
 }
@@ -363,6 +393,7 @@ template <int S, bool WK = false>
 struct RegBeam {
     static constexpr uint32_t CAP = 64u * S;
     static constexpr bool kWide = WK;
+    static constexpr int kSlots = S;
     float d[S];
     uint32_t lo[WK ? S : 1];
     uint32_t id[S]; // id | flags
@@ -524,6 +555,7 @@ struct RegBeam {
 template <bool WK = false>
 struct LdsBeamT {
     static constexpr bool kWide = WK;
+    static constexpr int kSlots = 0;
     float *bd;
     uint32_t *bl; // low key words (WK)
     uint32_t *bi;
@@ -898,29 +930,48 @@ struct QCtr {
 #endif
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
+// The entry point's distance, when the caller already has it: the entry point of layer l-1 is the nearest result of layer l
+// (:450-459), whose distance that layer computed -- the same query against the same row gives the same bits, so the
+// evaluation (one dependent round trip to HBM per layer) is skipped and only counted (n_dist is the reference's count).
+struct EpKnown {
+    bool known = false;
+    float key = 0.f;
+    uint32_t lo = 0u;
+};
+
 template <int PREC, int METRIC, int NCH, class BeamT, class VisT, int WIDE = 1>
 __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT &vis,
-                             const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr) {
+                             const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr,
+                             EpKnown epk = EpKnown()) {
     const int lane = kdb_lane();
     b.reset(ef);
     constexpr bool WK = BeamT::kWide; // int8: 64-bit distance keys (the reference orders float64 distances)
     NrListT<WK> nr;
     nr.bind(s);
     vis.begin_layer(level > 0);
+    // neighbour lists kept on chip (latency mode, level 0): tag of slot `lane` / free slots
+    const bool adjc = WIDE > 1 && level == 0 && s.adj_cache != nullptr;
+    uint32_t ctag = 0u;
+    unsigned long long cfree = ~0ull;
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
-    if (lane == 0) s.nb_id[0] = ep;
-    wave_lds_fence();
-    dists<PREC, METRIC, NCH, WIDE>(v, s, 1, qnorm);
+    float ep_key = epk.key;
+    uint32_t ep_lo = epk.lo;
+    if (!epk.known) {
+        if (lane == 0) s.nb_id[0] = ep;
+        wave_lds_fence();
+        dists<PREC, METRIC, NCH, WIDE>(v, s, 1, qnorm);
+        ep_key = unif(s.nb_d[0]);
+        ep_lo = WK ? uni(s.nb_lo[0]) : 0u;
+    }
     ctr.n_dist++;
     {
         (void)vis.test_and_set(ep, lane == 0);
         bool no_result = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
         if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) no_result = true;
-        const uint32_t ep_lo = WK ? uni(s.nb_lo[0]) : 0u;
         if (no_result) {
-            nr.push(unif(s.nb_d[0]), ep_lo, ep, INFINITY, 0u, false);
+            nr.push(ep_key, ep_lo, ep, INFINITY, 0u, false);
         } else {
-            b.insert(unif(s.nb_d[0]), ep_lo, ep);
+            b.insert(ep_key, ep_lo, ep);
             b.n_res++;
             b.trim(ef);
         }
@@ -957,11 +1008,24 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
             b.mark_expanded((uint32_t)idx);
             b.scan_from = (uint32_t)idx + 1;
         }
-        if (level > 0 && (int)v.levels[cur] < level) continue; // :2524-2527 node lacks this level
+        const uint32_t *adj = v.adj0 + (size_t)cur * v.deg0;
+        if (level > 0) { // the node's level and its first upper slot are requested together (one wait, not two dependent ones)
+            const int lv = (int)v.levels[cur];
+            const uint32_t upi = v.up_idx[cur];
+            if (lv < level) continue; // :2524-2527 node lacks this level
+            adj = v.adj_up + ((size_t)upi + (size_t)(level - 1)) * v.deg_up;
+        }
         ctr.n_hops++;
         KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter();)
-        const uint32_t *adj = level == 0 ? v.adj0 + (size_t)cur * v.deg0
-                                         : v.adj_up + ((size_t)v.up_idx[cur] + (size_t)(level - 1)) * v.deg_up;
+        int cslot = -1; // the popped node's list is on chip?
+        if (adjc) {
+            const unsigned long long hit = __ballot(ctag == cur);
+            if (hit) {
+                cslot = (int)__builtin_ctzll(hit);
+                if (lane == cslot) ctag = 0u; // an expanded entry is never popped again: the slot is free
+                cfree |= 1ull << cslot;
+            }
+        }
         bool spec_hop = false;
         if constexpr (WIDE > 1) {
             if (s.spec && level == 0) { // the helper waves start on the rows now (coop_spec_share)
@@ -974,7 +1038,9 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 __syncthreads();
             }
         }
-        uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        uint32_t nb;
+        if (cslot >= 0) nb = (uint32_t)lane < deg ? s.adj_cache[(uint32_t)cslot * v.deg0 + (uint32_t)lane] : 0u;
+        else nb = (uint32_t)lane < deg ? adj[lane] : 0u;
         // visited test-and-set (:2539-2542)
         bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
@@ -1018,7 +1084,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
         KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter();)
-        dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
+        dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, adjc);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
@@ -1026,6 +1092,97 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
         KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); ctr.t_dist += tq2 - tq1;)
+        // One-pass insertion (single-register beam, no deleted nodes): the reference takes the candidates one by one in
+        // stored order against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome
+        // is simply the ef smallest of beam + candidates, so every beam entry counts the candidates below it (its shift),
+        // every candidate the beam entries and candidates below it (its place), one scatter through LDS puts everybody
+        // where he belongs.  Any tie at all -> the sequential path below, which is the definition.
+        if constexpr (BeamT::kSlots == 1 && !WK) {
+            const uint32_t npass = (uint32_t)__builtin_popcountll(pass);
+            if (npass >= 2u && !v.has_deleted) {
+                const uint32_t m = b.count;
+                const bool in_beam = (uint32_t)lane < m;
+                const bool in_pass = ((pass >> lane) & 1ull) != 0ull;
+                const float bd = b.d[0];
+                uint32_t shift = 0u, place = 0u;
+                bool tie = false;
+                for (unsigned long long rest = pass; rest;) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    const float cd = readlane_f(my_d, j);
+                    shift += (in_beam && cd < bd) ? 1u : 0u;
+                    const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(in_beam && bd < cd));
+                    tie = tie || (in_beam && bd == cd) || (in_pass && (uint32_t)lane != j && cd == my_d);
+                    place += (in_pass && cd < my_d) ? 1u : 0u;
+                    if ((uint32_t)lane == j) place += below;
+                }
+                if (__ballot(tie) == 0ull) {
+                    const uint32_t total = m + npass;
+                    const uint32_t ncount = total < ef ? total : ef;
+                    const uint32_t b_to = (uint32_t)lane + shift;
+                    const bool b_keep = in_beam && b_to < ef, c_keep = in_pass && place < ef;
+                    if (adjc) {
+                        // entries pushed out give their list slots back (those that still hold one) ...
+                        for (unsigned long long out = __ballot(in_beam && !b_keep && !(b.id[0] & KDB_F_EXPANDED)); out;) {
+                            const uint32_t l = (uint32_t)__builtin_ctzll(out);
+                            out &= out - 1ull;
+                            const unsigned long long hit = __ballot(ctag == (readlane_u(b.id[0], l) & KDB_ID_MASK));
+                            if (hit) {
+                                if (lane == (int)__builtin_ctzll(hit)) ctag = 0u;
+                                cfree |= hit & (~hit + 1ull);
+                            }
+                        }
+                        // ... and the newcomers' lists (staged beside their rows) move into free slots
+                        const uint32_t P = v.deg0 >> 2;
+                        for (unsigned long long in = __ballot(c_keep); in && cfree;) {
+                            const uint32_t j = (uint32_t)__builtin_ctzll(in);
+                            in &= in - 1ull;
+                            const uint32_t sl = (uint32_t)__builtin_ctzll(cfree);
+                            cfree &= cfree - 1ull;
+                            const uint32_t idj = readlane_u(my_id, j);
+                            if ((uint32_t)lane == sl) ctag = idj;
+                            if ((uint32_t)lane < P)
+                                reinterpret_cast<uint4 *>(s.adj_cache + (size_t)sl * v.deg0)[lane] = reinterpret_cast<const uint4 *>(s.adj_stage + (size_t)j * v.deg0)[lane];
+                        }
+                    }
+                    // scatter (nb_d / nb_id are free: this hop's values live in registers), gather
+                    wave_lds_fence();
+                    if (b_keep) {
+                        s.nb_d[b_to] = bd;
+                        s.nb_id[b_to] = b.id[0];
+                    }
+                    if (c_keep) {
+                        s.nb_d[place] = my_d;
+                        s.nb_id[place] = my_id;
+                    }
+                    wave_lds_fence();
+                    const bool live = (uint32_t)lane < ncount;
+                    b.d[0] = live ? s.nb_d[lane] : INFINITY;
+                    b.id[0] = live ? s.nb_id[lane] : 0u;
+                    wave_lds_fence();
+                    // the nearest newcomer: the pop scan restarts there if it lies before the scan position
+                    const unsigned long long newc = __ballot(c_keep);
+                    uint32_t lowest = 0xffffffffu;
+                    for (unsigned long long r2 = newc; r2;) { // few bits; the lowest place among the newcomers
+                        const uint32_t j = (uint32_t)__builtin_ctzll(r2);
+                        r2 &= r2 - 1ull;
+                        const uint32_t pj = readlane_u(place, j);
+                        lowest = pj < lowest ? pj : lowest;
+                    }
+                    if (lowest < b.scan_from) b.scan_from = lowest;
+                    b.count = ncount;
+                    b.n_res = ncount;
+                    if (ncount >= ef) {
+                        b.worst = readlane_f(b.d[0], ncount - 1u);
+                    } else {
+                        b.worst = INFINITY;
+                    }
+                    b.worst_lo = 0u;
+                    KDB_T(ctr.n_ins += npass;)
+                    pass = 0ull;
+                }
+            }
+        }
         while (pass) { // sequential, in stored order (:2577-2590)
             const uint32_t j = (uint32_t)__builtin_ctzll(pass);
             pass &= pass - 1;
@@ -1039,10 +1196,31 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
                 // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
                 // (ef <= 64 stays inside one register slot: ef=64 ran 10 % slower than ef=60 before)
-                if (b.n_res >= ef) b.drop_last();
+                if (b.n_res >= ef) {
+                    if (adjc) { // the entry that leaves gives its list slot back (if it still holds one: not expanded yet)
+                        float ed;
+                        uint32_t el, ef_;
+                        b.get(b.count - 1u, ed, el, ef_);
+                        const unsigned long long hit = __ballot(ctag == (ef_ & KDB_ID_MASK));
+                        if (hit) {
+                            if (lane == (int)__builtin_ctzll(hit)) ctag = 0u;
+                            cfree |= hit & (~hit + 1ull);
+                        }
+                    }
+                    b.drop_last();
+                }
                 b.insert(d, dlo, id);
                 b.n_res++;
                 b.trim(ef);
+                if (adjc && cfree) { // keep the newcomer's neighbour list (staged beside its row) for the hop that pops it
+                    const uint32_t sl = (uint32_t)__builtin_ctzll(cfree);
+                    cfree &= cfree - 1ull;
+                    if ((uint32_t)lane == sl) ctag = id;
+                    const uint32_t P = v.deg0 >> 2;
+                    if ((uint32_t)lane < P)
+                        reinterpret_cast<uint4 *>(s.adj_cache + (size_t)sl * v.deg0)[lane] = reinterpret_cast<const uint4 *>(s.adj_stage + (size_t)j * v.deg0)[lane];
+                    wave_lds_fence();
+                }
                 KDB_T(ctr.n_ins++;)
             }
         }
@@ -1062,6 +1240,7 @@ __host__ __device__ inline uint32_t kdb_vis_hash_size(uint32_t ef) {
 // beam slots needed for ef (the beam never holds more than ef entries); 0 = use the LDS beam
 __host__ __device__ inline int kdb_beam_slots(uint32_t ef) {
     const uint32_t need = ef;
+    if (need <= 64) return 1; // one entry per lane: every beam operation stays inside one register
     if (need <= 128) return 2;
     if (need <= 256) return 4;
     if (need <= 384) return 6;

@@ -80,6 +80,15 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.ctl = reinterpret_cast<uint32_t *>(smem + off);
     if (WIDE > 1) off += 16;
     s.spec = (WIDE > 1 && (raw & 8u)) ? 1u : 0u;
+    // raw & 16 (latency mode, mMax0 <= 32): neighbour lists staged beside the rows + the 64-slot on-chip list cache
+    s.adj_stage = nullptr;
+    s.adj_cache = nullptr;
+    if (WIDE > 1 && (raw & 16u)) {
+        s.adj_stage = reinterpret_cast<uint32_t *>(smem + off);
+        off += (size_t)32 * v.deg0 * 4;
+        s.adj_cache = reinterpret_cast<uint32_t *>(smem + off);
+        off += (size_t)64 * v.deg0 * 4;
+    }
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
     s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
@@ -186,9 +195,10 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             }
         }
         bool failed = ep == 0u;
+        EpKnown epk; // the next layer's entry point is this layer's nearest result: its distance is known
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
-            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr, epk);
             const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
@@ -196,11 +206,14 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
                 uint32_t bl_, bf_;
                 b.get((uint32_t)best, bd_, bl_, bf_);
                 ep = bf_ & KDB_ID_MASK;
+                epk.known = true;
+                epk.key = bd_;
+                epk.lo = bl_;
             }
         }
         uint32_t nout = 0;
         if (!failed) {
-            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr);
+            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr, epk);
             // results, ascending (:2596-2610), first k
             // raw & 4 (int8 indexes): out_dist is a double array -- the reference's float64 distances, not their float rounding
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
@@ -261,6 +274,8 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.nr_lo = nullptr;
     s.ctl = nullptr;
     s.spec = 0u;
+    s.adj_stage = nullptr;
+    s.adj_cache = nullptr;
     const int lane = kdb_lane();
     const uint32_t chunks = (C + 31) / 32;
     const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -563,15 +578,16 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * (WK ? 12 : 8) : 0) + 64 * (WK ? 12 : 8) + (size_t)nr_cap * (WK ? 12 : 8);
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
-    const uint32_t hsize = (BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
+    const uint32_t hsize = (BS == 1 || BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
     const size_t lds1 = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
     if (lds1 + 16 > 160 * 1024) {
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds1);
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t ncu = (uint32_t)idx->n_cu;
+    const size_t lds_lists = (size_t)(32 + 64) * v.deg0 * 4; // staged + cached neighbour lists (latency mode)
     auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u, uint32_t raw_extra = 0u) -> int {
-        const size_t lds = lds1 + (waves > 1u ? 16u : 0u);
+        const size_t lds = lds1 + (waves > 1u ? 16u : 0u) + ((raw_extra & 16u) ? lds_lists : 0u);
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
@@ -587,7 +603,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
     };
-    if constexpr (BS == 2) {
+    if constexpr (BS == 1 || BS == 2) {
         // latency mode: a batch that leaves most of the chip idle gives every query four waves (one HBM round trip per
         // hop instead of three); same walk, same results, same counters
         // (as long as every query gets its own resident workgroup: 512 at 768-d float32; measured 1M x 768, ef=60, one box:
@@ -595,7 +611,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
             auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
-            const size_t wlds = lds1 + 16;
+            const size_t wlds = lds1 + 16 + lds_lists;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
             // 16..256 queries: the helper waves fetch every neighbour's row beside the visited test (coop_spec_share; measured
@@ -603,10 +619,14 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
             // 0.591 ms; a single short walk loses 13 %, 384+ queries run into the HBM bandwidth the extra rows cost)
             static const uint32_t spec_max = [] { const char *e = getenv("KDB_WIDE_SPEC_MAX_B"); return e ? (uint32_t)atoi(e) : 256u; }();
             static const uint32_t spec_min = [] { const char *e = getenv("KDB_WIDE_SPEC_MIN_B"); return e ? (uint32_t)atoi(e) : 16u; }();
-            if (B <= wide_max) return launch(wk, hsize, 4u, (B >= spec_min && B <= spec_max) ? 8u : 0u);
+            // neighbour lists fetched beside the rows and kept on chip for the entries that enter the beam (round 3): a hop
+            // is one dependent round trip instead of two; with it the speculative row fetch has nothing left to hide
+            const char *lc = getenv("KDB_WIDE_LISTS"); // measurement knob: 0 = off
+            const bool lists = v.deg0 <= 32u && (v.deg0 & 3u) == 0u && !(lc && atoi(lc) == 0);
+            if (B <= wide_max) return launch(wk, hsize, 4u, lists ? 16u : ((B >= spec_min && B <= spec_max) ? 8u : 0u));
         }
     }
-    if constexpr (BS == 2 || BS == 4) {
+    if constexpr (BS == 1 || BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
     }
     return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 0>, 0u);
@@ -619,7 +639,8 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef;
 #define KDB_A idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, ma, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
-    switch (kdb_beam_slots(eff)) { // beam in registers (2/4/6 slots of 64 entries) or in LDS
+    switch (kdb_beam_slots(eff)) { // beam in registers (1/2/4/6 slots of 64 entries) or in LDS
+    case 1: return launch_search_bs<PREC, METRIC, NCH, 1>(KDB_A);
     case 2: return launch_search_bs<PREC, METRIC, NCH, 2>(KDB_A);
     case 4: return launch_search_bs<PREC, METRIC, NCH, 4>(KDB_A);
     case 6: return launch_search_bs<PREC, METRIC, NCH, 6>(KDB_A);

@@ -63,9 +63,9 @@ def main():
             idx.flat_scan_groups_dev(Qs, k, offs, d_lists, *out, max_total_allowed=total)
         idx.sync()
         wall = (time.perf_counter() - t0) / reps
-        st = idx.launch_stats(reps)
-        kms = float(np.mean([c["kernel_ms"] for c in st]))
-        exact_q, rescue_q = st[-1]["n_hops"] & 0xffffffff, st[-1]["n_hops"] >> 32
+        ls = idx.launch_stats(reps)
+        kms = float(np.mean([c["kernel_ms"] for c in ls]))
+        exact_q, rescue_q = ls[-1]["n_hops"] & 0xffffffff, ls[-1]["n_hops"] >> 32
         sig = hashlib.sha1(out[0].cpu().numpy().tobytes() + out[1].cpu().numpy().tobytes()).hexdigest()[:12]
         print(f"stripes {st:>4}: wall {wall * 1e3:7.3f} ms ({B / wall / 1e3:6.1f} k QPS)  ranking kernel {kms:7.3f} ms = "
               f"{gbytes / kms:6.2f} TB/s   exact-pass queries {exact_q}, rescued {rescue_q}   answers {sig}", flush=True)
