@@ -91,14 +91,13 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
-    s.spec = 0u;
-    s.adj_stage = nullptr;
-    s.adj_cache = nullptr;
     (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
     off += 64 * 4;
+    s.ins_d = s.nb_d;
+    s.ins_id = s.nb_id;
     s.nb_lo = I8 ? reinterpret_cast<uint32_t *>(smem + off) : nullptr; // int8: low words of the 64-bit distance keys
     if (I8) off += 64 * 4;
     s.marks = reinterpret_cast<uint32_t *>(smem + off);

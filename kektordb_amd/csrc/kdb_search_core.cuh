@@ -42,17 +42,15 @@ struct WaveLds {
     uint32_t *nb_lo;   // [64]   int8 only: low word of the 64-bit distance key (kdb_i8_key)
     uint32_t *beam_lo; // [cap]  int8 + LdsBeam
     uint32_t *nr_lo;   // [nr_cap] int8
-    uint32_t *ctl;     // [4] latency mode (several waves per query): [0] rows posted / exit / speculative hop, [1] query norm bits, [2] node
-    uint32_t spec;     // latency mode, few queries: the helper waves fetch ALL neighbours of a level-0 hop beside the visited test
-    // latency mode, level 0: the neighbour list of every row a hop evaluates is fetched BESIDE the row (same id, same round
-    // trip) into adj_stage[j] (j = the row's place in nb_id); wave 0 keeps the lists of the entries that enter the beam in
-    // adj_cache (64 slots, tags in a register, free slots in a scalar mask), so that popping such an entry later needs no
-    // trip to HBM for its list: a hop is ONE dependent round trip (the rows) instead of two.  null = off.
-    uint32_t *adj_stage; // [32][deg0]
-    uint32_t *adj_cache; // [64][deg0]
+    uint32_t *ctl;     // [16] latency mode (several waves per query): the command word and what goes with it (KDB_CTL_*)
+    float *ins_d;      // [64] scatter scratch of the one-pass insertion (may alias nb_d when nobody else writes nb_id)
+    uint32_t *ins_id;  // [64]
 };
-constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;
-constexpr uint32_t KDB_COOP_SPEC = 0xfffffffeu;
+// ctl[KDB_CTL_CMD]: a row count n (every wave evaluates its share of nb_id[0..n)), or one of
+constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;  // the batch is done
+constexpr uint32_t KDB_COOP_VISIT = 0xfffffffeu; // wave 1 fetches node ctl[NODE]'s level-0 list and tests it against the visited set
+enum { KDB_CTL_CMD = 0, KDB_CTL_QNORM = 1, KDB_CTL_NODE = 2, KDB_CTL_N = 3, KDB_CTL_VIS_N = 4, KDB_CTL_VIS_BITS = 5,
+       KDB_CTL_ALLOW_LO = 6, KDB_CTL_ALLOW_HI = 7 };
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
 // told they are uniform
@@ -286,91 +284,84 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     wave_lds_fence();
 }
 
-// Latency mode: WIDE waves share one query.  Wave 0 walks the graph (beam, visited set, insertion order: the walk of
-// search_layer, unchanged); the rows of a hop are split into WIDE contiguous runs, one per wave, so that a hop with 32
-// fresh neighbours is ONE round trip to HBM instead of three.  A row's distance does not depend on which wave or
-// 16-lane group evaluates it (same pieces per lane, same reduction), so results and counters equal the one-wave walk.
-// rows [lo, lo+cnt) of nb_id (cnt <= 8): their distances, and -- when the hop stages neighbour lists -- their level-0 lists,
-// requested BEFORE the rows so that both travel in the same round trip
-template <int PREC, int METRIC, int NCH>
-__device__ __forceinline__ void dists_and_lists(const KdbView &v, const WaveLds &s, uint32_t lo, uint32_t cnt, float qnorm, bool lists) {
+// Latency mode: WIDE waves share one query.  Wave 0 walks the graph (beam, insertion order: the walk of search_layer,
+// unchanged); the rows of a hop are split into WIDE contiguous runs, one per wave, so that a hop with 32 fresh neighbours
+// is ONE round trip to HBM instead of three.  A row's distance does not depend on which wave or 16-lane group evaluates it
+// (same pieces per lane, same reduction), so results and counters equal the one-wave walk.
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave) {
+    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
+    const uint32_t lo = wave * chunk;
+    if (lo >= n) return;
     WaveLds s2 = s;
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
     if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    if (!lists) {
-        compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
-        return;
-    }
-    // (the launcher turns the lists on only for deg0 <= 32: a list is P <= 8 pieces of 16 bytes, 8 lists per pass, and a
-    // wave's share of a hop is at most 8 rows)
-    const uint32_t lane = (uint32_t)kdb_lane();
-    const uint32_t P = v.deg0 >> 2;
-    const uint32_t r = lane / P, piece = lane % P;
-    const bool act = r < cnt && r < 8u;
-    uint4 av = make_uint4(0u, 0u, 0u, 0u);
-    if (act) av = reinterpret_cast<const uint4 *>(v.adj0 + (size_t)s2.nb_id[r] * v.deg0)[piece];
-    compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
-    if (act) reinterpret_cast<uint4 *>(s.adj_stage + (size_t)(lo + r) * v.deg0)[piece] = av;
-    wave_lds_fence();
-}
-template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave, bool lists) {
-    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
-    const uint32_t lo = wave * chunk;
-    if (lo >= n) return;
-    dists_and_lists<PREC, METRIC, NCH>(v, s, lo, n - lo < chunk ? n - lo : chunk, qnorm, lists);
+    compute_dists<PREC, METRIC, NCH, 2>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
 }
 // wave 0's side (the other waves sit in coop_helper_loop)
-constexpr uint32_t KDB_COOP_LISTS = 0x80000000u; // ctl[0]: row count | this flag = stage the rows' neighbour lists too
 template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, bool lists = false) {
+__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     if constexpr (WIDE == 1) {
         compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
     } else {
         if (n <= 4u) { // one 16-lane group per row: a single trip anyway
-            dists_and_lists<PREC, METRIC, NCH>(v, s, 0u, n, qnorm, lists);
+            compute_dists<PREC, METRIC, NCH, 2>(v, s, n, qnorm);
             return;
         }
         if (kdb_lane() == 0) {
-            s.ctl[0] = n | (lists ? KDB_COOP_LISTS : 0u);
-            s.ctl[1] = __float_as_uint(qnorm);
+            s.ctl[KDB_CTL_CMD] = n;
+            s.ctl[KDB_CTL_QNORM] = __float_as_uint(qnorm);
         }
         __syncthreads(); // rows posted (nb_id, the query) ...
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u, lists);
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
         __syncthreads(); // ... distances back in nb_d
     }
 }
-// Speculative hop (few queries in flight, level 0): while wave 0 fetches node `cur`'s neighbour list and tests it against
-// the visited set, the helper waves fetch the same list and evaluate ALL its rows -- helper h (1..WIDE-1) the slots
-// [(h-1)*c, h*c), c = ceil(deg0 / (WIDE-1)) -- into nb_d[slot].  Rows that turn out to be visited already are read for
-// nothing (4x the row bytes of the hop: affordable only while the batch leaves HBM idle), but the row round trip no longer
-// waits for the visited test and the compaction; wave 0 then inserts the fresh slots in stored order, as before.
-template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void coop_spec_share(const KdbView &v, const WaveLds &s, uint32_t cur, float qnorm, uint32_t wave) {
-    const uint32_t lane = (uint32_t)kdb_lane();
-    const uint32_t chunk = (v.deg0 + (uint32_t)WIDE - 2u) / ((uint32_t)WIDE - 1u);
-    const uint32_t lo = (wave - 1u) * chunk;
-    if (lo >= v.deg0) return;
-    const uint32_t cnt = v.deg0 - lo < chunk ? v.deg0 - lo : chunk;
-    uint32_t nb = lane < cnt ? v.adj0[(size_t)cur * v.deg0 + lo + lane] : 0u;
-    if (nb > v.count) nb = 0u; // row 0 is all zero
-    if (lane < cnt) s.nb_id[lo + lane] = nb;
-    wave_lds_fence();
-    WaveLds s2 = s;
-    s2.nb_id = s.nb_id + lo;
-    s2.nb_d = s.nb_d + lo;
-    if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    compute_dists<PREC, METRIC, NCH, 2>(v, s2, cnt, qnorm);
+// Pipelined hop (round 3; level 0, index without deleted nodes).  Measured per level-0 hop of a four-wave walk, 1M x 768,
+// ef=60 (make dbgs): pop 420 cycles, neighbour list 375, visited test 600, rows 1550, insertions 930 -- a chain of
+// dependent work in ONE wave of which only the rows touch HBM.  As soon as a hop's distances are back wave 0 knows which
+// node it will pop next -- the nearer of the first un-expanded beam entry and the nearest candidate about to enter (exact
+// unless distances tie, and then it simply does not use this path) -- and posts it; while wave 0 inserts the hop's
+// candidates, wave 1 fetches that node's list, runs the visited test-and-set (the hash set lives in LDS: any wave of the
+// workgroup can work on it, and only one does at a time) and the allow-list test, and leaves the fresh ids in nb_id.  The
+// two meet at a barrier, and every wave goes straight to the rows.  Same walk, same visited marks, same counters.
+template <class VisT>
+__device__ __forceinline__ void coop_visit(const KdbView &v, const WaveLds &s, VisT vis) {
+    if constexpr (VisT::kHash) {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        const uint32_t node = uni(s.ctl[KDB_CTL_NODE]);
+        vis.n = uni(s.ctl[KDB_CTL_VIS_N]);
+        vis.in_bits = uni(s.ctl[KDB_CTL_VIS_BITS]) != 0u;
+        vis.bs.record = false;
+        vis.bs.n_marks = 0;
+        const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_CTL_ALLOW_HI]) << 32) | uni(s.ctl[KDB_CTL_ALLOW_LO]));
+        const uint32_t nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
+        bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count); // :2539-2542
+        if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
+        const unsigned long long m = __ballot(fresh);
+        if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+        if (lane == 0) {
+            s.ctl[KDB_CTL_N] = (uint32_t)__builtin_popcountll(m);
+            s.ctl[KDB_CTL_VIS_N] = vis.n;
+            s.ctl[KDB_CTL_VIS_BITS] = vis.in_bits ? 1u : 0u;
+        }
+    }
 }
-template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
+template <int PREC, int METRIC, int NCH, int WIDE, class VisT>
+__device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave, const VisT &vis) {
     for (;;) {
         __syncthreads();
-        const uint32_t n = uni(s.ctl[0]);
-        if (n == KDB_COOP_EXIT) return;
-        if (n == KDB_COOP_SPEC) coop_spec_share<PREC, METRIC, NCH, WIDE>(v, s, uni(s.ctl[2]), __uint_as_float(uni(s.ctl[1])), wave);
-        else coop_share<PREC, METRIC, NCH, WIDE>(v, s, n & ~KDB_COOP_LISTS, __uint_as_float(uni(s.ctl[1])), wave, (n & KDB_COOP_LISTS) != 0u);
+        const uint32_t cmd = uni(s.ctl[KDB_CTL_CMD]);
+        if (cmd == KDB_COOP_EXIT) return;
+        uint32_t n = cmd;
+        if (cmd == KDB_COOP_VISIT) {
+            if (wave == 1u) coop_visit(v, s, vis);
+            __syncthreads(); // the list is tested (wave 1), the previous hop's candidates are inserted (wave 0)
+            n = uni(s.ctl[KDB_CTL_N]);
+            if (n == 0u) continue;
+        }
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[KDB_CTL_QNORM])), wave);
         __syncthreads();
     }
 }
@@ -920,7 +911,7 @@ struct QCtr {
     uint32_t n_dist, n_hops, n_dropped;
 #ifdef KDB_SEARCH_TIMERS // measurement build (make dbgs): where a walk's time goes
     uint32_t n_ins;
-    unsigned long long t_adj, t_dist, t_ins;
+    unsigned long long t_adj, t_dist, t_ins, t_pop, t_vis, t_upper;
 #endif
 };
 #ifdef KDB_SEARCH_TIMERS
@@ -949,10 +940,6 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
     NrListT<WK> nr;
     nr.bind(s);
     vis.begin_layer(level > 0);
-    // neighbour lists kept on chip (latency mode, level 0): tag of slot `lane` / free slots
-    const bool adjc = WIDE > 1 && level == 0 && s.adj_cache != nullptr;
-    uint32_t ctag = 0u;
-    unsigned long long cfree = ~0ull;
     // entry point (:2461-2489): always scored, always a candidate, a result only if allowed and live
     float ep_key = epk.key;
     uint32_t ep_lo = epk.lo;
@@ -977,7 +964,14 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
+    // pipelined hops (see coop_visit): wave 1 prepares the next node while wave 0 inserts
+    constexpr bool kPipe = WIDE > 1 && VisT::kHash && !WK;
+    const bool pipe = kPipe && level == 0 && !v.has_deleted && s.ctl != nullptr;
+    bool pre = false;       // the node about to be popped has been prepared: nb_id[0..pre_n) holds its fresh neighbours
+    uint32_t pre_node = 0u, pre_n = 0u;
+    KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
     for (;;) {
+        KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
         // heap_pop(candidates): the nearest un-expanded beam entry or the nearest traversal-only candidate
         const int idx = b.next();
         float cur_d = INFINITY;
@@ -1016,82 +1010,90 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
             adj = v.adj_up + ((size_t)upi + (size_t)(level - 1)) * v.deg_up;
         }
         ctr.n_hops++;
-        KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter();)
-        int cslot = -1; // the popped node's list is on chip?
-        if (adjc) {
-            const unsigned long long hit = __ballot(ctag == cur);
-            if (hit) {
-                cslot = (int)__builtin_ctzll(hit);
-                if (lane == cslot) ctag = 0u; // an expanded entry is never popped again: the slot is free
-                cfree |= 1ull << cslot;
-            }
+        KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter(); if (level == 0) ctr.t_pop += tq0 - tq_a;)
+        uint32_t n;
+        const bool prepared = kPipe && pre; // (the prediction is exact: pre_node == cur)
+        if (prepared) {
+            n = pre_n;
+            pre = false;
+            (void)pre_node;
+        } else {
+            const uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+            KDB_T(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tq_v = __builtin_readcyclecounter();)
+            // visited test-and-set (:2539-2542)
+            bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
+            if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
+            const unsigned long long m = __ballot(fresh);
+            n = (uint32_t)__builtin_popcountll(m);
+            KDB_T(if (level == 0) { ctr.t_adj += tq_v - tq0; ctr.t_vis += __builtin_readcyclecounter() - tq_v; })
+            if (n == 0) continue;
+            if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+            wave_lds_fence();
         }
-        bool spec_hop = false;
-        if constexpr (WIDE > 1) {
-            if (s.spec && level == 0) { // the helper waves start on the rows now (coop_spec_share)
-                spec_hop = true;
-                if (lane == 0) {
-                    s.ctl[0] = KDB_COOP_SPEC;
-                    s.ctl[1] = __float_as_uint(qnorm);
-                    s.ctl[2] = cur;
-                }
-                __syncthreads();
-            }
-        }
-        uint32_t nb;
-        if (cslot >= 0) nb = (uint32_t)lane < deg ? s.adj_cache[(uint32_t)cslot * v.deg0 + (uint32_t)lane] : 0u;
-        else nb = (uint32_t)lane < deg ? adj[lane] : 0u;
-        // visited test-and-set (:2539-2542)
-        bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
-        if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
-        const unsigned long long m = __ballot(fresh);
-        const uint32_t n = (uint32_t)__builtin_popcountll(m);
-        KDB_T(ctr.t_adj += __builtin_readcyclecounter() - tq0;)
-        if constexpr (WIDE > 1) {
-            if (spec_hop) { // distances of ALL slots are on their way: nb_d[slot]; the fresh ones are inserted in stored order
-                const uint32_t delw_s = (fresh && v.has_deleted) ? v.deleted[nb >> 5] : 0u;
-                __syncthreads();
-                if (n == 0) continue;
-                ctr.n_dist += n;
-                const bool nr_s = ((delw_s >> (nb & 31)) & 1u) != 0;
-                const float d_s = fresh ? s.nb_d[lane] : INFINITY;
-                const uint32_t lo_s = (WK && fresh) ? s.nb_lo[lane] : 0u;
-                unsigned long long pass = __ballot(fresh && (b.n_res < ef || key_lt<WK>(d_s, lo_s, b.worst, b.worst_lo)));
-                while (pass) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(pass);
-                    pass &= pass - 1;
-                    const float d = readlane_f(d_s, j);
-                    const uint32_t dlo = WK ? readlane_u(lo_s, j) : 0u;
-                    if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
-                    const uint32_t id = readlane_u(nb, j);
-                    if (readlane_u((uint32_t)nr_s, j) != 0) {
-                        nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
-                    } else {
-                        if (b.n_res >= ef) b.drop_last();
-                        b.insert(d, dlo, id);
-                        b.n_res++;
-                        b.trim(ef);
-                    }
-                }
-                continue;
-            }
-        }
-        if (n == 0) continue;
-        if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
-        wave_lds_fence();
+        if (n == 0) continue; // (a prepared node without fresh neighbours: the helper waves skipped the rows too)
         // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather;
         // skipped when the index holds no deleted node
         uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
         KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter();)
-        dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, adjc);
+        if constexpr (kPipe) {
+            if (prepared) { // every wave has read n behind the barrier that ended the preparation: straight to the rows
+                coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
+                __syncthreads();
+            } else {
+                dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
+            }
+        } else {
+            dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
+        }
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
-        KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); ctr.t_dist += tq2 - tq1;)
+        KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); if (level == 0) ctr.t_dist += tq2 - tq1;)
+        bool posted = false;
+        if constexpr (kPipe) {
+            if (pipe && nr.count == 0u) {
+                // The next pop, known before the insertion: the first un-expanded entry of the beam as it is, or the nearest
+                // candidate that is about to enter it.  (The nearest passing candidate always enters: fewer than ef entries
+                // are nearer than the worst it beat.  An entry the candidates push out is farther than one of them.)  Equal
+                // distances in play -> no prediction, this hop takes the plain path.
+                const int i2 = b.next();
+                float od = INFINITY;
+                uint32_t olo, oidf = 0u;
+                if (i2 >= 0) b.get((uint32_t)i2, od, olo, oidf);
+                float cm = pass >> lane & 1ull ? my_d : INFINITY; // the nearest passing candidate: row minimum, then across rows
+                cm = fminf(cm, kdb_row_ror<8>(cm));
+                cm = fminf(cm, kdb_row_ror<4>(cm));
+                cm = fminf(cm, kdb_row_ror<2>(cm));
+                cm = fminf(cm, kdb_row_ror<1>(cm));
+                float cmin = fminf(readlane_f(cm, 0), readlane_f(cm, 16));
+                if (v.deg0 > 32u) cmin = fminf(cmin, fminf(readlane_f(cm, 32), readlane_f(cm, 48)));
+                uint32_t nxt = 0u;
+                if (i2 >= 0 && od < cmin) {
+                    nxt = oidf & KDB_ID_MASK;
+                } else if (pass && !(i2 >= 0 && od == cmin)) {
+                    const unsigned long long at = __ballot((pass >> lane & 1ull) && my_d == cmin);
+                    if (__builtin_popcountll(at) == 1) nxt = readlane_u(my_id, (uint32_t)__builtin_ctzll(at));
+                }
+                if (nxt) {
+                    if (lane == 0) {
+                        s.ctl[KDB_CTL_CMD] = KDB_COOP_VISIT;
+                        s.ctl[KDB_CTL_QNORM] = __float_as_uint(qnorm);
+                        s.ctl[KDB_CTL_NODE] = nxt;
+                        s.ctl[KDB_CTL_VIS_N] = vis.n;
+                        s.ctl[KDB_CTL_VIS_BITS] = vis.in_bits ? 1u : 0u;
+                        s.ctl[KDB_CTL_ALLOW_LO] = (uint32_t)(unsigned long long)allow;
+                        s.ctl[KDB_CTL_ALLOW_HI] = (uint32_t)((unsigned long long)allow >> 32);
+                    }
+                    __syncthreads(); // wave 1 starts on nxt (it writes nb_id: this hop's ids and distances are in registers)
+                    posted = true;
+                    pre_node = nxt;
+                }
+            }
+        }
         // One-pass insertion (single-register beam, no deleted nodes): the reference takes the candidates one by one in
         // stored order against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome
         // is simply the ef smallest of beam + candidates, so every beam entry counts the candidates below it (its shift),
@@ -1121,49 +1123,23 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                     const uint32_t ncount = total < ef ? total : ef;
                     const uint32_t b_to = (uint32_t)lane + shift;
                     const bool b_keep = in_beam && b_to < ef, c_keep = in_pass && place < ef;
-                    if (adjc) {
-                        // entries pushed out give their list slots back (those that still hold one) ...
-                        for (unsigned long long out = __ballot(in_beam && !b_keep && !(b.id[0] & KDB_F_EXPANDED)); out;) {
-                            const uint32_t l = (uint32_t)__builtin_ctzll(out);
-                            out &= out - 1ull;
-                            const unsigned long long hit = __ballot(ctag == (readlane_u(b.id[0], l) & KDB_ID_MASK));
-                            if (hit) {
-                                if (lane == (int)__builtin_ctzll(hit)) ctag = 0u;
-                                cfree |= hit & (~hit + 1ull);
-                            }
-                        }
-                        // ... and the newcomers' lists (staged beside their rows) move into free slots
-                        const uint32_t P = v.deg0 >> 2;
-                        for (unsigned long long in = __ballot(c_keep); in && cfree;) {
-                            const uint32_t j = (uint32_t)__builtin_ctzll(in);
-                            in &= in - 1ull;
-                            const uint32_t sl = (uint32_t)__builtin_ctzll(cfree);
-                            cfree &= cfree - 1ull;
-                            const uint32_t idj = readlane_u(my_id, j);
-                            if ((uint32_t)lane == sl) ctag = idj;
-                            if ((uint32_t)lane < P)
-                                reinterpret_cast<uint4 *>(s.adj_cache + (size_t)sl * v.deg0)[lane] = reinterpret_cast<const uint4 *>(s.adj_stage + (size_t)j * v.deg0)[lane];
-                        }
-                    }
-                    // scatter (nb_d / nb_id are free: this hop's values live in registers), gather
                     wave_lds_fence();
                     if (b_keep) {
-                        s.nb_d[b_to] = bd;
-                        s.nb_id[b_to] = b.id[0];
+                        s.ins_d[b_to] = bd;
+                        s.ins_id[b_to] = b.id[0];
                     }
                     if (c_keep) {
-                        s.nb_d[place] = my_d;
-                        s.nb_id[place] = my_id;
+                        s.ins_d[place] = my_d;
+                        s.ins_id[place] = my_id;
                     }
                     wave_lds_fence();
                     const bool live = (uint32_t)lane < ncount;
-                    b.d[0] = live ? s.nb_d[lane] : INFINITY;
-                    b.id[0] = live ? s.nb_id[lane] : 0u;
+                    b.d[0] = live ? s.ins_d[lane] : INFINITY;
+                    b.id[0] = live ? s.ins_id[lane] : 0u;
                     wave_lds_fence();
-                    // the nearest newcomer: the pop scan restarts there if it lies before the scan position
-                    const unsigned long long newc = __ballot(c_keep);
+                    // the pop scan restarts at the nearest newcomer if that lies before the scan position
                     uint32_t lowest = 0xffffffffu;
-                    for (unsigned long long r2 = newc; r2;) { // few bits; the lowest place among the newcomers
+                    for (unsigned long long r2 = __ballot(c_keep); r2;) { // (few bits)
                         const uint32_t j = (uint32_t)__builtin_ctzll(r2);
                         r2 &= r2 - 1ull;
                         const uint32_t pj = readlane_u(place, j);
@@ -1172,11 +1148,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                     if (lowest < b.scan_from) b.scan_from = lowest;
                     b.count = ncount;
                     b.n_res = ncount;
-                    if (ncount >= ef) {
-                        b.worst = readlane_f(b.d[0], ncount - 1u);
-                    } else {
-                        b.worst = INFINITY;
-                    }
+                    b.worst = ncount >= ef ? readlane_f(b.d[0], ncount - 1u) : INFINITY;
                     b.worst_lo = 0u;
                     KDB_T(ctr.n_ins += npass;)
                     pass = 0ull;
@@ -1195,37 +1167,25 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
             } else {
                 // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
                 // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
-                // (ef <= 64 stays inside one register slot: ef=64 ran 10 % slower than ef=60 before)
-                if (b.n_res >= ef) {
-                    if (adjc) { // the entry that leaves gives its list slot back (if it still holds one: not expanded yet)
-                        float ed;
-                        uint32_t el, ef_;
-                        b.get(b.count - 1u, ed, el, ef_);
-                        const unsigned long long hit = __ballot(ctag == (ef_ & KDB_ID_MASK));
-                        if (hit) {
-                            if (lane == (int)__builtin_ctzll(hit)) ctag = 0u;
-                            cfree |= hit & (~hit + 1ull);
-                        }
-                    }
-                    b.drop_last();
-                }
+                if (b.n_res >= ef) b.drop_last();
                 b.insert(d, dlo, id);
                 b.n_res++;
                 b.trim(ef);
-                if (adjc && cfree) { // keep the newcomer's neighbour list (staged beside its row) for the hop that pops it
-                    const uint32_t sl = (uint32_t)__builtin_ctzll(cfree);
-                    cfree &= cfree - 1ull;
-                    if ((uint32_t)lane == sl) ctag = id;
-                    const uint32_t P = v.deg0 >> 2;
-                    if ((uint32_t)lane < P)
-                        reinterpret_cast<uint4 *>(s.adj_cache + (size_t)sl * v.deg0)[lane] = reinterpret_cast<const uint4 *>(s.adj_stage + (size_t)j * v.deg0)[lane];
-                    wave_lds_fence();
-                }
                 KDB_T(ctr.n_ins++;)
             }
         }
-        KDB_T(ctr.t_ins += __builtin_readcyclecounter() - tq2;)
+        KDB_T(if (level == 0) ctr.t_ins += __builtin_readcyclecounter() - tq2;)
+        if constexpr (kPipe) {
+            if (posted) {
+                __syncthreads(); // wave 1 is done with the next node's list
+                pre = true;
+                pre_n = uni(s.ctl[KDB_CTL_N]);
+                vis.n = uni(s.ctl[KDB_CTL_VIS_N]);
+                vis.in_bits = uni(s.ctl[KDB_CTL_VIS_BITS]) != 0u;
+            }
+        }
     }
+    KDB_T(if (level > 0) ctr.t_upper += __builtin_readcyclecounter() - tq_layer;)
     ctr.n_dropped += nr.dropped;
     vis.end_layer();
 }

@@ -78,16 +78,15 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.nb_lo = PREC == KDB_PREC_I8 ? reinterpret_cast<uint32_t *>(smem + off) : nullptr;
     if (PREC == KDB_PREC_I8) off += 64 * 4;
     s.ctl = reinterpret_cast<uint32_t *>(smem + off);
-    if (WIDE > 1) off += 16;
-    s.spec = (WIDE > 1 && (raw & 8u)) ? 1u : 0u;
-    // raw & 16 (latency mode, mMax0 <= 32): neighbour lists staged beside the rows + the 64-slot on-chip list cache
-    s.adj_stage = nullptr;
-    s.adj_cache = nullptr;
-    if (WIDE > 1 && (raw & 16u)) {
-        s.adj_stage = reinterpret_cast<uint32_t *>(smem + off);
-        off += (size_t)32 * v.deg0 * 4;
-        s.adj_cache = reinterpret_cast<uint32_t *>(smem + off);
-        off += (size_t)64 * v.deg0 * 4;
+    if (WIDE > 1) off += 64;
+    // scatter scratch of the one-pass insertion: its own in latency mode (wave 1 fills nb_id for the next hop meanwhile)
+    s.ins_d = s.nb_d;
+    s.ins_id = s.nb_id;
+    if (WIDE > 1) {
+        s.ins_d = reinterpret_cast<float *>(smem + off);
+        off += 64 * 4;
+        s.ins_id = reinterpret_cast<uint32_t *>(smem + off);
+        off += 64 * 4;
     }
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
@@ -100,15 +99,6 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     s.beam_cap = beam_cap;
 
     const int lane = kdb_lane();
-    if constexpr (WIDE > 1) {
-        if (threadIdx.x >= 64u) { // the walk belongs to wave 0; the others evaluate their share of every hop's rows
-            coop_helper_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6);
-            return;
-        }
-    }
-    unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
-    typename BeamSel<BS, PREC == KDB_PREC_I8>::type b;
-    b.bind(s);
     typename VisSel<VIS>::type vis;
     if constexpr (VIS == 1) {
         vis.tab = s.marks;
@@ -123,6 +113,15 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         vis.words = v.vis_words;
         vis.marks = s.marks;
     }
+    if constexpr (WIDE > 1) {
+        if (threadIdx.x >= 64u) { // the walk belongs to wave 0; the others evaluate their share of every hop's rows, and wave 1
+            coop_helper_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6, vis); // prepares the next node (coop_visit)
+            return;
+        }
+    }
+    unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
+    typename BeamSel<BS, PREC == KDB_PREC_I8>::type b;
+    b.bind(s);
     for (;;) {
         uint32_t qi = 0;
         if (lane == 0) qi = atomicAdd(work, 1u);
@@ -230,14 +229,14 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
             if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
         }
-        KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu adj+visited %llu dists %llu inserts %llu\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_adj, ctr.t_dist, ctr.t_ins);)
+        KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu upper-layers %llu | level 0: pop %llu list %llu visited %llu rows %llu inserts %llu\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_upper, ctr.t_pop, ctr.t_adj, ctr.t_vis, ctr.t_dist, ctr.t_ins);)
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         tot_dropped += ctr.n_dropped;
         wave_lds_fence();
     }
     if constexpr (WIDE > 1) {
-        if (lane == 0) s.ctl[0] = KDB_COOP_EXIT;
+        if (lane == 0) s.ctl[KDB_CTL_CMD] = KDB_COOP_EXIT;
         __syncthreads();
     }
     if (lane == 0 && gctr) {
@@ -273,9 +272,8 @@ distance_tile_kernel(KdbView v, const void *__restrict__ queries, const float *_
     s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
-    s.spec = 0u;
-    s.adj_stage = nullptr;
-    s.adj_cache = nullptr;
+    s.ins_d = s.nb_d;
+    s.ins_id = s.nb_id;
     const int lane = kdb_lane();
     const uint32_t chunks = (C + 31) / 32;
     const uint32_t b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -585,9 +583,8 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t ncu = (uint32_t)idx->n_cu;
-    const size_t lds_lists = (size_t)(32 + 64) * v.deg0 * 4; // staged + cached neighbour lists (latency mode)
-    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u, uint32_t raw_extra = 0u) -> int {
-        const size_t lds = lds1 + (waves > 1u ? 16u : 0u) + ((raw_extra & 16u) ? lds_lists : 0u);
+    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
+        const size_t lds = lds1 + (waves > 1u ? 64u + 512u : 0u);
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
@@ -597,33 +594,24 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
         KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw | raw_extra, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
     };
     if constexpr (BS == 1 || BS == 2) {
-        // latency mode: a batch that leaves most of the chip idle gives every query four waves (one HBM round trip per
-        // hop instead of three); same walk, same results, same counters
-        // (as long as every query gets its own resident workgroup: 512 at 768-d float32; measured 1M x 768, ef=60, one box:
-        // 64 queries 0.554 -> 0.511 ms, 256 queries 0.650 -> 0.611 ms, 512 queries 0.665 -> 0.625 ms)
+        // latency mode: a batch that leaves most of the chip idle gives every query four waves: wave 0 walks, all four
+        // evaluate a hop's rows (one HBM round trip per hop instead of three), wave 1 prepares the next node while wave 0
+        // inserts (coop_visit); same walk, same results, same counters -- as long as every query gets its own resident
+        // workgroup (512 at 768-d float32)
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
             auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
-            const size_t wlds = lds1 + 16 + lds_lists;
+            const size_t wlds = lds1 + 64 + 512;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
-            // 16..256 queries: the helper waves fetch every neighbour's row beside the visited test (coop_spec_share; measured
-            // on one box, 1M x 768, ef=60: 32 / 64 / 128 / 256 queries 0.515 / 0.515 / 0.528 / 0.616 -> 0.471 / 0.476 / 0.493 /
-            // 0.591 ms; a single short walk loses 13 %, 384+ queries run into the HBM bandwidth the extra rows cost)
-            static const uint32_t spec_max = [] { const char *e = getenv("KDB_WIDE_SPEC_MAX_B"); return e ? (uint32_t)atoi(e) : 256u; }();
-            static const uint32_t spec_min = [] { const char *e = getenv("KDB_WIDE_SPEC_MIN_B"); return e ? (uint32_t)atoi(e) : 16u; }();
-            // neighbour lists fetched beside the rows and kept on chip for the entries that enter the beam (round 3): a hop
-            // is one dependent round trip instead of two; with it the speculative row fetch has nothing left to hide
-            const char *lc = getenv("KDB_WIDE_LISTS"); // measurement knob: 0 = off
-            const bool lists = v.deg0 <= 32u && (v.deg0 & 3u) == 0u && !(lc && atoi(lc) == 0);
-            if (B <= wide_max) return launch(wk, hsize, 4u, lists ? 16u : ((B >= spec_min && B <= spec_max) ? 8u : 0u));
+            if (B <= wide_max) return launch(wk, hsize, 4u);
         }
     }
     if constexpr (BS == 1 || BS == 2 || BS == 4) {

@@ -27,7 +27,7 @@ t0 = time.time()
 idx.build(n, batch=16384, ef_construction=200, seed=1)
 print(f"build {time.time() - t0:.1f}s", flush=True)
 Bs = [int(x) for x in os.environ.get("LAT_BS", "1,8,64,256,512,1024,2048,8192").split(",")]
-for lists in os.environ.get("LAT_LISTS", "0,1").split(","):
+for lists in os.environ.get("LAT_LISTS", "1").split(","):
     os.environ["KDB_WIDE_LISTS"] = lists
     sig = hashlib.sha1()
     for B in Bs:
@@ -62,5 +62,5 @@ for lists in os.environ.get("LAT_LISTS", "0,1").split(","):
             idx.sync()
             lat.append((time.perf_counter() - t0) * 1e3)
         print(f"lists={lists} B={B:5d}: kernel {ms:.3f} ms, back-to-back {wall:.3f} ms/call ({B / wall * 1e3:9.0f} QPS), single call "
-              f"{np.median(lat):.3f} ms   hops/q {nh.float().mean().item():.1f} dist/q {nd.float().mean().item():.1f}", flush=True)
+              f"{np.median(lat):.3f} ms   hops/q mean {nh.float().mean().item():.1f} max {nh.max().item()} dist/q mean {nd.float().mean().item():.1f} max {nd.max().item()}", flush=True)
     print(f"lists={lists} answers+counters signature {sig.hexdigest()[:16]}", flush=True)
