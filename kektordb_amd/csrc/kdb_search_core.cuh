@@ -49,8 +49,10 @@ struct WaveLds {
 // ctl[KDB_CTL_CMD]: a row count n (every wave evaluates its share of nb_id[0..n)), or one of
 constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;  // the batch is done
 constexpr uint32_t KDB_COOP_VISIT = 0xfffffffeu; // wave 1 fetches node ctl[NODE]'s level-0 list and tests it against the visited set
+// (two 16-byte groups, each read with one ds_read_b128; NEXT2 on its own)
 enum { KDB_CTL_CMD = 0, KDB_CTL_QNORM = 1, KDB_CTL_NODE = 2, KDB_CTL_N = 3, KDB_CTL_VIS_N = 4, KDB_CTL_VIS_BITS = 5,
-       KDB_CTL_ALLOW_LO = 6, KDB_CTL_ALLOW_HI = 7 };
+       KDB_CTL_ALLOW_LO = 6, KDB_CTL_ALLOW_HI = 7,
+       KDB_CTL_NEXT2 = 8 }; // the beam's first un-expanded entry behind the node being expanded: the likely next VISIT
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
 // told they are uniform
@@ -327,16 +329,18 @@ __device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32
 // workgroup can work on it, and only one does at a time) and the allow-list test, and leaves the fresh ids in nb_id.  The
 // two meet at a barrier, and every wave goes straight to the rows.  Same walk, same visited marks, same counters.
 template <class VisT>
-__device__ __forceinline__ void coop_visit(const KdbView &v, const WaveLds &s, VisT vis) {
+__device__ __forceinline__ void coop_visit(const KdbView &v, const WaveLds &s, VisT vis, uint32_t node, uint32_t pf_node, uint32_t pf_nb) {
     if constexpr (VisT::kHash) {
         const uint32_t lane = (uint32_t)kdb_lane();
-        const uint32_t node = uni(s.ctl[KDB_CTL_NODE]);
-        vis.n = uni(s.ctl[KDB_CTL_VIS_N]);
-        vis.in_bits = uni(s.ctl[KDB_CTL_VIS_BITS]) != 0u;
+        const uint4 c1 = *reinterpret_cast<const uint4 *>(s.ctl + KDB_CTL_VIS_N);
+        vis.n = uni(c1.x);
+        vis.in_bits = uni(c1.y) != 0u;
         vis.bs.record = false;
         vis.bs.n_marks = 0;
-        const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_CTL_ALLOW_HI]) << 32) | uni(s.ctl[KDB_CTL_ALLOW_LO]));
-        const uint32_t nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
+        const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(c1.w) << 32) | uni(c1.z));
+        // the list: already on its way since the rows of the hop before (when the guess was right), else fetched now
+        uint32_t nb = pf_nb;
+        if (node != pf_node) nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
         bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count); // :2539-2542
         if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
         const unsigned long long m = __ballot(fresh);
@@ -350,18 +354,26 @@ __device__ __forceinline__ void coop_visit(const KdbView &v, const WaveLds &s, V
 }
 template <int PREC, int METRIC, int NCH, int WIDE, class VisT>
 __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave, const VisT &vis) {
+    // wave 1: the neighbour list of the node wave 0 will most likely expand next (ctl[NEXT2], posted with every hop), requested
+    // before this wave's share of the hop's rows -- it is in a register by the time the VISIT arrives
+    uint32_t pf_node = 0u, pf_nb = 0u;
     for (;;) {
         __syncthreads();
-        const uint32_t cmd = uni(s.ctl[KDB_CTL_CMD]);
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(s.ctl);
+        const uint32_t cmd = uni(c0.x);
         if (cmd == KDB_COOP_EXIT) return;
         uint32_t n = cmd;
         if (cmd == KDB_COOP_VISIT) {
-            if (wave == 1u) coop_visit(v, s, vis);
+            if (wave == 1u) coop_visit(v, s, vis, uni(c0.z), pf_node, pf_nb);
             __syncthreads(); // the list is tested (wave 1), the previous hop's candidates are inserted (wave 0)
             n = uni(s.ctl[KDB_CTL_N]);
-            if (n == 0u) continue;
         }
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[KDB_CTL_QNORM])), wave);
+        if (VisT::kHash && wave == 1u) {
+            pf_node = uni(s.ctl[KDB_CTL_NEXT2]);
+            pf_nb = (pf_node != 0u && (uint32_t)kdb_lane() < v.deg0) ? v.adj0[(size_t)pf_node * v.deg0 + (uint32_t)kdb_lane()] : 0u;
+        }
+        if (n == 0u) continue;
+        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(c0.y)), wave);
         __syncthreads();
     }
 }
@@ -434,6 +446,23 @@ struct RegBeam {
             if (m) return (int)(64u * s + (uint32_t)__builtin_ctzll(m));
         }
         return -1;
+    }
+    // id of the SECOND un-expanded entry at or behind scan_from (single-slot beams; 0 = none): what the walk pops after the
+    // next pop if nothing nearer turns up -- a prefetch hint, never a decision
+    __device__ __forceinline__ uint32_t second_pending() const {
+        if constexpr (S != 1) return 0u;
+        const uint32_t lane = (uint32_t)kdb_lane();
+        unsigned long long m = __ballot(lane >= scan_from && lane < count && !(id[0] & KDB_F_EXPANDED));
+        if (!m) return 0u;
+        m &= m - 1ull;
+        if (!m) return 0u;
+        return readlane_u(id[0], (uint32_t)__builtin_ctzll(m)) & KDB_ID_MASK;
+    }
+    __device__ __forceinline__ uint32_t first_pending() const {
+        if constexpr (S != 1) return 0u;
+        const uint32_t lane = (uint32_t)kdb_lane();
+        const unsigned long long m = __ballot(lane >= scan_from && lane < count && !(id[0] & KDB_F_EXPANDED));
+        return m ? readlane_u(id[0], (uint32_t)__builtin_ctzll(m)) & KDB_ID_MASK : 0u;
     }
     __device__ __forceinline__ void insert(float dd, uint32_t dlo, uint32_t idf) {
         const uint32_t lane = (uint32_t)kdb_lane();
@@ -584,6 +613,8 @@ struct LdsBeamT {
         }
         return -1;
     }
+    __device__ __forceinline__ uint32_t second_pending() const { return 0u; }
+    __device__ __forceinline__ uint32_t first_pending() const { return 0u; }
     __device__ __forceinline__ void insert(float dd, uint32_t dlo, uint32_t idf) {
         const int lane = kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
@@ -1041,6 +1072,10 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
                 __syncthreads();
             } else {
+                if (pipe) { // hint for wave 1 (cur is marked: the first pending entry is the one behind it)
+                    const uint32_t h1 = b.first_pending();
+                    if (lane == 0) s.ctl[KDB_CTL_NEXT2] = h1;
+                }
                 dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
             }
         } else {
@@ -1177,6 +1212,10 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         KDB_T(if (level == 0) ctr.t_ins += __builtin_readcyclecounter() - tq2;)
         if constexpr (kPipe) {
             if (posted) {
+                { // hint for the hop after next: the entry behind the node about to be popped
+                    const uint32_t h2 = b.second_pending();
+                    if (lane == 0) s.ctl[KDB_CTL_NEXT2] = h2;
+                }
                 __syncthreads(); // wave 1 is done with the next node's list
                 pre = true;
                 pre_n = uni(s.ctl[KDB_CTL_N]);

@@ -583,8 +583,12 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t ncu = (uint32_t)idx->n_cu;
+    // latency mode: a four times larger hash set (LDS is plentiful with one or two workgroups per CU): the visited test is a
+    // compare-and-swap probe loop that ends when the slowest of 32 lanes has found its slot -- at a load below 7 % that is
+    // two rounds, not three
+    const uint32_t hsize_w = hsize ? (hsize * 4u > 16384u ? 16384u : hsize * 4u) : 0u;
     auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
-        const size_t lds = lds1 + (waves > 1u ? 64u + 512u : 0u);
+        const size_t lds = lds1 + (waves > 1u ? 64u + 512u + (size_t)(hsize_w - hsize) * 4 : 0u);
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
@@ -608,10 +612,10 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
             auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
-            const size_t wlds = lds1 + 64 + 512;
+            const size_t wlds = lds1 + 64 + 512 + (size_t)(hsize_w - hsize) * 4;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
-            if (B <= wide_max) return launch(wk, hsize, 4u);
+            if (B <= wide_max) return launch(wk, hsize_w, 4u);
         }
     }
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
