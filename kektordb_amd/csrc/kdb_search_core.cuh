@@ -370,6 +370,7 @@ __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds
         }
         if (VisT::kHash && wave == 1u) {
             pf_node = uni(s.ctl[KDB_CTL_NEXT2]);
+            if (pf_node > v.count) pf_node = 0u;
             pf_nb = (pf_node != 0u && (uint32_t)kdb_lane() < v.deg0) ? v.adj0[(size_t)pf_node * v.deg0 + (uint32_t)kdb_lane()] : 0u;
         }
         if (n == 0u) continue;
@@ -1000,6 +1001,10 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
     const bool pipe = kPipe && level == 0 && !v.has_deleted && s.ctl != nullptr;
     bool pre = false;       // the node about to be popped has been prepared: nb_id[0..pre_n) holds its fresh neighbours
     uint32_t pre_node = 0u, pre_n = 0u;
+    if constexpr (WIDE > 1) {
+        if (lane == 0) s.ctl[KDB_CTL_NEXT2] = 0u; // (no hint yet: upper layers and the first hop post none)
+        wave_lds_fence();
+    }
     KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
     for (;;) {
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
