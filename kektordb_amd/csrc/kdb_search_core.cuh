@@ -26,6 +26,12 @@
 #ifndef KDB_F16_ROWS
 #define KDB_F16_ROWS 2
 #endif
+// measurement build (make dbgs): where a walk's time goes
+#ifdef KDB_SEARCH_TIMERS
+#define KDB_T(x) x
+#else
+#define KDB_T(x)
+#endif
 namespace kdbcore {
 
 struct WaveLds {
@@ -364,7 +370,9 @@ __device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds
         if (cmd == KDB_COOP_EXIT) return;
         uint32_t n = cmd;
         if (cmd == KDB_COOP_VISIT) {
+            KDB_T(const unsigned long long tv0 = __builtin_readcyclecounter();)
             if (wave == 1u) coop_visit(v, s, vis, uni(c0.z), pf_node, pf_nb);
+            KDB_T(if (wave == 1u && kdb_lane() == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); atomicAdd(reinterpret_cast<unsigned long long *>(s.ctl + 12), __builtin_readcyclecounter() - tv0); if (uni(c0.z) == pf_node) atomicAdd(s.ctl + 14, 1u); })
             __syncthreads(); // the list is tested (wave 1), the previous hop's candidates are inserted (wave 0)
             n = uni(s.ctl[KDB_CTL_N]);
         }
@@ -943,14 +951,9 @@ struct QCtr {
     uint32_t n_dist, n_hops, n_dropped;
 #ifdef KDB_SEARCH_TIMERS // measurement build (make dbgs): where a walk's time goes
     uint32_t n_ins;
-    unsigned long long t_adj, t_dist, t_ins, t_pop, t_vis, t_upper;
+    unsigned long long t_adj, t_dist, t_ins, t_pop, t_vis, t_upper, t_wait, t_pred;
 #endif
 };
-#ifdef KDB_SEARCH_TIMERS
-#define KDB_T(x) x
-#else
-#define KDB_T(x)
-#endif
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer; leaves the result in the beam.
 // The entry point's distance, when the caller already has it: the entry point of layer l-1 is the nearest result of layer l
@@ -1134,6 +1137,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 }
             }
         }
+        KDB_T(ctr.t_pred += __builtin_readcyclecounter() - tq2;)
         // One-pass insertion (single-register beam, no deleted nodes): the reference takes the candidates one by one in
         // stored order against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome
         // is simply the ef smallest of beam + candidates, so every beam entry counts the candidates below it (its shift),
@@ -1221,7 +1225,9 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                     const uint32_t h2 = b.second_pending();
                     if (lane == 0) s.ctl[KDB_CTL_NEXT2] = h2;
                 }
+                KDB_T(const unsigned long long tw0 = __builtin_readcyclecounter();)
                 __syncthreads(); // wave 1 is done with the next node's list
+                KDB_T(ctr.t_wait += __builtin_readcyclecounter() - tw0;)
                 pre = true;
                 pre_n = uni(s.ctl[KDB_CTL_N]);
                 vis.n = uni(s.ctl[KDB_CTL_VIS_N]);

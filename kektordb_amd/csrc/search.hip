@@ -114,6 +114,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         vis.marks = s.marks;
     }
     if constexpr (WIDE > 1) {
+        if (threadIdx.x < 16u) s.ctl[threadIdx.x] = 0u;
+        __syncthreads();
         if (threadIdx.x >= 64u) { // the walk belongs to wave 0; the others evaluate their share of every hop's rows, and wave 1
             coop_helper_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6, vis); // prepares the next node (coop_visit)
             return;
@@ -229,7 +231,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
             if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
         }
-        KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu upper-layers %llu | level 0: pop %llu list %llu visited %llu rows %llu inserts %llu\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_upper, ctr.t_pop, ctr.t_adj, ctr.t_vis, ctr.t_dist, ctr.t_ins);)
+        KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu upper-layers %llu | level 0: pop %llu list %llu visited %llu rows %llu predict+post %llu predict+post+insert %llu wait-for-wave-1 %llu | wave 1: visit %llu cycles, hint hits %u\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_upper, ctr.t_pop, ctr.t_adj, ctr.t_vis, ctr.t_dist, ctr.t_pred, ctr.t_ins, ctr.t_wait, WIDE > 1 ? *reinterpret_cast<unsigned long long *>(s.ctl + 12) : 0ull, WIDE > 1 ? s.ctl[14] : 0u);)
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         tot_dropped += ctr.n_dropped;
