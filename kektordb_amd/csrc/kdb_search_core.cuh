@@ -52,13 +52,20 @@ struct WaveLds {
     float *ins_d;      // [64] scatter scratch of the one-pass insertion (may alias nb_d when nobody else writes nb_id)
     uint32_t *ins_id;  // [64]
 };
-// ctl[KDB_CTL_CMD]: a row count n (every wave evaluates its share of nb_id[0..n)), or one of
-constexpr uint32_t KDB_COOP_EXIT = 0xffffffffu;  // the batch is done
-constexpr uint32_t KDB_COOP_VISIT = 0xfffffffeu; // wave 1 fetches node ctl[NODE]'s level-0 list and tests it against the visited set
-// (two 16-byte groups, each read with one ds_read_b128; NEXT2 on its own)
-enum { KDB_CTL_CMD = 0, KDB_CTL_QNORM = 1, KDB_CTL_NODE = 2, KDB_CTL_N = 3, KDB_CTL_VIS_N = 4, KDB_CTL_VIS_BITS = 5,
-       KDB_CTL_ALLOW_LO = 6, KDB_CTL_ALLOW_HI = 7,
-       KDB_CTL_NEXT2 = 8 }; // the beam's first un-expanded entry behind the node being expanded: the likely next VISIT
+// Latency mode (several waves per query): the control words through which the waves of a workgroup talk.  No barriers:
+// a word that announces something (MB_SEQ, ROWS_SEQ, DONE) is written AFTER what it announces and polled by its reader;
+// LDS operations of one wave are performed in the order they were issued.
+enum { KDB_W_MB_SEQ = 0,   // wave 0 -> wave 1: a new request (counts up)
+       KDB_W_MB_KIND = 1, KDB_W_MB_NODE = 2, KDB_W_MB_LEVEL = 3,
+       KDB_W_ROWS_SEQ = 4, // wave 1 -> the other helper waves: nb_id[0..ROWS_N) is ready for this request
+       KDB_W_ROWS_N = 5,
+       KDB_W_DONE = 6,     // every helper wave adds 1 when its share of the request's rows is in nb_d
+       KDB_W_QNORM = 7,    // int8: the query's norm
+       KDB_W_NEXT2 = 8,    // hint: the node the walk pops after the one in work if nothing nearer turns up
+       KDB_W_ALLOW_LO = 9, KDB_W_ALLOW_HI = 10 };
+enum { KDB_W_VISIT = 0u, KDB_W_BEGIN = 1u, KDB_W_EXIT = 2u };
+constexpr uint32_t KDB_W_N_SKIP = 0xfffffffdu; // the node lacks the level (:2524-2527): not a hop
+constexpr uint32_t KDB_W_N_EXIT = 0xffffffffu;
 
 // wave-uniform values that come out of LDS reads / cross-lane ops live in VGPRs unless the compiler is
 // told they are uniform
@@ -292,98 +299,147 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     wave_lds_fence();
 }
 
-// Latency mode: WIDE waves share one query.  Wave 0 walks the graph (beam, insertion order: the walk of search_layer,
-// unchanged); the rows of a hop are split into WIDE contiguous runs, one per wave, so that a hop with 32 fresh neighbours
-// is ONE round trip to HBM instead of three.  A row's distance does not depend on which wave or 16-lane group evaluates it
-// (same pieces per lane, same reduction), so results and counters equal the one-wave walk.
+// ------------------------------------------------------------------------------------------------
+// Latency mode: WIDE waves share one query (round 3: an asynchronous pipeline, no workgroup barriers).
+//   wave 0    walks: pops, decides, inserts -- the reference's walk, step for step (search_layer_wide);
+//   wave 1    owns the visited set: for the node it is told to visit it fetches the neighbour list, runs the visited
+//             test-and-set and the allow-list test, leaves the fresh ids in nb_id, then evaluates its share of their rows;
+//   waves 2.. evaluate their share of the rows.
+// What this buys (measured per level-0 hop of a four-wave walk at 1M x 768, ef=60, make dbgs: pop 420 cycles, list 375,
+// visited test 600, rows 1550, insertions 930 -- one dependent chain in ONE wave, of which only the rows touch HBM):
+// as soon as a hop's distances are back wave 0 knows which node it will pop next -- the nearer of the first un-expanded
+// beam entry and the nearest candidate about to enter (exact unless distances tie; then it just asks after the pop) --
+// and asks for it BEFORE it inserts the hop's candidates.  Insertion and pop then run beside wave 1's visit and the row
+// fetch; the chain of a hop is visit -> rows -> decision.  Same walk, same visited marks, same counters: a row's distance
+// does not depend on which wave or 16-lane group evaluates it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wide_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wide_store(uint32_t *p, uint32_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wide_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void wide_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+// spin until *p differs from `old`; returns the new value (wave-uniform)
+__device__ __forceinline__ uint32_t wide_poll_change(const uint32_t *p, uint32_t old) {
+    uint32_t x;
+    while ((x = uni(wide_load(p))) == old) __builtin_amdgcn_s_sleep(1);
+    wide_acquire();
+    return x;
+}
+
+struct WideCtx { // wave 0's side
+    uint32_t seq = 0u, done_target = 0u;
+};
+template <int WIDE>
+__device__ __forceinline__ void wide_request(const WaveLds &s, WideCtx &c, uint32_t kind, uint32_t node, uint32_t level) {
+    c.seq++;
+    c.done_target += (uint32_t)(WIDE - 1);
+    if (kdb_lane() == 0) {
+        s.ctl[KDB_W_MB_KIND] = kind;
+        s.ctl[KDB_W_MB_NODE] = node;
+        s.ctl[KDB_W_MB_LEVEL] = level;
+        wide_release();
+        wide_store(s.ctl + KDB_W_MB_SEQ, c.seq);
+    }
+}
+// wait until every helper wave has delivered its share of the last request; returns the request's row count (or N_SKIP)
+__device__ __forceinline__ uint32_t wide_wait(const WaveLds &s, const WideCtx &c) {
+    while (uni(wide_load(s.ctl + KDB_W_DONE)) != c.done_target) __builtin_amdgcn_s_sleep(1);
+    wide_acquire();
+    return uni(s.ctl[KDB_W_ROWS_N]);
+}
+// helper wave h (0-based) of H: rows [lo, lo+cnt) of nb_id[0..n)
 template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void coop_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t wave) {
-    const uint32_t chunk = (n + (uint32_t)WIDE - 1u) / (uint32_t)WIDE;
-    const uint32_t lo = wave * chunk;
+__device__ __forceinline__ void wide_rows_share(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm, uint32_t h) {
+    constexpr uint32_t H = (uint32_t)(WIDE - 1);
+    const uint32_t chunk = (n + H - 1u) / H;
+    const uint32_t lo = h * chunk;
     if (lo >= n) return;
     WaveLds s2 = s;
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
     if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    compute_dists<PREC, METRIC, NCH, 2>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
+    compute_dists<PREC, METRIC, NCH, (WIDE > 2 ? 2 : 0)>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
 }
-// wave 0's side (the other waves sit in coop_helper_loop)
-template <int PREC, int METRIC, int NCH, int WIDE>
-__device__ __forceinline__ void dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
-    if constexpr (WIDE == 1) {
-        compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
-    } else {
-        if (n <= 4u) { // one 16-lane group per row: a single trip anyway
-            compute_dists<PREC, METRIC, NCH, 2>(v, s, n, qnorm);
+// wave 1
+template <int PREC, int METRIC, int NCH, int WIDE, class VisT>
+__device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) {
+    const uint32_t lane = (uint32_t)kdb_lane();
+    uint32_t seen = 0u;
+    uint32_t pf_node = 0u, pf_nb = 0u; // the list of the node wave 0 will most likely ask for next: requested a hop early
+    for (;;) {
+        seen = wide_poll_change(s.ctl + KDB_W_MB_SEQ, seen);
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(s.ctl); // seq, kind, node, level
+        const uint32_t kind = uni(c0.y), node = uni(c0.z), lvw = uni(c0.w);
+        if (kind == KDB_W_EXIT) {
+            if (lane == 0) {
+                s.ctl[KDB_W_ROWS_N] = KDB_W_N_EXIT;
+                wide_release();
+                wide_store(s.ctl + KDB_W_ROWS_SEQ, seen);
+            }
             return;
         }
-        if (kdb_lane() == 0) {
-            s.ctl[KDB_CTL_CMD] = n;
-            s.ctl[KDB_CTL_QNORM] = __float_as_uint(qnorm);
+        const float qnorm = __uint_as_float(uni(s.ctl[KDB_W_QNORM]));
+        uint32_t n = 0u;
+        KDB_T(const unsigned long long tv0 = __builtin_readcyclecounter();)
+        if (kind == KDB_W_BEGIN) { // a layer search starts (:2461-2489): clear the set, mark the entry point, score it if asked
+            const int level = (int)(lvw & 0xffu);
+            vis.begin_layer(level > 0);
+            (void)vis.test_and_set(node, lane == 0);
+            if (lvw & 0x100u) {
+                if (lane == 0) s.nb_id[0] = node;
+                n = 1u;
+            }
+            pf_node = 0u;
+        } else {
+            const int level = (int)lvw;
+            const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_W_ALLOW_HI]) << 32) | uni(s.ctl[KDB_W_ALLOW_LO]));
+            uint32_t nb = 0u;
+            bool has_level = true;
+            if (level == 0) {
+                nb = pf_nb; // on its way since the hop before, when the guess was right
+                if (node != pf_node) nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
+            } else { // the node's level and its first upper slot are requested together
+                const int lv = (int)v.levels[node];
+                const uint32_t upi = v.up_idx[node];
+                has_level = lv >= level;
+                if (has_level) nb = lane < v.deg_up ? v.adj_up[((size_t)upi + (size_t)(level - 1)) * v.deg_up + lane] : 0u;
+            }
+            if (!has_level) {
+                n = KDB_W_N_SKIP;
+            } else {
+                bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count); // :2539-2542
+                if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
+                const unsigned long long m = __ballot(fresh);
+                if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+                n = (uint32_t)__builtin_popcountll(m);
+            }
         }
-        __syncthreads(); // rows posted (nb_id, the query) ...
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
-        __syncthreads(); // ... distances back in nb_d
-    }
-}
-// Pipelined hop (round 3; level 0, index without deleted nodes).  Measured per level-0 hop of a four-wave walk, 1M x 768,
-// ef=60 (make dbgs): pop 420 cycles, neighbour list 375, visited test 600, rows 1550, insertions 930 -- a chain of
-// dependent work in ONE wave of which only the rows touch HBM.  As soon as a hop's distances are back wave 0 knows which
-// node it will pop next -- the nearer of the first un-expanded beam entry and the nearest candidate about to enter (exact
-// unless distances tie, and then it simply does not use this path) -- and posts it; while wave 0 inserts the hop's
-// candidates, wave 1 fetches that node's list, runs the visited test-and-set (the hash set lives in LDS: any wave of the
-// workgroup can work on it, and only one does at a time) and the allow-list test, and leaves the fresh ids in nb_id.  The
-// two meet at a barrier, and every wave goes straight to the rows.  Same walk, same visited marks, same counters.
-template <class VisT>
-__device__ __forceinline__ void coop_visit(const KdbView &v, const WaveLds &s, VisT vis, uint32_t node, uint32_t pf_node, uint32_t pf_nb) {
-    if constexpr (VisT::kHash) {
-        const uint32_t lane = (uint32_t)kdb_lane();
-        const uint4 c1 = *reinterpret_cast<const uint4 *>(s.ctl + KDB_CTL_VIS_N);
-        vis.n = uni(c1.x);
-        vis.in_bits = uni(c1.y) != 0u;
-        vis.bs.record = false;
-        vis.bs.n_marks = 0;
-        const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(c1.w) << 32) | uni(c1.z));
-        // the list: already on its way since the rows of the hop before (when the guess was right), else fetched now
-        uint32_t nb = pf_nb;
-        if (node != pf_node) nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
-        bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count); // :2539-2542
-        if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
-        const unsigned long long m = __ballot(fresh);
-        if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+        KDB_T(if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(s.ctl + 12), __builtin_readcyclecounter() - tv0); if (kind == KDB_W_VISIT && node == pf_node) atomicAdd(s.ctl + 14, 1u); })
         if (lane == 0) {
-            s.ctl[KDB_CTL_N] = (uint32_t)__builtin_popcountll(m);
-            s.ctl[KDB_CTL_VIS_N] = vis.n;
-            s.ctl[KDB_CTL_VIS_BITS] = vis.in_bits ? 1u : 0u;
+            s.ctl[KDB_W_ROWS_N] = n;
+            wide_release();
+            wide_store(s.ctl + KDB_W_ROWS_SEQ, seen);
         }
+        if (n != 0u && n != KDB_W_N_SKIP) wide_rows_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
+        wide_release();
+        if (lane == 0) atomicAdd(s.ctl + KDB_W_DONE, 1u);
+        // the hint (wave 0 posts it once it has popped the node in work): request that list now, it is in a register by the
+        // time the next VISIT arrives
+        pf_node = uni(wide_load(s.ctl + KDB_W_NEXT2));
+        if (pf_node > v.count) pf_node = 0u;
+        pf_nb = (pf_node != 0u && lane < v.deg0) ? v.adj0[(size_t)pf_node * v.deg0 + lane] : 0u;
     }
 }
-template <int PREC, int METRIC, int NCH, int WIDE, class VisT>
-__device__ __forceinline__ void coop_helper_loop(const KdbView &v, const WaveLds &s, uint32_t wave, const VisT &vis) {
-    // wave 1: the neighbour list of the node wave 0 will most likely expand next (ctl[NEXT2], posted with every hop), requested
-    // before this wave's share of the hop's rows -- it is in a register by the time the VISIT arrives
-    uint32_t pf_node = 0u, pf_nb = 0u;
+// waves 2 ..
+template <int PREC, int METRIC, int NCH, int WIDE>
+__device__ void wide_rows_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
+    uint32_t seen = 0u;
     for (;;) {
-        __syncthreads();
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(s.ctl);
-        const uint32_t cmd = uni(c0.x);
-        if (cmd == KDB_COOP_EXIT) return;
-        uint32_t n = cmd;
-        if (cmd == KDB_COOP_VISIT) {
-            KDB_T(const unsigned long long tv0 = __builtin_readcyclecounter();)
-            if (wave == 1u) coop_visit(v, s, vis, uni(c0.z), pf_node, pf_nb);
-            KDB_T(if (wave == 1u && kdb_lane() == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); atomicAdd(reinterpret_cast<unsigned long long *>(s.ctl + 12), __builtin_readcyclecounter() - tv0); if (uni(c0.z) == pf_node) atomicAdd(s.ctl + 14, 1u); })
-            __syncthreads(); // the list is tested (wave 1), the previous hop's candidates are inserted (wave 0)
-            n = uni(s.ctl[KDB_CTL_N]);
-        }
-        if (VisT::kHash && wave == 1u) {
-            pf_node = uni(s.ctl[KDB_CTL_NEXT2]);
-            if (pf_node > v.count) pf_node = 0u;
-            pf_nb = (pf_node != 0u && (uint32_t)kdb_lane() < v.deg0) ? v.adj0[(size_t)pf_node * v.deg0 + (uint32_t)kdb_lane()] : 0u;
-        }
-        if (n == 0u) continue;
-        coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(c0.y)), wave);
-        __syncthreads();
+        seen = wide_poll_change(s.ctl + KDB_W_ROWS_SEQ, seen);
+        const uint32_t n = uni(s.ctl[KDB_W_ROWS_N]);
+        if (n == KDB_W_N_EXIT) return;
+        if (n != 0u && n != KDB_W_N_SKIP) wide_rows_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[KDB_W_QNORM])), wave - 1u);
+        wide_release();
+        if (kdb_lane() == 0) atomicAdd(s.ctl + KDB_W_DONE, 1u);
     }
 }
 
@@ -965,7 +1021,134 @@ struct EpKnown {
     uint32_t lo = 0u;
 };
 
-template <int PREC, int METRIC, int NCH, class BeamT, class VisT, int WIDE = 1>
+// A hop's candidates (lanes < n hold id / key / deleted flag; `pass` = those that may still enter) go into the beam.
+// One-pass form (single-register beam, no deleted nodes): the reference takes the candidates one by one in stored order
+// against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome is simply the ef
+// smallest of beam + candidates, so every beam entry counts the candidates below it (its shift), every candidate the beam
+// entries and candidates below it (its place), one scatter through LDS puts everybody where he belongs.  Any tie at all ->
+// the sequential form, which is the definition.
+template <class BeamT, class NrT>
+__device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLds &s, BeamT &b, NrT &nr, uint32_t ef, unsigned long long pass,
+                                                  float my_d, uint32_t my_lo, uint32_t my_id, bool my_nr, QCtr &ctr) {
+    constexpr bool WK = BeamT::kWide;
+    const int lane = kdb_lane();
+    if constexpr (BeamT::kSlots == 1 && !WK) {
+        const uint32_t npass = (uint32_t)__builtin_popcountll(pass);
+        if (npass >= 2u && !v.has_deleted) {
+            const uint32_t m = b.count;
+            const bool in_beam = (uint32_t)lane < m;
+            const bool in_pass = ((pass >> lane) & 1ull) != 0ull;
+            const float bd = b.d[0];
+            uint32_t shift = 0u, place = 0u;
+            bool tie = false;
+            for (unsigned long long rest = pass; rest;) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                const float cd = readlane_f(my_d, j);
+                shift += (in_beam && cd < bd) ? 1u : 0u;
+                const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(in_beam && bd < cd));
+                tie = tie || (in_beam && bd == cd) || (in_pass && (uint32_t)lane != j && cd == my_d);
+                place += (in_pass && cd < my_d) ? 1u : 0u;
+                if ((uint32_t)lane == j) place += below;
+            }
+            if (__ballot(tie) == 0ull) {
+                const uint32_t total = m + npass;
+                const uint32_t ncount = total < ef ? total : ef;
+                const uint32_t b_to = (uint32_t)lane + shift;
+                const bool b_keep = in_beam && b_to < ef, c_keep = in_pass && place < ef;
+                wave_lds_fence();
+                if (b_keep) {
+                    s.ins_d[b_to] = bd;
+                    s.ins_id[b_to] = b.id[0];
+                }
+                if (c_keep) {
+                    s.ins_d[place] = my_d;
+                    s.ins_id[place] = my_id;
+                }
+                wave_lds_fence();
+                const bool live = (uint32_t)lane < ncount;
+                b.d[0] = live ? s.ins_d[lane] : INFINITY;
+                b.id[0] = live ? s.ins_id[lane] : 0u;
+                wave_lds_fence();
+                // the pop scan restarts at the nearest newcomer if that lies before the scan position
+                uint32_t lowest = 0xffffffffu;
+                for (unsigned long long r2 = __ballot(c_keep); r2;) { // (few bits)
+                    const uint32_t j = (uint32_t)__builtin_ctzll(r2);
+                    r2 &= r2 - 1ull;
+                    const uint32_t pj = readlane_u(place, j);
+                    lowest = pj < lowest ? pj : lowest;
+                }
+                if (lowest < b.scan_from) b.scan_from = lowest;
+                b.count = ncount;
+                b.n_res = ncount;
+                b.worst = ncount >= ef ? readlane_f(b.d[0], ncount - 1u) : INFINITY;
+                b.worst_lo = 0u;
+                KDB_T(ctr.n_ins += npass;)
+                return;
+            }
+        }
+    }
+    while (pass) { // sequential, in stored order (:2577-2590)
+        const uint32_t j = (uint32_t)__builtin_ctzll(pass);
+        pass &= pass - 1;
+        const float d = readlane_f(my_d, j);
+        const uint32_t dlo = WK ? readlane_u(my_lo, j) : 0u;
+        if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
+        const uint32_t id = readlane_u(my_id, j);
+        if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
+            nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
+        } else {
+            // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
+            // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
+            if (b.n_res >= ef) b.drop_last();
+            b.insert(d, dlo, id);
+            b.n_res++;
+            b.trim(ef);
+            KDB_T(ctr.n_ins++;)
+        }
+    }
+}
+
+// heap_pop(candidates): the nearest un-expanded beam entry or the nearest traversal-only candidate; false = the layer
+// search is over (:2495-2506)
+template <class BeamT, class NrT>
+__device__ __forceinline__ bool pop_candidate(BeamT &b, NrT &nr, uint32_t ef, uint32_t &cur) {
+    constexpr bool WK = BeamT::kWide;
+    const int idx = b.next();
+    float cur_d = INFINITY;
+    uint32_t cur_lo = 0;
+    cur = 0;
+    if (idx >= 0) {
+        uint32_t cur_f;
+        b.get((uint32_t)idx, cur_d, cur_lo, cur_f);
+        cur = cur_f & KDB_ID_MASK;
+    }
+    bool from_nr = false;
+    uint32_t nr_pos = 0;
+    if (nr.count) { // wave-uniform; only indexes with deleted nodes (or a filtered-out entry point) get here
+        float nd;
+        uint32_t nlo, nid;
+        nr_pos = nr.template extreme<false>(nd, nlo, nid);
+        if (idx < 0 || key_lt<WK>(nd, nlo, cur_d, cur_lo) || (key_eq<WK>(nd, nlo, cur_d, cur_lo) && nid < cur)) {
+            from_nr = true;
+            cur_d = nd;
+            cur_lo = nlo;
+            cur = nid;
+        }
+    }
+    if (idx < 0 && !from_nr) return false;
+    if (b.n_res >= ef && key_lt<WK>(b.worst, b.worst_lo, cur_d, cur_lo)) return false; // :2501-2506 (only a traversal-only candidate can be this far)
+    if (from_nr) {
+        nr.remove(nr_pos);
+    } else {
+        b.mark_expanded((uint32_t)idx);
+        b.scan_from = (uint32_t)idx + 1;
+    }
+    return true;
+}
+
+// searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer, ONE wave; leaves the result in the beam.
+template <int PREC, int METRIC, int NCH, class BeamT, class VisT>
 __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT &vis,
                              const uint32_t *allow, uint32_t ep, int level, uint32_t ef, float qnorm, QCtr &ctr,
                              EpKnown epk = EpKnown()) {
@@ -981,7 +1164,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
     if (!epk.known) {
         if (lane == 0) s.nb_id[0] = ep;
         wave_lds_fence();
-        dists<PREC, METRIC, NCH, WIDE>(v, s, 1, qnorm);
+        compute_dists<PREC, METRIC, NCH>(v, s, 1, qnorm);
         ep_key = unif(s.nb_d[0]);
         ep_lo = WK ? uni(s.nb_lo[0]) : 0u;
     }
@@ -999,48 +1182,11 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
-    // pipelined hops (see coop_visit): wave 1 prepares the next node while wave 0 inserts
-    constexpr bool kPipe = WIDE > 1 && VisT::kHash && !WK;
-    const bool pipe = kPipe && level == 0 && !v.has_deleted && s.ctl != nullptr;
-    bool pre = false;       // the node about to be popped has been prepared: nb_id[0..pre_n) holds its fresh neighbours
-    uint32_t pre_node = 0u, pre_n = 0u;
-    if constexpr (WIDE > 1) {
-        if (lane == 0) s.ctl[KDB_CTL_NEXT2] = 0u; // (no hint yet: upper layers and the first hop post none)
-        wave_lds_fence();
-    }
     KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
     for (;;) {
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
-        // heap_pop(candidates): the nearest un-expanded beam entry or the nearest traversal-only candidate
-        const int idx = b.next();
-        float cur_d = INFINITY;
-        uint32_t cur = 0, cur_lo = 0;
-        if (idx >= 0) {
-            uint32_t cur_f;
-            b.get((uint32_t)idx, cur_d, cur_lo, cur_f);
-            cur = cur_f & KDB_ID_MASK;
-        }
-        bool from_nr = false;
-        uint32_t nr_pos = 0;
-        if (nr.count) { // wave-uniform; only indexes with deleted nodes (or a filtered-out entry point) get here
-            float nd;
-            uint32_t nlo, nid;
-            nr_pos = nr.template extreme<false>(nd, nlo, nid);
-            if (idx < 0 || key_lt<WK>(nd, nlo, cur_d, cur_lo) || (key_eq<WK>(nd, nlo, cur_d, cur_lo) && nid < cur)) {
-                from_nr = true;
-                cur_d = nd;
-                cur_lo = nlo;
-                cur = nid;
-            }
-        }
-        if (idx < 0 && !from_nr) break;
-        if (b.n_res >= ef && key_lt<WK>(b.worst, b.worst_lo, cur_d, cur_lo)) break; // :2501-2506 (only a traversal-only candidate can be this far)
-        if (from_nr) {
-            nr.remove(nr_pos);
-        } else {
-            b.mark_expanded((uint32_t)idx);
-            b.scan_from = (uint32_t)idx + 1;
-        }
+        uint32_t cur;
+        if (!pop_candidate(b, nr, ef, cur)) break;
         const uint32_t *adj = v.adj0 + (size_t)cur * v.deg0;
         if (level > 0) { // the node's level and its first upper slot are requested together (one wait, not two dependent ones)
             const int lv = (int)v.levels[cur];
@@ -1050,64 +1196,105 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
         ctr.n_hops++;
         KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter(); if (level == 0) ctr.t_pop += tq0 - tq_a;)
-        uint32_t n;
-        const bool prepared = kPipe && pre; // (the prediction is exact: pre_node == cur)
-        if (prepared) {
-            n = pre_n;
-            pre = false;
-            (void)pre_node;
-        } else {
-            const uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
-            KDB_T(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tq_v = __builtin_readcyclecounter();)
-            // visited test-and-set (:2539-2542)
-            bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
-            if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
-            const unsigned long long m = __ballot(fresh);
-            n = (uint32_t)__builtin_popcountll(m);
-            KDB_T(if (level == 0) { ctr.t_adj += tq_v - tq0; ctr.t_vis += __builtin_readcyclecounter() - tq_v; })
-            if (n == 0) continue;
-            if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
-            wave_lds_fence();
-        }
-        if (n == 0) continue; // (a prepared node without fresh neighbours: the helper waves skipped the rows too)
+        const uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        KDB_T(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tq_v = __builtin_readcyclecounter();)
+        // visited test-and-set (:2539-2542)
+        bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
+        if (fresh && allow) fresh = ((allow[nb >> 5] >> (nb & 31)) & 1u) != 0; // :2545-2549
+        const unsigned long long m = __ballot(fresh);
+        const uint32_t n = (uint32_t)__builtin_popcountll(m);
+        KDB_T(if (level == 0) { ctr.t_adj += tq_v - tq0; ctr.t_vis += __builtin_readcyclecounter() - tq_v; })
+        if (n == 0) continue;
+        if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
+        wave_lds_fence();
         // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather;
         // skipped when the index holds no deleted node
-        uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
+        const uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
         KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter();)
-        if constexpr (kPipe) {
-            if (prepared) { // every wave has read n behind the barrier that ended the preparation: straight to the rows
-                coop_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
-                __syncthreads();
-            } else {
-                if (pipe) { // hint for wave 1 (cur is marked: the first pending entry is the one behind it)
-                    const uint32_t h1 = b.first_pending();
-                    if (lane == 0) s.ctl[KDB_CTL_NEXT2] = h1;
-                }
-                dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
-            }
-        } else {
-            dists<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm);
-        }
+        compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
-        unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
+        const unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
         KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); if (level == 0) ctr.t_dist += tq2 - tq1;)
-        bool posted = false;
-        if constexpr (kPipe) {
-            if (pipe && nr.count == 0u) {
+        insert_candidates(v, s, b, nr, ef, pass, my_d, my_lo, my_id, my_nr, ctr);
+        KDB_T(if (level == 0) ctr.t_ins += __builtin_readcyclecounter() - tq2;)
+    }
+    KDB_T(if (level > 0) ctr.t_upper += __builtin_readcyclecounter() - tq_layer;)
+    ctr.n_dropped += nr.dropped;
+    vis.end_layer();
+}
+
+// The same layer search as wave 0 of the latency mode runs it: every list / visited test / row evaluation is a request to
+// the helper waves (wide_visitor_loop, wide_rows_loop); the decisions -- pops, acceptance, insertion order -- are the ones
+// above, in the same order.
+template <int PREC, int METRIC, int NCH, class BeamT, int WIDE>
+__device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, WideCtx &wc, uint32_t ep, int level, uint32_t ef,
+                                  const uint32_t *allow, QCtr &ctr, EpKnown epk = EpKnown()) {
+    const int lane = kdb_lane();
+    b.reset(ef);
+    constexpr bool WK = BeamT::kWide;
+    NrListT<WK> nr;
+    nr.bind(s);
+    if (lane == 0) s.ctl[KDB_W_NEXT2] = 0u;
+    // entry point (:2461-2489): wave 1 clears the visited set, marks it and -- unless its distance is known -- scores it
+    wide_request<WIDE>(s, wc, KDB_W_BEGIN, ep, (uint32_t)level | (epk.known ? 0u : 0x100u));
+    (void)wide_wait(s, wc);
+    const float ep_key = epk.known ? epk.key : unif(s.nb_d[0]);
+    const uint32_t ep_lo = epk.known ? epk.lo : (WK ? uni(s.nb_lo[0]) : 0u);
+    ctr.n_dist++;
+    {
+        bool no_result = ((v.deleted[ep >> 5] >> (ep & 31)) & 1u) != 0;
+        if (allow && !((allow[ep >> 5] >> (ep & 31)) & 1u)) no_result = true;
+        if (no_result) {
+            nr.push(ep_key, ep_lo, ep, INFINITY, 0u, false);
+        } else {
+            b.insert(ep_key, ep_lo, ep);
+            b.n_res++;
+            b.trim(ef);
+        }
+    }
+    bool asked = false; // the node the next pop yields is already in work
+    KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
+    for (;;) {
+        KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
+        uint32_t cur;
+        if (!pop_candidate(b, nr, ef, cur)) break;
+        if (!asked) wide_request<WIDE>(s, wc, KDB_W_VISIT, cur, (uint32_t)level);
+        asked = false;
+        { // hint for wave 1: the entry behind the node in work (cur is marked: the first pending entry)
+            const uint32_t h = b.first_pending();
+            if (lane == 0) wide_store(s.ctl + KDB_W_NEXT2, h);
+        }
+        KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter(); if (level == 0) ctr.t_pop += tq0 - tq_a;)
+        const uint32_t n = wide_wait(s, wc);
+        KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter(); if (level == 0) ctr.t_wait += tq1 - tq0;)
+        if (n == KDB_W_N_SKIP) continue; // :2524-2527 node lacks this level
+        ctr.n_hops++;
+        if (n == 0) continue;
+        const uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
+        const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
+        const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
+        // soft-delete flags of the new neighbours (Node.Deleted); skipped when the index holds no deleted node
+        const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
+        ctr.n_dist += n;
+        const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
+        // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
+        const unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
+        if constexpr (!WK) {
+            if (!v.has_deleted && nr.count == 0u) {
                 // The next pop, known before the insertion: the first un-expanded entry of the beam as it is, or the nearest
                 // candidate that is about to enter it.  (The nearest passing candidate always enters: fewer than ef entries
                 // are nearer than the worst it beat.  An entry the candidates push out is farther than one of them.)  Equal
-                // distances in play -> no prediction, this hop takes the plain path.
+                // distances in play -> no prediction: the request follows the pop.
                 const int i2 = b.next();
                 float od = INFINITY;
                 uint32_t olo, oidf = 0u;
                 if (i2 >= 0) b.get((uint32_t)i2, od, olo, oidf);
-                float cm = pass >> lane & 1ull ? my_d : INFINITY; // the nearest passing candidate: row minimum, then across rows
+                float cm = ((pass >> lane) & 1ull) ? my_d : INFINITY; // the nearest passing candidate: row minimum, then across rows
                 cm = fminf(cm, kdb_row_ror<8>(cm));
                 cm = fminf(cm, kdb_row_ror<4>(cm));
                 cm = fminf(cm, kdb_row_ror<2>(cm));
@@ -1118,126 +1305,22 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
                 if (i2 >= 0 && od < cmin) {
                     nxt = oidf & KDB_ID_MASK;
                 } else if (pass && !(i2 >= 0 && od == cmin)) {
-                    const unsigned long long at = __ballot((pass >> lane & 1ull) && my_d == cmin);
+                    const unsigned long long at = __ballot(((pass >> lane) & 1ull) && my_d == cmin);
                     if (__builtin_popcountll(at) == 1) nxt = readlane_u(my_id, (uint32_t)__builtin_ctzll(at));
                 }
                 if (nxt) {
-                    if (lane == 0) {
-                        s.ctl[KDB_CTL_CMD] = KDB_COOP_VISIT;
-                        s.ctl[KDB_CTL_QNORM] = __float_as_uint(qnorm);
-                        s.ctl[KDB_CTL_NODE] = nxt;
-                        s.ctl[KDB_CTL_VIS_N] = vis.n;
-                        s.ctl[KDB_CTL_VIS_BITS] = vis.in_bits ? 1u : 0u;
-                        s.ctl[KDB_CTL_ALLOW_LO] = (uint32_t)(unsigned long long)allow;
-                        s.ctl[KDB_CTL_ALLOW_HI] = (uint32_t)((unsigned long long)allow >> 32);
-                    }
-                    __syncthreads(); // wave 1 starts on nxt (it writes nb_id: this hop's ids and distances are in registers)
-                    posted = true;
-                    pre_node = nxt;
+                    wide_request<WIDE>(s, wc, KDB_W_VISIT, nxt, (uint32_t)level);
+                    asked = true;
                 }
             }
         }
-        KDB_T(ctr.t_pred += __builtin_readcyclecounter() - tq2;)
-        // One-pass insertion (single-register beam, no deleted nodes): the reference takes the candidates one by one in
-        // stored order against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome
-        // is simply the ef smallest of beam + candidates, so every beam entry counts the candidates below it (its shift),
-        // every candidate the beam entries and candidates below it (its place), one scatter through LDS puts everybody
-        // where he belongs.  Any tie at all -> the sequential path below, which is the definition.
-        if constexpr (BeamT::kSlots == 1 && !WK) {
-            const uint32_t npass = (uint32_t)__builtin_popcountll(pass);
-            if (npass >= 2u && !v.has_deleted) {
-                const uint32_t m = b.count;
-                const bool in_beam = (uint32_t)lane < m;
-                const bool in_pass = ((pass >> lane) & 1ull) != 0ull;
-                const float bd = b.d[0];
-                uint32_t shift = 0u, place = 0u;
-                bool tie = false;
-                for (unsigned long long rest = pass; rest;) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
-                    rest &= rest - 1ull;
-                    const float cd = readlane_f(my_d, j);
-                    shift += (in_beam && cd < bd) ? 1u : 0u;
-                    const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(in_beam && bd < cd));
-                    tie = tie || (in_beam && bd == cd) || (in_pass && (uint32_t)lane != j && cd == my_d);
-                    place += (in_pass && cd < my_d) ? 1u : 0u;
-                    if ((uint32_t)lane == j) place += below;
-                }
-                if (__ballot(tie) == 0ull) {
-                    const uint32_t total = m + npass;
-                    const uint32_t ncount = total < ef ? total : ef;
-                    const uint32_t b_to = (uint32_t)lane + shift;
-                    const bool b_keep = in_beam && b_to < ef, c_keep = in_pass && place < ef;
-                    wave_lds_fence();
-                    if (b_keep) {
-                        s.ins_d[b_to] = bd;
-                        s.ins_id[b_to] = b.id[0];
-                    }
-                    if (c_keep) {
-                        s.ins_d[place] = my_d;
-                        s.ins_id[place] = my_id;
-                    }
-                    wave_lds_fence();
-                    const bool live = (uint32_t)lane < ncount;
-                    b.d[0] = live ? s.ins_d[lane] : INFINITY;
-                    b.id[0] = live ? s.ins_id[lane] : 0u;
-                    wave_lds_fence();
-                    // the pop scan restarts at the nearest newcomer if that lies before the scan position
-                    uint32_t lowest = 0xffffffffu;
-                    for (unsigned long long r2 = __ballot(c_keep); r2;) { // (few bits)
-                        const uint32_t j = (uint32_t)__builtin_ctzll(r2);
-                        r2 &= r2 - 1ull;
-                        const uint32_t pj = readlane_u(place, j);
-                        lowest = pj < lowest ? pj : lowest;
-                    }
-                    if (lowest < b.scan_from) b.scan_from = lowest;
-                    b.count = ncount;
-                    b.n_res = ncount;
-                    b.worst = ncount >= ef ? readlane_f(b.d[0], ncount - 1u) : INFINITY;
-                    b.worst_lo = 0u;
-                    KDB_T(ctr.n_ins += npass;)
-                    pass = 0ull;
-                }
-            }
-        }
-        while (pass) { // sequential, in stored order (:2577-2590)
-            const uint32_t j = (uint32_t)__builtin_ctzll(pass);
-            pass &= pass - 1;
-            const float d = readlane_f(my_d, j);
-            const uint32_t dlo = WK ? readlane_u(my_lo, j) : 0u;
-            if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
-            const uint32_t id = readlane_u(my_id, j);
-            if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
-                nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
-            } else {
-                // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
-                // worst of a full set, so the worst leaves FIRST and the beam never holds more than ef entries
-                if (b.n_res >= ef) b.drop_last();
-                b.insert(d, dlo, id);
-                b.n_res++;
-                b.trim(ef);
-                KDB_T(ctr.n_ins++;)
-            }
-        }
+        KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); if (level == 0) ctr.t_pred += tq2 - tq1;)
+        insert_candidates(v, s, b, nr, ef, pass, my_d, my_lo, my_id, my_nr, ctr);
         KDB_T(if (level == 0) ctr.t_ins += __builtin_readcyclecounter() - tq2;)
-        if constexpr (kPipe) {
-            if (posted) {
-                { // hint for the hop after next: the entry behind the node about to be popped
-                    const uint32_t h2 = b.second_pending();
-                    if (lane == 0) s.ctl[KDB_CTL_NEXT2] = h2;
-                }
-                KDB_T(const unsigned long long tw0 = __builtin_readcyclecounter();)
-                __syncthreads(); // wave 1 is done with the next node's list
-                KDB_T(ctr.t_wait += __builtin_readcyclecounter() - tw0;)
-                pre = true;
-                pre_n = uni(s.ctl[KDB_CTL_N]);
-                vis.n = uni(s.ctl[KDB_CTL_VIS_N]);
-                vis.in_bits = uni(s.ctl[KDB_CTL_VIS_BITS]) != 0u;
-            }
-        }
     }
+    if (asked) (void)wide_wait(s, wc); // (cannot happen: a predicted node is in the beam, un-expanded)
     KDB_T(if (level > 0) ctr.t_upper += __builtin_readcyclecounter() - tq_layer;)
     ctr.n_dropped += nr.dropped;
-    vis.end_layer();
 }
 
 // LDS hash-set size (words) for ef; 0 = use the HBM bitset

@@ -16,7 +16,8 @@
 //     caller's buffer; queries are pulled from an atomic work counter by persistent waves;
 //   * one allow list per batch or one per query; its entry point (hnsw_index.go:437-447) is chosen on the device;
 //   * small batches (every query gets its own resident workgroup) run four waves per query: wave 0 walks, all four
-//     evaluate the rows of a hop (dists() / coop_spec_share() in kdb_search_core.cuh) -- same walk, same counters.
+//     evaluate the rows of a hop, wave 1 owns the visited set and prepares the next node while wave 0 inserts
+//     (search_layer_wide / wide_visitor_loop in kdb_search_core.cuh) -- same walk, same counters.
 #include "kdb_search_core.cuh"
 #include <map>
 #include <tuple>
@@ -116,11 +117,13 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     if constexpr (WIDE > 1) {
         if (threadIdx.x < 16u) s.ctl[threadIdx.x] = 0u;
         __syncthreads();
-        if (threadIdx.x >= 64u) { // the walk belongs to wave 0; the others evaluate their share of every hop's rows, and wave 1
-            coop_helper_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6, vis); // prepares the next node (coop_visit)
+        if (threadIdx.x >= 64u) { // the walk belongs to wave 0; wave 1 owns the visited set and prepares every node wave 0 asks
+            if ((threadIdx.x >> 6) == 1u) wide_visitor_loop<PREC, METRIC, NCH, WIDE>(v, s, vis); // for; all helpers evaluate rows
+            else wide_rows_loop<PREC, METRIC, NCH, WIDE>(v, s, threadIdx.x >> 6);
             return;
         }
     }
+    WideCtx wc;
     unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
     typename BeamSel<BS, PREC == KDB_PREC_I8>::type b;
     b.bind(s);
@@ -197,9 +200,20 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
         bool failed = ep == 0u;
         EpKnown epk; // the next layer's entry point is this layer's nearest result: its distance is known
+        if constexpr (WIDE > 1) { // what the helper waves need to know about this query
+            if (lane == 0) {
+                s.ctl[KDB_W_QNORM] = __float_as_uint(qnorm);
+                s.ctl[KDB_W_ALLOW_LO] = (uint32_t)(unsigned long long)q_allow;
+                s.ctl[KDB_W_ALLOW_HI] = (uint32_t)((unsigned long long)q_allow >> 32);
+            }
+        }
+        auto layer = [&](uint32_t from, int l, uint32_t ef_l) {
+            if constexpr (WIDE > 1) search_layer_wide<PREC, METRIC, NCH, decltype(b), WIDE>(v, s, b, wc, from, l, ef_l, q_allow, ctr, epk);
+            else search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis)>(v, s, b, vis, q_allow, from, l, ef_l, qnorm, ctr, epk);
+        };
         // greedy descent, ef = 1 (:450-459)
         for (int l = v.max_level; l > 0 && !failed; l--) {
-            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, l, 1u, qnorm, ctr, epk);
+            layer(ep, l, 1u);
             const int best = b.first_result();
             if (best < 0) failed = true; // "search failed at level" (:455-457)
             else {
@@ -214,7 +228,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
         uint32_t nout = 0;
         if (!failed) {
-            search_layer<PREC, METRIC, NCH, decltype(b), decltype(vis), WIDE>(v, s, b, vis, q_allow, ep, 0, ef, qnorm, ctr, epk);
+            layer(ep, 0, ef);
             // results, ascending (:2596-2610), first k
             // raw & 4 (int8 indexes): out_dist is a double array -- the reference's float64 distances, not their float rounding
             nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
@@ -237,10 +251,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         tot_dropped += ctr.n_dropped;
         wave_lds_fence();
     }
-    if constexpr (WIDE > 1) {
-        if (lane == 0) s.ctl[KDB_CTL_CMD] = KDB_COOP_EXIT;
-        __syncthreads();
-    }
+    if constexpr (WIDE > 1) wide_request<WIDE>(s, wc, KDB_W_EXIT, 0u, 0u);
     if (lane == 0 && gctr) {
         atomicAdd(&gctr[0], tot_dist);
         atomicAdd(&gctr[1], tot_hops);
@@ -607,10 +618,10 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         return KDB_OK;
     };
     if constexpr (BS == 1 || BS == 2) {
-        // latency mode: a batch that leaves most of the chip idle gives every query four waves: wave 0 walks, all four
-        // evaluate a hop's rows (one HBM round trip per hop instead of three), wave 1 prepares the next node while wave 0
-        // inserts (coop_visit); same walk, same results, same counters -- as long as every query gets its own resident
-        // workgroup (512 at 768-d float32)
+        // latency mode: a batch that leaves most of the chip idle gives every query four waves: wave 0 walks, the other
+        // three evaluate a hop's rows (one HBM round trip per hop instead of three), wave 1 prepares the next node while
+        // wave 0 inserts (search_layer_wide); same walk, same results, same counters -- as long as every query gets its own
+        // resident workgroup (512 at 768-d float32)
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
             auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
