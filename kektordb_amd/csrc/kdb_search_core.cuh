@@ -55,14 +55,16 @@ struct WaveLds {
 // Latency mode (several waves per query): the control words through which the waves of a workgroup talk.  No barriers:
 // a word that announces something (MB_SEQ, ROWS_SEQ, DONE) is written AFTER what it announces and polled by its reader;
 // LDS operations of one wave are performed in the order they were issued.
-enum { KDB_W_MB_SEQ = 0,   // wave 0 -> wave 1: a new request (counts up)
-       KDB_W_MB_KIND = 1, KDB_W_MB_NODE = 2, KDB_W_MB_LEVEL = 3,
+// (a sequence number and its payload share one aligned 8-byte word: written and read with ONE LDS operation)
+enum { KDB_W_MB_SEQ = 0,   // wave 0 -> wave 1: a new request (counts up) ...
+       KDB_W_MB_ARG = 1,   // ... node << 2 | kind
+       KDB_W_LEVEL = 2,    // of the layer search in progress | 0x100 = score the entry point (written before a BEGIN)
+       KDB_W_NEXT2 = 3,    // hint: the node the walk pops after the one in work if nothing nearer turns up
        KDB_W_ROWS_SEQ = 4, // wave 1 -> the other helper waves: nb_id[0..ROWS_N) is ready for this request
        KDB_W_ROWS_N = 5,
        KDB_W_DONE = 6,     // every helper wave adds 1 when its share of the request's rows is in nb_d
        KDB_W_QNORM = 7,    // int8: the query's norm
-       KDB_W_NEXT2 = 8,    // hint: the node the walk pops after the one in work if nothing nearer turns up
-       KDB_W_ALLOW_LO = 9, KDB_W_ALLOW_HI = 10 };
+       KDB_W_ALLOW_LO = 8, KDB_W_ALLOW_HI = 9 };
 enum { KDB_W_VISIT = 0u, KDB_W_BEGIN = 1u, KDB_W_EXIT = 2u };
 constexpr uint32_t KDB_W_N_SKIP = 0xfffffffdu; // the node lacks the level (:2524-2527): not a hop
 constexpr uint32_t KDB_W_N_EXIT = 0xffffffffu;
@@ -317,34 +319,38 @@ __device__ __forceinline__ uint32_t wide_load(const uint32_t *p) { return __hip_
 __device__ __forceinline__ void wide_store(uint32_t *p, uint32_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wide_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
 __device__ __forceinline__ void wide_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
-// spin until *p differs from `old`; returns the new value (wave-uniform)
-__device__ __forceinline__ uint32_t wide_poll_change(const uint32_t *p, uint32_t old) {
-    uint32_t x;
-    while ((x = uni(wide_load(p))) == old) __builtin_amdgcn_s_sleep(1);
+// spin until the sequence word at p[0] differs from `old`; returns (seq, payload p[1]) read by one 8-byte LDS load
+__device__ __forceinline__ uint2 wide_poll_change(const uint32_t *p, uint32_t old) {
+    unsigned long long x;
+    do {
+        x = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } while (uni((uint32_t)x) == old);
     wide_acquire();
-    return x;
+    return make_uint2(uni((uint32_t)x), uni((uint32_t)(x >> 32)));
+}
+__device__ __forceinline__ void wide_post(uint32_t *p, uint32_t seq, uint32_t payload) { // lane 0
+    wide_release();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)payload << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 struct WideCtx { // wave 0's side
     uint32_t seq = 0u, done_target = 0u;
 };
 template <int WIDE>
-__device__ __forceinline__ void wide_request(const WaveLds &s, WideCtx &c, uint32_t kind, uint32_t node, uint32_t level) {
+__device__ __forceinline__ void wide_request(const WaveLds &s, WideCtx &c, uint32_t kind, uint32_t node) {
     c.seq++;
     c.done_target += (uint32_t)(WIDE - 1);
-    if (kdb_lane() == 0) {
-        s.ctl[KDB_W_MB_KIND] = kind;
-        s.ctl[KDB_W_MB_NODE] = node;
-        s.ctl[KDB_W_MB_LEVEL] = level;
-        wide_release();
-        wide_store(s.ctl + KDB_W_MB_SEQ, c.seq);
-    }
+    if (kdb_lane() == 0) wide_post(s.ctl + KDB_W_MB_SEQ, c.seq, node << 2 | kind);
 }
 // wait until every helper wave has delivered its share of the last request; returns the request's row count (or N_SKIP)
 __device__ __forceinline__ uint32_t wide_wait(const WaveLds &s, const WideCtx &c) {
-    while (uni(wide_load(s.ctl + KDB_W_DONE)) != c.done_target) __builtin_amdgcn_s_sleep(1);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 x; // rows_seq, rows_n, done, qnorm: one 16-byte LDS load per look
+    do {
+        x = *reinterpret_cast<const volatile u32x4 *>(s.ctl + KDB_W_ROWS_SEQ);
+    } while (uni(x.z) != c.done_target);
     wide_acquire();
-    return uni(s.ctl[KDB_W_ROWS_N]);
+    return uni(x.y);
 }
 // helper wave h (0-based) of H: rows [lo, lo+cnt) of nb_id[0..n)
 template <int PREC, int METRIC, int NCH, int WIDE>
@@ -365,23 +371,23 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
     const uint32_t lane = (uint32_t)kdb_lane();
     uint32_t seen = 0u;
     uint32_t pf_node = 0u, pf_nb = 0u; // the list of the node wave 0 will most likely ask for next: requested a hop early
+    uint32_t lvw = 0u;                 // of the layer search in progress (told with its BEGIN)
+    int level = 0;
+    const uint32_t *allow = nullptr;
+    float qnorm = 1.f;
     for (;;) {
-        seen = wide_poll_change(s.ctl + KDB_W_MB_SEQ, seen);
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(s.ctl); // seq, kind, node, level
-        const uint32_t kind = uni(c0.y), node = uni(c0.z), lvw = uni(c0.w);
+        const uint2 rq = wide_poll_change(s.ctl + KDB_W_MB_SEQ, seen);
+        seen = rq.x;
+        const uint32_t kind = rq.y & 3u, node = rq.y >> 2;
         if (kind == KDB_W_EXIT) {
-            if (lane == 0) {
-                s.ctl[KDB_W_ROWS_N] = KDB_W_N_EXIT;
-                wide_release();
-                wide_store(s.ctl + KDB_W_ROWS_SEQ, seen);
-            }
+            if (lane == 0) wide_post(s.ctl + KDB_W_ROWS_SEQ, seen, KDB_W_N_EXIT);
             return;
         }
-        const float qnorm = __uint_as_float(uni(s.ctl[KDB_W_QNORM]));
         uint32_t n = 0u;
         KDB_T(const unsigned long long tv0 = __builtin_readcyclecounter();)
         if (kind == KDB_W_BEGIN) { // a layer search starts (:2461-2489): clear the set, mark the entry point, score it if asked
-            const int level = (int)(lvw & 0xffu);
+            lvw = uni(s.ctl[KDB_W_LEVEL]);
+            level = (int)(lvw & 0xffu);
             vis.begin_layer(level > 0);
             (void)vis.test_and_set(node, lane == 0);
             if (lvw & 0x100u) {
@@ -389,9 +395,9 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
                 n = 1u;
             }
             pf_node = 0u;
+            allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_W_ALLOW_HI]) << 32) | uni(s.ctl[KDB_W_ALLOW_LO]));
+            qnorm = __uint_as_float(uni(s.ctl[KDB_W_QNORM]));
         } else {
-            const int level = (int)lvw;
-            const uint32_t *allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_W_ALLOW_HI]) << 32) | uni(s.ctl[KDB_W_ALLOW_LO]));
             uint32_t nb = 0u;
             bool has_level = true;
             if (level == 0) {
@@ -414,17 +420,13 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
             }
         }
         KDB_T(if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(s.ctl + 12), __builtin_readcyclecounter() - tv0); if (kind == KDB_W_VISIT && node == pf_node) atomicAdd(s.ctl + 14, 1u); })
-        if (lane == 0) {
-            s.ctl[KDB_W_ROWS_N] = n;
-            wide_release();
-            wide_store(s.ctl + KDB_W_ROWS_SEQ, seen);
-        }
+        if (lane == 0) wide_post(s.ctl + KDB_W_ROWS_SEQ, seen, n);
         if (n != 0u && n != KDB_W_N_SKIP) wide_rows_share<PREC, METRIC, NCH, WIDE>(v, s, n, qnorm, 0u);
         wide_release();
         if (lane == 0) atomicAdd(s.ctl + KDB_W_DONE, 1u);
         // the hint (wave 0 posts it once it has popped the node in work): request that list now, it is in a register by the
         // time the next VISIT arrives
-        pf_node = uni(wide_load(s.ctl + KDB_W_NEXT2));
+        pf_node = level == 0 ? uni(wide_load(s.ctl + KDB_W_NEXT2)) : 0u;
         if (pf_node > v.count) pf_node = 0u;
         pf_nb = (pf_node != 0u && lane < v.deg0) ? v.adj0[(size_t)pf_node * v.deg0 + lane] : 0u;
     }
@@ -434,8 +436,9 @@ template <int PREC, int METRIC, int NCH, int WIDE>
 __device__ void wide_rows_loop(const KdbView &v, const WaveLds &s, uint32_t wave) {
     uint32_t seen = 0u;
     for (;;) {
-        seen = wide_poll_change(s.ctl + KDB_W_ROWS_SEQ, seen);
-        const uint32_t n = uni(s.ctl[KDB_W_ROWS_N]);
+        const uint2 rw = wide_poll_change(s.ctl + KDB_W_ROWS_SEQ, seen);
+        seen = rw.x;
+        const uint32_t n = rw.y;
         if (n == KDB_W_N_EXIT) return;
         if (n != 0u && n != KDB_W_N_SKIP) wide_rows_share<PREC, METRIC, NCH, WIDE>(v, s, n, __uint_as_float(uni(s.ctl[KDB_W_QNORM])), wave - 1u);
         wide_release();
@@ -833,6 +836,7 @@ struct VisBitset {
 
 struct VisHash { // hybrid: LDS hash set that migrates into the wave's HBM bitset if it fills up
     uint32_t *tab;   // LDS, `size` words, 0 = empty, else node id
+    uint32_t full_size; // words available (power of two); upper layers (ef = 1: a few dozen ids) use and clear 1024 of them
     uint32_t size;   // power of two
     uint32_t shift;  // 32 - log2(size)
     uint32_t n, limit;
@@ -849,7 +853,10 @@ struct VisHash { // hybrid: LDS hash set that migrates into the wave's HBM bitse
         wave_lds_fence();
     }
     __device__ __forceinline__ void begin_query() {}
-    __device__ __forceinline__ void begin_layer(bool) { // BitSet.Clear per layer call (bitset.go:44-48)
+    __device__ __forceinline__ void begin_layer(bool upper) { // BitSet.Clear per layer call (bitset.go:44-48)
+        size = (upper && full_size > 1024u) ? 1024u : full_size;
+        shift = 32u - (uint32_t)__builtin_ctz(size);
+        limit = size - size / 8u - 64u; // probing stays short; room for one more hop
         in_bits = false;
         bs.record = false;
         bs.n_marks = 0;
@@ -1241,7 +1248,8 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
     nr.bind(s);
     if (lane == 0) s.ctl[KDB_W_NEXT2] = 0u;
     // entry point (:2461-2489): wave 1 clears the visited set, marks it and -- unless its distance is known -- scores it
-    wide_request<WIDE>(s, wc, KDB_W_BEGIN, ep, (uint32_t)level | (epk.known ? 0u : 0x100u));
+    if (lane == 0) s.ctl[KDB_W_LEVEL] = (uint32_t)level | (epk.known ? 0u : 0x100u);
+    wide_request<WIDE>(s, wc, KDB_W_BEGIN, ep);
     (void)wide_wait(s, wc);
     const float ep_key = epk.known ? epk.key : unif(s.nb_d[0]);
     const uint32_t ep_lo = epk.known ? epk.lo : (WK ? uni(s.nb_lo[0]) : 0u);
@@ -1263,7 +1271,7 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
         uint32_t cur;
         if (!pop_candidate(b, nr, ef, cur)) break;
-        if (!asked) wide_request<WIDE>(s, wc, KDB_W_VISIT, cur, (uint32_t)level);
+        if (!asked) wide_request<WIDE>(s, wc, KDB_W_VISIT, cur);
         asked = false;
         { // hint for wave 1: the entry behind the node in work (cur is marked: the first pending entry)
             const uint32_t h = b.first_pending();
@@ -1309,7 +1317,7 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
                     if (__builtin_popcountll(at) == 1) nxt = readlane_u(my_id, (uint32_t)__builtin_ctzll(at));
                 }
                 if (nxt) {
-                    wide_request<WIDE>(s, wc, KDB_W_VISIT, nxt, (uint32_t)level);
+                    wide_request<WIDE>(s, wc, KDB_W_VISIT, nxt);
                     asked = true;
                 }
             }

@@ -103,9 +103,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     typename VisSel<VIS>::type vis;
     if constexpr (VIS == 1) {
         vis.tab = s.marks;
-        vis.size = vis_size;
-        vis.shift = 32u - (uint32_t)__builtin_ctz(vis_size);
-        vis.limit = vis_size - vis_size / 8 - 64u; // probing stays short; room for one more hop
+        vis.full_size = vis_size; // (size / shift / limit: set per layer by begin_layer)
         vis.bs.bits = visited_pool + (size_t)blockIdx.x * v.vis_words;
         vis.bs.words = v.vis_words;
         vis.bs.marks = nullptr;
@@ -251,7 +249,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         tot_dropped += ctr.n_dropped;
         wave_lds_fence();
     }
-    if constexpr (WIDE > 1) wide_request<WIDE>(s, wc, KDB_W_EXIT, 0u, 0u);
+    if constexpr (WIDE > 1) wide_request<WIDE>(s, wc, KDB_W_EXIT, 0u);
     if (lane == 0 && gctr) {
         atomicAdd(&gctr[0], tot_dist);
         atomicAdd(&gctr[1], tot_hops);
@@ -623,12 +621,18 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // wave 0 inserts (search_layer_wide); same walk, same results, same counters -- as long as every query gets its own
         // resident workgroup (512 at 768-d float32)
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
+        static const int wide2_env = [] { const char *e = getenv("KDB_WIDE2_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
-            auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
             const size_t wlds = lds1 + 64 + 512 + (size_t)(hsize_w - hsize) * 4;
+            auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
             if (B <= wide_max) return launch(wk, hsize_w, 4u);
+            // twice as many queries than that: two waves per query -- the walker and one wave that prepares nodes and evaluates rows
+            auto wk2 = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 2>;
+            if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+            const uint32_t wide2_max = wide2_env >= 0 ? (uint32_t)wide2_env : ncu * (uint32_t)occupancy_blocks(wk2, 128, wlds);
+            if (B <= wide2_max) return launch(wk2, hsize_w, 2u);
         }
     }
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
