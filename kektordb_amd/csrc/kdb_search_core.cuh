@@ -397,7 +397,8 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
             pf_node = 0u;
             allow = reinterpret_cast<const uint32_t *>(((unsigned long long)uni(s.ctl[KDB_W_ALLOW_HI]) << 32) | uni(s.ctl[KDB_W_ALLOW_LO]));
             qnorm = __uint_as_float(uni(s.ctl[KDB_W_QNORM]));
-        } else {
+        }
+        if (kind == KDB_W_VISIT || (lvw & 0x300u) == 0x200u) { // (a BEGIN whose entry distance is known goes straight on to the entry point's list: it is the first pop)
             uint32_t nb = 0u;
             bool has_level = true;
             if (level == 0) {
@@ -1248,9 +1249,11 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
     nr.bind(s);
     if (lane == 0) s.ctl[KDB_W_NEXT2] = 0u;
     // entry point (:2461-2489): wave 1 clears the visited set, marks it and -- unless its distance is known -- scores it
-    if (lane == 0) s.ctl[KDB_W_LEVEL] = (uint32_t)level | (epk.known ? 0u : 0x100u);
+    // (with the distance known, the same request also visits the entry point: whatever it is -- a result or, filtered out
+    // or deleted, a traversal-only candidate -- it is the only candidate and therefore the first pop)
+    if (lane == 0) s.ctl[KDB_W_LEVEL] = (uint32_t)level | (epk.known ? 0x200u : 0x100u);
     wide_request<WIDE>(s, wc, KDB_W_BEGIN, ep);
-    (void)wide_wait(s, wc);
+    if (!epk.known) (void)wide_wait(s, wc);
     const float ep_key = epk.known ? epk.key : unif(s.nb_d[0]);
     const uint32_t ep_lo = epk.known ? epk.lo : (WK ? uni(s.nb_lo[0]) : 0u);
     ctr.n_dist++;
@@ -1265,7 +1268,7 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
             b.trim(ef);
         }
     }
-    bool asked = false; // the node the next pop yields is already in work
+    bool asked = epk.known; // the node the next pop yields is already in work
     KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
     for (;;) {
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
