@@ -23,6 +23,9 @@
 #ifndef KDB_F32_DUAL
 #define KDB_F32_DUAL 1
 #endif
+#ifndef KDB_WIDE4_ROWS
+#define KDB_WIDE4_ROWS 1 // rows per 16-lane group and trip of a helper wave of the four-wave mode (three helpers: 12 rows per trip)
+#endif
 #ifndef KDB_F16_ROWS
 #define KDB_F16_ROWS 2
 #endif
@@ -363,7 +366,7 @@ __device__ __forceinline__ void wide_rows_share(const KdbView &v, const WaveLds 
     s2.nb_id = s.nb_id + lo;
     s2.nb_d = s.nb_d + lo;
     if (s.nb_lo) s2.nb_lo = s.nb_lo + lo;
-    compute_dists<PREC, METRIC, NCH, (WIDE > 2 ? 2 : 0)>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
+    compute_dists<PREC, METRIC, NCH, (WIDE > 2 ? KDB_WIDE4_ROWS : 0)>(v, s2, n - lo < chunk ? n - lo : chunk, qnorm);
 }
 // wave 1
 template <int PREC, int METRIC, int NCH, int WIDE, class VisT>

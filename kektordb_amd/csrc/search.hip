@@ -48,14 +48,18 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #ifndef KDB_F32_MINW
 #define KDB_F32_MINW 2 // measured: 2 waves/SIMD without spills equal 3 at ef=64 and win 4-5 % at ef 128-200
 #endif
+#ifndef KDB_WIDE4_MINW
+#define KDB_WIDE4_MINW 4 // waves per SIMD the four-wave kernels are compiled for (0 = as the one-wave kernels): measured 1M x 768,
+                         // 118 VGPRs, one row per 16-lane group and trip: 1 / 64 queries 0.150 / 0.305 -> 0.145 / 0.298 ms against 2 rows, 158 VGPRs
+#endif
 #ifndef KDB_SEARCH_MINW
 #define KDB_SEARCH_MINW 4
 #endif
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
-// WIDE > 1: latency mode, WIDE waves per query (see dists() in kdb_search_core.cuh).
+// WIDE > 1: latency mode, WIDE waves per query (search_layer_wide in kdb_search_core.cuh).
 template <int PREC, int METRIC, int NCH, int BS, int VIS, int WIDE = 1>
-__global__ void __launch_bounds__(64 * WIDE, (PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64 * WIDE, (WIDE == 4 && KDB_WIDE4_MINW ? KDB_WIDE4_MINW : PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,

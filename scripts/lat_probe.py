@@ -1,6 +1,6 @@
 """Latency regime of the graph search (1M x 768 clustered, ef=60): batches of 1 ... 8192 queries on ONE stream, kernel time
-(HIP events of the library) and whole-call time, with the on-chip neighbour-list cache off / on (KDB_WIDE_LISTS, read per
-call).  Prints a signature of ids + distance bits + walk counters per setting: they must not depend on it."""
+(HIP events of the library), back-to-back calls and single calls.  Prints a signature of ids + distance bits + walk counters
+(compare builds on ONE box: KEKTOR_HIP_LIB selects another build of the library)."""
 import hashlib
 import os
 import sys
@@ -27,8 +27,7 @@ t0 = time.time()
 idx.build(n, batch=16384, ef_construction=200, seed=1)
 print(f"build {time.time() - t0:.1f}s", flush=True)
 Bs = [int(x) for x in os.environ.get("LAT_BS", "1,8,64,256,512,1024,2048,8192").split(",")]
-for lists in os.environ.get("LAT_LISTS", "1").split(","):
-    os.environ["KDB_WIDE_LISTS"] = lists
+for lists in ("-",):
     sig = hashlib.sha1()
     for B in Bs:
         q = Q[:B].contiguous()
@@ -61,6 +60,6 @@ for lists in os.environ.get("LAT_LISTS", "1").split(","):
             idx.search_batch_dev(q, k, ef, oi, od, oc)
             idx.sync()
             lat.append((time.perf_counter() - t0) * 1e3)
-        print(f"lists={lists} B={B:5d}: kernel {ms:.3f} ms, back-to-back {wall:.3f} ms/call ({B / wall * 1e3:9.0f} QPS), single call "
+        print(f"B={B:5d}: kernel {ms:.3f} ms, back-to-back {wall:.3f} ms/call ({B / wall * 1e3:9.0f} QPS), single call "
               f"{np.median(lat):.3f} ms   hops/q mean {nh.float().mean().item():.1f} max {nh.max().item()} dist/q mean {nd.float().mean().item():.1f} max {nd.max().item()}", flush=True)
-    print(f"lists={lists} answers+counters signature {sig.hexdigest()[:16]}", flush=True)
+    print(f"answers+counters signature {sig.hexdigest()[:16]}", flush=True)
