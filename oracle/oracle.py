@@ -259,9 +259,9 @@ class OracleIndex:
         self.L.orc_search_many(handle or self.h, _p(q), nq, k, ef, _p(ids), _p(dist), _p(cnt), C.byref(ctr))
         return ids, dist, cnt, (int(ctr.n_dist), int(ctr.n_hops))
 
-    def search_many_threads(self, queries, k, ef, threads):
+    def search_many_threads(self, queries, k, ef, threads, pin=None):
         """One query per thread across `threads` host threads (ctypes releases the
-        GIL), mirroring the Go server's goroutine-per-request model."""
+        GIL), mirroring the Go server's goroutine-per-request model.  pin: one CPU id per thread."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         nq = q.shape[0]
         threads = max(1, min(threads, nq))
@@ -271,6 +271,11 @@ class OracleIndex:
         bounds = np.linspace(0, nq, threads + 1).astype(int)
 
         def work(t):
+            if pin is not None:
+                try:
+                    os.sched_setaffinity(0, {pin[t % len(pin)]})  # the calling thread
+                except Exception:
+                    pass
             out[t] = self.search_many(q[bounds[t]:bounds[t + 1]], k, ef, handle=self._views[t])
 
         ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
