@@ -20,7 +20,8 @@
  *   kdb_index_upload_graph  Node.Connections (pkg/core/hnsw/hnsw_node.go:13-68) as exported by
  *                           SnapshotData (hnsw_index.go:3064): per-level adjacency, entry point, maxLevel
  *   kdb_index_mark_deleted  Node.Deleted soft delete (hnsw_index.go:2303)
- *   kdb_index_build         addBatchInternal (hnsw_index.go:1479-2088), phases 1-4, on the GPU
+ *   kdb_index_build         addBatchInternal (hnsw_index.go:1479-2088), phases 1-4, on the GPU (fast linking)
+ *   kdb_index_add_batch     the same phases with the reference's own linking: lists equal the restated batch insert's
  *   kdb_merge_topk          the merge step of the id-range shard (no reference
  *                           counterpart -- the reference is single process)
  *   kdb_sharded_search_batch  the same path over every GPU of a node from ONE process: fan-out,
@@ -264,6 +265,22 @@ KDB_API int kdb_index_get_quantizer(kdb_index *idx, float *abs_max);
 
 /* GPU batched graph construction over rows 1..count already uploaded.                             */
 KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
+
+/* AddBatch -> addBatchInternal (hnsw_index.go:1479-2088) for rows ALREADY uploaded at ids first_id .. first_id+n-1 (phase 0 /
+ * 1B of the reference = kdb_index_upload_rows [+ norms]): phase 1 (every new node searches the graph as the batch found it),
+ * phases 2-3 linked EXACTLY as the reference links them -- a request for all efConstruction candidates and a reverse request to
+ * each of them, per target the sorted de-duplicated union, stored as it is (ascending ids) up to maxM entries, else scored,
+ * sorted by (distance, id) and pruned by selectNeighbors -- and phase 4 (entry point / maxLevel).  The lists equal those of
+ * the restated batch insert (oracle) link for link (tests/test_gpu_build.py); kdb_index_build is the FAST builder (its
+ * linking differs by design).  levels[i] = len(Connections)-1 of node first_id+i as the caller drew it
+ * (randomLevel, :2616-2625; capped at maxLevel+1 like there).  first_id = count+1 appends; first_id = count re-uses the last
+ * slot, which is what the reference's id arithmetic does for the first batch after single Adds (:1620 vs :590).  The index
+ * must hold a graph (the reference inserts its first efConstruction nodes one by one, :1505-1516: upload those).
+ * At most 4096 - mMax0 nodes per call.  KDB_ERR_UNSUPPORTED (lists still consistent) when a re-used slot would have to grow
+ * a level.  float32 / float16 / int8.                                                                              */
+#define KDB_ADD_REFERENCE_LINKS 1u /* (the only linking this entry point has; accepted for symmetry with kdb_build_params.flags) */
+KDB_API int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction,
+                                uint32_t flags);
 
 /* TEST HOOK -- selectNeighbors (hnsw_index.go:2629-2701) exactly as the GPU builder runs it (build_select_kernel's
  * workgroup routine), on caller-supplied candidate lists: list t holds cand_cnt[t] <= stride <= 320 entries at

@@ -357,7 +357,7 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLdsT<typename B
                     nsel++;
                     selmask |= 1u << i;
                 } else {
-                    if (tid == 0) p.disc[ndisc] = (uint16_t)(b0 + i);
+                    if (tid == 0 && ndisc < (uint32_t)PR_MAXSEL) p.disc[ndisc] = (uint16_t)(b0 + i); // (the back-fill never needs more than maxm of them)
                     ndisc++;
                 }
             }
@@ -371,7 +371,7 @@ __device__ void select_neighbors_wg(const KdbView &v, const PruneLdsT<typename B
     }
     if (tid == 0) { // back-fill from the discarded, in order (:2688-2698)
         uint32_t nsel = p.misc[0];
-        const uint32_t ndisc = p.misc[1];
+        const uint32_t ndisc = p.misc[1] < (uint32_t)PR_MAXSEL ? p.misc[1] : (uint32_t)PR_MAXSEL;
         for (uint32_t i = 0; i < ndisc && nsel < maxm; i++) {
             p.s_id[nsel] = p.c_id[p.disc[i]];
             p.s_key[nsel] = p.c_key[p.disc[i]];
@@ -387,6 +387,27 @@ __device__ __forceinline__ bool key_before(KT k1, uint32_t i1, KT k2, uint32_t i
     return (k1 < k2) || (k1 == k2 && i1 < i2);
 }
 
+// task -> (node, level): tasks [0, nb) are the level-0 searches of the batch, the upper ones follow in node order
+template <typename KT>
+__device__ __forceinline__ void task_owner(const BuildViewT<KT> &bv, uint32_t task, uint32_t &node, uint32_t &level) {
+    if (task < bv.nb) {
+        node = bv.first + task;
+        level = 0;
+        return;
+    }
+    // upper task: find owner by binary search over up_task (non-decreasing)
+    const uint32_t ut = task - bv.nb;
+    uint32_t lo = 0, hi = bv.nb - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (bv.up_task[mid] <= ut) lo = mid; else hi = mid - 1;
+    }
+    // several batch nodes without upper levels share the same up_task value: take the one that owns it
+    while (lo + 1 < bv.nb && bv.up_task[lo + 1] <= ut) lo++;
+    node = bv.first + lo;
+    level = ut - bv.up_task[lo] + 1;
+}
+
 // ---- phase 2: new node keeps selectNeighbors(cands); emits reverse requests ---------------------------
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
@@ -397,24 +418,8 @@ build_select_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv) {
     prune_carve(smem, p);
     const int tid = (int)threadIdx.x;
     const uint32_t task = blockIdx.x;
-    // decode task -> (node, level)
     uint32_t node, level;
-    if (task < bv.nb) {
-        node = bv.first + task;
-        level = 0;
-    } else {
-        // upper task: find owner by binary search over up_task (non-decreasing)
-        const uint32_t ut = task - bv.nb;
-        uint32_t lo = 0, hi = bv.nb - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (bv.up_task[mid] <= ut) lo = mid; else hi = mid - 1;
-        }
-        // several batch nodes without upper levels share the same up_task value: take the one that owns it
-        while (lo + 1 < bv.nb && bv.up_task[lo + 1] <= ut) lo++;
-        node = bv.first + lo;
-        level = ut - bv.up_task[lo] + 1;
-    }
+    task_owner(bv, task, node, level);
     const uint32_t n = bv.cand_cnt[task];
     const uint32_t maxm = level == 0 ? v.deg0 : v.deg_up;
     for (uint32_t i = (uint32_t)tid; i < n; i += 256) {
@@ -549,6 +554,257 @@ build_reverse_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t 
         adj[tid] = (uint32_t)tid < nsel ? p.s_id[tid] : 0u;
         akey[tid] = (uint32_t)tid < nsel ? p.s_key[tid] : (KT)0;
     }
+}
+
+// =====================================================================================================================
+// Reference linking (kdb_index_add_batch): phases 2 and 3 of addBatchInternal AS WRITTEN (:1864-2060), so that the lists
+// can be compared with the restated batch insert (oracle: orc_index_add_batch) link for link:
+//   * every new node asks for ALL its efConstruction candidates (direct request), and every candidate gets a reverse
+//     request for the new node (:1869-1889) -- not only the neighbours the node keeps, no cap per target;
+//   * per (target, level): current links + requested ids, sorted, de-duplicated, without the node itself (:1983-2003);
+//     up to maxM of them are stored AS THEY ARE, in ascending id order (:2011-2013); more are scored against the target
+//     (distanceBetweenNodes, nil / deleted candidates dropped), sorted by distance -- the unstable sort's tie order restated
+//     as (distance, id), as in the oracle -- and pruned by selectNeighbors (:2015-2040).
+// A target is one workgroup; its union (<= maxM + batch size entries) is sorted in LDS.
+// =====================================================================================================================
+constexpr uint32_t RL_UCAP = 4096; // union entries per (target, level): batches of at most RL_UCAP - mMax0 nodes
+
+// combined request counters: [0, n1) level-0 targets by id, [n1, n1 + slots] upper targets by slot
+template <typename KT>
+__global__ void __launch_bounds__(256)
+rl_count_kernel(KdbView v, BuildViewT<KT> bv, uint32_t n1, uint32_t *cnt, uint32_t *slot_owner, uint32_t *cursor /* null: count; else fill */,
+                const uint32_t *off, uint32_t *req, uint32_t *err) {
+    const uint32_t task = blockIdx.x;
+    uint32_t node, level;
+    task_owner(bv, task, node, level);
+    const uint32_t n = bv.cand_cnt[task];
+    if (n == 0) return;
+    const uint32_t own = level == 0 ? node : n1 + v.up_idx[node] + (level - 1u);
+    if (threadIdx.x == 0 && !cursor) {
+        atomicAdd(&cnt[own], n); // the direct request: all candidates
+        if (level) slot_owner[own - n1] = node;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t c = bv.cand_id[(size_t)task * bv.efc + i];
+        if (cursor) req[off[own] + atomicAdd(&cursor[own], 1u)] = c;
+        uint32_t code = c;
+        if (level) {
+            // a candidate evaluated at a level above its own: only the slot the reference's batch path re-uses (:1620) can be
+            // one -- the reference then GROWS that node's Connections; the fixed upper slots here cannot: counted, skipped
+            if ((uint32_t)v.levels[c] < level) {
+                if (!cursor) atomicAdd(err, 1u);
+                continue;
+            }
+            code = n1 + v.up_idx[c] + (level - 1u);
+            if (!cursor) slot_owner[code - n1] = c;
+        }
+        if (cursor) req[off[code] + atomicAdd(&cursor[code], 1u)] = node;
+        else atomicAdd(&cnt[code], 1u);
+    }
+}
+// exclusive prefix over the counters; touched targets appended (order irrelevant); out[0] = total, out[1] = n_touched
+__global__ void __launch_bounds__(1024)
+rl_scan_kernel(const uint32_t *cnt, uint32_t L, uint32_t *off, uint32_t *touched, uint32_t *out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < L; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t c = i < L ? cnt[i] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) inc += t;
+        }
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t base = carry + inc - c;
+        for (uint32_t j = 0; j < (threadIdx.x >> 6); j++) base += wsum[j];
+        if (i < L) off[i] = base;
+        if (c) touched[atomicAdd(&out[1], 1u)] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int j = 0; j < 16; j++) t += wsum[j];
+            carry += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = carry;
+}
+
+template <typename T>
+__device__ __forceinline__ void rl_swap(T &a, T &b) { T t = a; a = b; b = t; }
+
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+rl_commit_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const uint32_t *touched, const uint32_t *cnt, const uint32_t *off,
+                 const uint32_t *req, const uint32_t *slot_owner, uint32_t *err) {
+    using KT = typename BKey<PREC>::T;
+    constexpr bool I8 = PREC == KDB_PREC_I8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLdsT<KT> p;
+    prune_carve(smem, p);
+    size_t o = prune_lds_bytes<KT>();
+    KT *u_key = reinterpret_cast<KT *>(smem + o);
+    o += (size_t)RL_UCAP * sizeof(KT);
+    uint32_t *u_id = reinterpret_cast<uint32_t *>(smem + o);
+    o += (size_t)RL_UCAP * 4;
+    uint32_t *u_tmp = reinterpret_cast<uint32_t *>(smem + o); // de-dup scratch
+    o += (size_t)RL_UCAP * 4;
+    float *w_d = reinterpret_cast<float *>(smem + o); // [4][64] distances of a wave's chunk
+    o += 4 * 64 * 4;
+    uint32_t *w_lo = reinterpret_cast<uint32_t *>(smem + o);
+    o += 4 * 64 * 4;
+    float *tq = reinterpret_cast<float *>(smem + o); // the target's row as the query
+    __shared__ uint32_t sh[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t code = touched[blockIdx.x];
+    uint32_t t, level, maxm;
+    uint32_t *adj;
+    if (code < n1) {
+        t = code;
+        level = 0;
+        maxm = v.deg0;
+        adj = adj0 + (size_t)t * v.deg0;
+    } else {
+        const uint32_t ts = code - n1;
+        t = slot_owner[ts];
+        level = ts - v.up_idx[t] + 1u;
+        maxm = v.deg_up;
+        adj = adj_up + (size_t)ts * v.deg_up;
+    }
+    (void)level;
+    if ((v.deleted[t >> 5] >> (t & 31u)) & 1u) return; // "node == nil || node.Deleted: skip" (:1927-1930)
+    const uint32_t nreq = cnt[code];
+    if (tid == 0) {
+        uint32_t ne = 0;
+        while (ne < maxm && adj[ne] != 0u) ne++;
+        sh[0] = ne;
+    }
+    __syncthreads();
+    const uint32_t ne = sh[0], nu = ne + nreq;
+    if (nu > RL_UCAP) {
+        if (tid == 0) atomicAdd(err + 1, 1u);
+        return;
+    }
+    uint32_t P = 64;
+    while (P < nu) P <<= 1;
+    for (uint32_t i = tid; i < P; i += 256) u_id[i] = i < ne ? adj[i] : i < nu ? req[off[code] + (i - ne)] : 0xffffffffu;
+    __syncthreads();
+    // slices.Sort(uniqueIDs) (:1985)
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0u;
+                    uint32_t x = u_id[i], y = u_id[l];
+                    if ((x > y) == up) {
+                        u_id[i] = y;
+                        u_id[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // de-duplication without the node itself (:1987-2003); candidates that are nil or deleted never reach the prune
+    // (:2019-2024) -- but they DO count for "uniqCount <= maxM" and are stored then, exactly as the reference does
+    auto compact = [&](bool drop_deleted) -> uint32_t { // u_id[0..P) sorted -> u_tmp[0..nq) ; returns nq
+        if (tid == 0) sh[1] = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < P; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            const uint32_t x = i < P ? u_id[i] : 0xffffffffu;
+            bool keep = x != 0xffffffffu && x != t && (i == 0 || u_id[i - 1] != x);
+            if (keep && drop_deleted) keep = !((v.deleted[x >> 5] >> (x & 31u)) & 1u) && x <= v.count;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) sh[4 + wave] = (uint32_t)__builtin_popcountll(m);
+            __syncthreads();
+            uint32_t base = sh[1];
+            for (uint32_t w = 0; w < wave; w++) base += sh[4 + w];
+            if (keep) u_tmp[base + kdb_mbcnt(m)] = x;
+            __syncthreads();
+            if (tid == 0) sh[1] += sh[4] + sh[5] + sh[6] + sh[7];
+            __syncthreads();
+        }
+        return sh[1];
+    };
+    const uint32_t nq = compact(false);
+    if (nq <= maxm) { // the union as it is: ascending ids (:2011-2013)
+        if (tid < maxm) adj[tid] = tid < nq ? u_tmp[tid] : 0u;
+        return;
+    }
+    __syncthreads();
+    const uint32_t np = compact(true); // the candidates of the prune
+    __syncthreads();
+    // distanceBetweenNodes(node, candidate) (:297-340): the target's stored row is the query, 16 lanes per candidate row
+    float qnorm = 1.f;
+    if (I8) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const int8_t *>(v.rows) + (size_t)t * v.ld);
+        for (uint32_t i = tid; i < (v.ld >> 4); i += 256) reinterpret_cast<uint4 *>(tq)[i] = src[i];
+        qnorm = v.norms[t]; // (a zero norm on either side: distance 1 -- the dot with a zero row is 0, and 1 - 0 / (1 * n) = 1)
+        if (qnorm == 0.f) qnorm = 1.f;
+    } else if (PREC == KDB_PREC_F16) {
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)t * v.ld;
+        for (uint32_t i = tid; i < v.ld; i += 256) tq[i] = (float)__builtin_bit_cast(_Float16, src[i]);
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(v.rows) + (size_t)t * v.ld);
+        for (uint32_t i = tid; i < (v.ld >> 2); i += 256) reinterpret_cast<float4 *>(tq)[i] = src[i];
+    }
+    for (uint32_t i = tid; i < np; i += 256) u_id[i] = u_tmp[i];
+    __syncthreads();
+    {
+        WaveLds s{};
+        s.q = tq;
+        s.nb_d = w_d + wave * 64u;
+        s.nb_lo = I8 ? w_lo + wave * 64u : nullptr;
+        for (uint32_t c0 = wave * 64u; c0 < np; c0 += 256u) {
+            const uint32_t cn = np - c0 < 64u ? np - c0 : 64u;
+            s.nb_id = u_id + c0;
+            compute_dists<PREC, METRIC, 0>(v, s, cn, qnorm);
+            if (lane < cn) {
+                if constexpr (I8) u_key[c0 + lane] = kdb_i8_key_double(s.nb_d[lane], s.nb_lo[lane]);
+                else u_key[c0 + lane] = s.nb_d[lane];
+            }
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    uint32_t P2 = 64;
+    while (P2 < np) P2 <<= 1;
+    for (uint32_t i = np + tid; i < P2; i += 256) {
+        u_key[i] = (KT)INFINITY;
+        u_id[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    // slices.SortFunc by distance (:2026-2034); equal distances: by id (the restated tie order)
+    for (uint32_t k = 2; k <= P2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P2; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0u;
+                    const KT kx = u_key[i], ky = u_key[l];
+                    const uint32_t ix = u_id[i], iy = u_id[l];
+                    const bool gt = kx > ky || (kx == ky && ix > iy);
+                    if (gt == up) {
+                        u_key[i] = ky;
+                        u_key[l] = kx;
+                        u_id[i] = iy;
+                        u_id[l] = ix;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    p.c_id = u_id;
+    p.c_key = u_key;
+    select_neighbors_wg<METRIC, PREC>(v, p, np, maxm);
+    const uint32_t nsel = p.misc[0];
+    if (tid < maxm) adj[tid] = tid < nsel ? p.s_id[tid] : 0u;
 }
 
 // ---- test hook: selectNeighbors on caller-supplied candidate lists (kdb_test_select_neighbors) -----------------------
@@ -755,6 +1011,147 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     return KDB_OK;
 }
 
+// addBatchInternal for rows already in place (phases 1-4), reference linking.  idx->count etc. are updated on success.
+template <int METRIC, int PREC>
+int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_t *lv_in, uint32_t efc) {
+    using KT = typename BKey<PREC>::T;
+    constexpr size_t KB = sizeof(KT);
+    hipStream_t s = idx->stream;
+    const uint32_t new_count = first + nb - 1u;
+    const int frozen_max = idx->max_level;
+    // ---- phase 1B bookkeeping: levels (randomLevel's own cap, :2620-2623, against the maxLevel the batch started with) and
+    //      upper slots of the new nodes; a node that takes over a slot (first == count, :1620) gets fresh ones
+    std::vector<uint8_t> lv(nb);
+    std::vector<uint32_t> up_new(nb), up_task(nb);
+    size_t slots = idx->up_slots;
+    uint32_t nup = 0;
+    for (uint32_t i = 0; i < nb; i++) {
+        int l = lv_in[i];
+        if (l > frozen_max + 1) l = frozen_max + 1;
+        lv[i] = (uint8_t)l;
+        up_new[i] = (uint32_t)slots;
+        slots += (size_t)l;
+        up_task[i] = nup;
+        nup += (uint32_t)(l < frozen_max ? l : frozen_max); // links only up to the current top (:1829)
+    }
+    if (slots > idx->up_slots_cap || !idx->d_adj_up) { // grow the upper pool, keep what it holds
+        const size_t ncap = slots + slots / 2 + 1024;
+        uint32_t *nbuf = nullptr;
+        KDB_HIP(hipMalloc(&nbuf, (ncap * idx->deg_up + 4) * 4));
+        KDB_HIP(hipMemsetAsync(nbuf, 0, (ncap * idx->deg_up + 4) * 4, s));
+        if (idx->d_adj_up && idx->up_slots) KDB_HIP(hipMemcpyAsync(nbuf, idx->d_adj_up, idx->up_slots * idx->deg_up * 4, hipMemcpyDeviceToDevice, s));
+        KDB_HIP(hipStreamSynchronize(s));
+        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
+        idx->d_adj_up = nbuf;
+        idx->up_slots_cap = ncap;
+    } else if (slots > idx->up_slots) {
+        KDB_HIP(hipMemsetAsync(idx->d_adj_up + idx->up_slots * idx->deg_up, 0, (slots - idx->up_slots) * idx->deg_up * 4, s));
+    }
+    KDB_HIP(hipMemsetAsync(idx->d_adj0 + (size_t)first * idx->deg0, 0, (size_t)nb * idx->deg0 * 4, s)); // empty Connections (:1742)
+    KDB_HIP(hipMemcpyAsync(idx->d_levels + first, lv.data(), nb, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(idx->d_up_idx + first, up_new.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    idx->h_levels.resize((size_t)new_count + 1);
+    idx->h_up_idx.resize((size_t)new_count + 1);
+    for (uint32_t i = 0; i < nb; i++) {
+        idx->h_levels[first + i] = lv[i];
+        idx->h_up_idx[first + i] = up_new[i];
+    }
+    idx->up_slots = slots;
+    idx->count = new_count;
+    // ---- workspace
+    const size_t n1 = (size_t)idx->cap + 1;
+    const size_t L = n1 + slots + 1;
+    const uint32_t n_tasks = nb + nup;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_ckey = take((size_t)n_tasks * efc * KB), o_cid = take((size_t)n_tasks * efc * 4), o_ccnt = take((size_t)n_tasks * 4);
+    const size_t o_uptask = take((size_t)nb * 4 + 64), o_cnt = take(L * 4), o_off = take(L * 4), o_cur = take(L * 4);
+    const size_t o_owner = take((slots + 1) * 4), o_touch = take(L * 4), o_out = take(256);
+    const size_t req_max = (size_t)n_tasks * efc * 2;
+    const size_t o_req = take(req_max * 4 + 64);
+    if (idx->build_bytes < off) {
+        if (idx->d_build) KDB_HIP(hipFree(idx->d_build));
+        idx->d_build = nullptr;
+        idx->build_bytes = 0;
+        KDB_HIP(hipMalloc(&idx->d_build, off));
+        idx->build_bytes = off;
+    }
+    unsigned char *w = reinterpret_cast<unsigned char *>(idx->d_build);
+    BuildViewT<KT> bv{};
+    bv.adj0 = idx->d_adj0;
+    bv.adj_up = idx->d_adj_up;
+    bv.cand_id = reinterpret_cast<uint32_t *>(w + o_cid);
+    bv.cand_key = reinterpret_cast<KT *>(w + o_ckey);
+    bv.cand_cnt = reinterpret_cast<uint32_t *>(w + o_ccnt);
+    bv.up_task = reinterpret_cast<uint32_t *>(w + o_uptask);
+    bv.efc = efc;
+    bv.first = first;
+    bv.nb = nb;
+    bv.n_tasks = n_tasks;
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(w + o_cnt), *d_off = reinterpret_cast<uint32_t *>(w + o_off);
+    uint32_t *d_cur = reinterpret_cast<uint32_t *>(w + o_cur), *d_owner = reinterpret_cast<uint32_t *>(w + o_owner);
+    uint32_t *d_touch = reinterpret_cast<uint32_t *>(w + o_touch), *d_out = reinterpret_cast<uint32_t *>(w + o_out);
+    uint32_t *d_req = reinterpret_cast<uint32_t *>(w + o_req);
+    KDB_HIP(hipMemcpyAsync(bv.up_task, up_task.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemsetAsync(bv.cand_cnt, 0, (size_t)n_tasks * 4, s));
+    KDB_HIP(hipMemsetAsync(d_cnt, 0, L * 4, s));
+    KDB_HIP(hipMemsetAsync(d_cur, 0, L * 4, s));
+    KDB_HIP(hipMemsetAsync(d_out, 0, 256, s));
+    KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
+    // ---- phase 1: every new node searches the graph as it was (entry point / maxLevel frozen, :1796-1801)
+    const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
+    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4;
+    const int bs = kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
+    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
+    if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
+    const uint32_t slots_vis = (uint32_t)idx->n_cu * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
+    int rc = kdb_ensure_visited(idx, slots_vis, s);
+    if (rc) return rc;
+    KdbView v = kdb_make_view(idx); // count = new_count: the new ids are valid wherever a walk meets them (the re-used slot)
+    hipLaunchKernelGGL(ksearch, dim3(slots_vis < nb ? slots_vis : nb), dim3(64), lds_search, s, v, bv, beam_cap, idx->d_visited, idx->d_work);
+    KDB_HIP(hipGetLastError());
+    // ---- phases 2 + 3
+    hipLaunchKernelGGL((rl_count_kernel<KT>), dim3(n_tasks), dim3(256), 0, s, v, bv, (uint32_t)n1, d_cnt, d_owner, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (uint32_t *)nullptr, d_out + 2);
+    hipLaunchKernelGGL(rl_scan_kernel, dim3(1), dim3(1024), 0, s, d_cnt, (uint32_t)L, d_off, d_touch, d_out);
+    hipLaunchKernelGGL((rl_count_kernel<KT>), dim3(n_tasks), dim3(256), 0, s, v, bv, (uint32_t)n1, d_cnt, d_owner, d_cur, d_off, d_req, d_out + 2);
+    KDB_HIP(hipGetLastError());
+    uint32_t out[4] = {0, 0, 0, 0};
+    KDB_HIP(hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    if (out[0] > req_max) {
+        kdb_set_error("add_batch: request overflow");
+        return KDB_ERR_STATE;
+    }
+    if (out[1]) {
+        const size_t lds_commit = prune_lds_bytes<KT>() + (size_t)RL_UCAP * (KB + 8) + 2048 + (size_t)idx->ld * 4 + 64;
+        auto kc = rl_commit_kernel<METRIC, PREC>;
+        KDB_HIP(hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_commit));
+        hipLaunchKernelGGL(kc, dim3(out[1]), dim3(256), lds_commit, s, v, idx->d_adj0, idx->d_adj_up, (uint32_t)n1, d_touch, d_cnt, d_off, d_req, d_owner,
+                           d_out + 2);
+        KDB_HIP(hipGetLastError());
+    }
+    KDB_HIP(hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    // ---- phase 4: entry point / maxLevel (:2066-2080)
+    for (uint32_t i = 0; i < nb; i++)
+        if ((int)lv[i] > idx->max_level) {
+            idx->max_level = (int)lv[i];
+            idx->entry = first + i;
+        }
+    if (out[3]) {
+        kdb_set_error("add_batch: a target's union of links and requests exceeded %u entries (%u targets skipped): use smaller batches", RL_UCAP, out[3]);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    if (out[2]) {
+        kdb_set_error("add_batch: %u requests asked a node for a level above its own (the slot the reference's batch path re-uses, "
+                      "hnsw_index.go:1620, after its level changed): the reference grows that node, the fixed upper slots here cannot; skipped", out[2]);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    return KDB_OK;
+}
+
 } // namespace
 
 // d_keys: float keys for float32 / float16 indexes, DOUBLE distances for int8 indexes (the reference's float64)
@@ -805,4 +1202,30 @@ int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p) {
         idx->h_up_idx.clear();
     }
     return rc;
+}
+
+// addBatchInternal (hnsw_index.go:1479-2088) for rows ALREADY uploaded at ids first_id .. first_id+n-1, linked exactly as the
+// reference links them (see "Reference linking" above).  levels: len(Connections)-1 of every new node as drawn by the caller
+// (randomLevel, :2616-2625).  first_id = count+1 appends; first_id = count re-uses the last node's slot, which is what the
+// reference's id arithmetic does for the first batch after single Adds (:1620, :590).
+int kdb_add_batch_ref(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction) {
+    const uint32_t efc = ef_construction ? ef_construction : idx->desc.ef_construction;
+    if (!idx->has_graph || idx->max_level < 0 || idx->h_levels.size() != (size_t)idx->count + 1) {
+        kdb_set_error("add_batch: the index needs a graph to add to (upload or build one: the reference inserts its first efConstruction nodes one by one, hnsw_index.go:1505-1516)");
+        return KDB_ERR_STATE;
+    }
+    if (n == 0) return KDB_OK;
+    if (!levels || (first_id != idx->count && first_id != idx->count + 1) || first_id == 0 || (uint64_t)first_id + n - 1 > idx->cap) {
+        kdb_set_error("add_batch: ids must start at count (%u, re-using the last slot) or count+1 and stay within capacity %u", idx->count, idx->cap);
+        return KDB_ERR_INVALID;
+    }
+    if (efc < 1 || efc > 256 || idx->deg0 > PR_MAXSEL || n + idx->deg0 > RL_UCAP) {
+        kdb_set_error("add_batch: ef_construction in 1..256, mMax0 <= %d, at most %u nodes per batch", PR_MAXSEL, RL_UCAP - idx->deg0);
+        return KDB_ERR_UNSUPPORTED;
+    }
+    KDB_HIP(hipDeviceSynchronize()); // walks of callers' streams may still read the lists this call rewrites
+    if (idx->desc.precision == KDB_PREC_F16) return add_batch_ref_impl<KDB_METRIC_L2, KDB_PREC_F16>(idx, first_id, n, levels, efc);
+    if (idx->desc.precision == KDB_PREC_I8) return add_batch_ref_impl<KDB_METRIC_COSINE, KDB_PREC_I8>(idx, first_id, n, levels, efc);
+    return idx->desc.metric == KDB_METRIC_COSINE ? add_batch_ref_impl<KDB_METRIC_COSINE, KDB_PREC_F32>(idx, first_id, n, levels, efc)
+                                                 : add_batch_ref_impl<KDB_METRIC_L2, KDB_PREC_F32>(idx, first_id, n, levels, efc);
 }

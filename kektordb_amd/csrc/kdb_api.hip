@@ -1201,6 +1201,20 @@ extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_p
     return kdb_build_graph(idx, count, params);
 }
 
+extern "C" int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction,
+                                   uint32_t flags) {
+    KDB_CHECK_IDX(idx);
+    if (flags & ~KDB_ADD_REFERENCE_LINKS) {
+        kdb_set_error("add_batch: unknown flag");
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    KdbLaneGuard lane(idx, idx->stream);
+    if (lane.rc) return lane.rc;
+    return kdb_add_batch_ref(idx, first_id, n, levels, ef_construction);
+}
+
 // test hook (see kektor_hip.h): host buffers in, selections out
 extern "C" int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *cand_ids,
                                          const void *cand_keys, const uint32_t *cand_cnt, uint32_t maxm, uint32_t *out_ids,

@@ -195,5 +195,6 @@ int kdb_launch_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t
                               hipStream_t s);
 // build.hip
 int kdb_build_graph(kdb_index *idx, uint32_t count, const kdb_build_params *p);
+int kdb_add_batch_ref(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction);
 int kdb_select_probe(kdb_index *idx, uint32_t n_lists, uint32_t stride, const uint32_t *d_ids, const void *d_keys,
                      const uint32_t *d_cnt, uint32_t maxm, uint32_t *d_out_ids, uint32_t *d_out_cnt, hipStream_t s);

@@ -186,6 +186,12 @@ class HipIndex:
         p = _lib.BuildParams(batch, ef_construction, seed, 0, 0)
         check(self.L.kdb_index_build(self.h, int(count), C.byref(p)), "kdb_index_build")
 
+    def add_batch(self, first_id: int, levels, ef_construction: int = 0):
+        """AddBatch (addBatchInternal, hnsw_index.go:1479-2088) for rows already uploaded at first_id.., linked as the
+        reference links them (kdb_index_add_batch); levels: one per new node"""
+        lv = np.ascontiguousarray(levels, dtype=np.uint8)
+        check(self.L.kdb_index_add_batch(self.h, int(first_id), lv.size, _ptr(lv), int(ef_construction), 1), "kdb_index_add_batch")
+
     def test_select_neighbors(self, cand_ids, cand_keys, cand_cnt, maxm: int):
         """TEST HOOK: the GPU builder's selectNeighbors on caller-supplied lists ([n_lists, stride] ids / ascending keys;
         keys are float32 ordering keys, or -- int8 indexes -- the float64 distances)"""
