@@ -11,7 +11,13 @@
  *       distance is the reference's fine-grained FFI; the GPU path replaces it with the
  *       batched kdb_distance_batch / kdb_search_batch of kektor_hip.h.  They exist here for link compatibility and
  *       for the CPU-side callers the shim does not move to the GPU (e.g. Add / selectNeighbors while the writers
- *       stay in Go); the bit patterns are those of the Rust crate.
+ *       stay in Go).  The three float routines return the bit patterns of the Rust crate (same lanes, same fold).
+ *       dot_product_i8 returns the FULL integer dot product -- the value the reference's default build computes
+ *       (dotProductGoInt8, pkg/core/distance/distance_go.go:107-116) and its own tests pin (lib.rs:446-458, short
+ *       vectors).  DELIBERATE DEVIATION from the crate's AVX2 path for len >= 32: its horizontal reduction
+ *       (lib.rs:171-176: `(hi64 + lo64) as i32` over the two 64-bit halves of the folded 128-bit sum) keeps only the 32-bit
+ *       lanes 0 and 2 and so drops half of the partial sums; that is a defect of the crate, not an order of summation,
+ *       and it is not reproduced (tests/test_compute_legacy.py states the same).
  *   kektordb_embed_init / kektordb_embed / kektordb_embed_batch / kektordb_free_embedding / kektordb_free_embeddings /
  *   kektordb_embed_destroy
  *       native/compute/include/kektordb_compute.h:14-24 (ONNX embedder, native/compute/src/embedder.rs): OUT OF SCOPE

@@ -7,7 +7,9 @@
 //              half, then upper pair onto lower pair, then lane 1 onto lane 0 (lib.rs:22-31); the remaining < 8
 //              elements are added one by one, each product rounded before the add (lib.rs:52-71: no FMA there).
 //   int8:      32-element blocks widened to i16, pairwise products summed into eight i32 lanes (madd), lanes folded;
-//              exact integer arithmetic, so any order gives the same i32 (wrap-around included).
+//              exact integer arithmetic, so any order gives the same i32 (wrap-around included).  NOT the crate's value for
+//              len >= 32 on AVX2: its reduction (lib.rs:171-176) sums only lanes 0 and 2 of the folded vector -- a defect, not
+//              reproduced (kektor_compute_legacy.h); the default Go build's dotProductGoInt8 is the reference value.
 //   CPUs without FMA (+F16C for the half routine) / AVX2 take the scalar loops of lib.rs:315-346.
 // No GPU, no oracle: plain C++ with target attributes and a run-time CPU check.
 #include "../../include/kektor_compute_legacy.h"

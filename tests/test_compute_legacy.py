@@ -4,7 +4,10 @@ by libkektor_hip.so and libkektordb_compute.a so that the reference's `-tags rus
 
 Checked against the known answers the reference's own tests hold (tests/golden/reference_kats.json:
 pkg/core/distance/distance_test.go:37-84, native/compute/src/lib.rs:423-458) and, bit for bit, against the oracle's
-restatement of the crate's AVX2/FMA arithmetic (ORC_ARITH_RUST) on random vectors of every tail length."""
+restatement of the crate's AVX2/FMA arithmetic (ORC_ARITH_RUST) on random vectors of every tail length.
+dot_product_i8 is checked against the exact integer dot product (= the default Go build's dotProductGoInt8): the crate's own
+AVX2 reduction drops two of the four 32-bit lanes for len >= 32 (lib.rs:171-176), which is deliberately not reproduced
+(include/kektor_compute_legacy.h)."""
 import ctypes as C
 import json
 import os
