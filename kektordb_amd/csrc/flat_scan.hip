@@ -1853,7 +1853,6 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_period = fb_period;
         { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     }
-    static const int fb_slab = [] { const char *e = getenv("KDB_FB_SLAB"); return e && atoi(e) == 128 ? 128 : 64; }(); // measurement knob
     auto launch_big = [&](auto kern, const void *rows_b, const void *q_b) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
         hipLaunchKernelGGL(kern, dim3(256), dim3(512), FB_LDS, s, v, reinterpret_cast<const unsigned char *>(rows_b),
@@ -1861,12 +1860,10 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         return KDB_OK;
     };
     if (big) {
-#define KDB_BIG(M, P, R, Q) (fb_slab == 128 ? launch_big(flat_scan_big_kernel<M, P, 128>, R, Q) : launch_big(flat_scan_big_kernel<M, P, 64>, R, Q))
-        if (v.precision == KDB_PREC_I8) rc = KDB_BIG(KDB_METRIC_COSINE, KDB_PREC_I8, v.rows, d_q);
-        else if (v.precision == KDB_PREC_F16) rc = KDB_BIG(KDB_METRIC_L2, KDB_PREC_F16, v.rows, d_fbq);
-        else if (v.metric == KDB_METRIC_COSINE) rc = KDB_BIG(KDB_METRIC_COSINE, FS_PREC_F32R, idx->d_rows16, d_fbq);
-        else rc = KDB_BIG(KDB_METRIC_L2, FS_PREC_F32R, idx->d_rows16, d_fbq);
-#undef KDB_BIG
+        if (v.precision == KDB_PREC_I8) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, v.rows, d_q);
+        else if (v.precision == KDB_PREC_F16) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16>, v.rows, d_fbq);
+        else if (v.metric == KDB_METRIC_COSINE) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+        else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
     } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
         const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
         if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, d_q, lds_r);

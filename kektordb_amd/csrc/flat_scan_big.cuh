@@ -39,10 +39,11 @@
 #endif
 #define FB_SB() __builtin_amdgcn_sched_barrier(0)
 constexpr int FB_T = 256;        // rows per tile = queries per tile
-constexpr int FB_SLAB = 128;     // rows must be whole multiples of this many bytes (the launcher's rule)
+constexpr int FB_SLAB = 128;     // bytes of every row per K slab
 constexpr int FB_CSLOTS = 20;     // fs_compact_wave register slots: a list never holds more than 64 * 20 entries
-constexpr uint32_t FB_STAGES_BYTES = 4u * FB_T * FB_SLAB; // all slab buffers together: 128 KB (2 x 64 KB or 4 x 32 KB)
-constexpr size_t FB_LDS = FB_STAGES_BYTES + FB_T * 12u + 2u * FB_T * 8u + FB_T * 4u + 64u;
+constexpr uint32_t FB_DUMPS = 96; // 16-score blocks a wave can park in its scratch between two phase-B passes
+constexpr uint32_t FB_STAGE = 2u * FB_T * FB_SLAB; // one slab buffer: rows + queries = 64 KB
+constexpr size_t FB_LDS = 2u * FB_STAGE + FB_T * 12u + 2u * FB_T * 8u + FB_T * 4u + 64u;
 
 // entries allocated per (stripe, query): lists are compacted every `period` tiles when they hold more than kl + slack
 // entries, and a tile appends at most FB_T entries to a list
@@ -77,50 +78,16 @@ __device__ __forceinline__ void fb_glds4(const unsigned char *g0, const unsigned
                  : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_dst)
                  : "memory", "scc");
 }
-__device__ __forceinline__ void fb_glds2(const unsigned char *g0, const unsigned char *g1, uint32_t lds_dst /* wave-uniform */) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, %3, 0x2000\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g0), "v"(g1), "s"(lds_dst)
-                 : "memory", "scc");
-}
 __device__ __forceinline__ float fb_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-// wait until at most `newer` slabs' worth of requests (REQ each) are outstanding: the counter retires in order, so the
-// slab requested before those has landed (anything else the wave has in flight is newer or older, never in between)
-template <int REQ>
-__device__ __forceinline__ void fb_dma_wait(uint32_t newer /* wave-uniform, 0..2 */) {
-    if (newer == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (newer == 1u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REQ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * REQ) : "memory");
-}
+__device__ __forceinline__ void fb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// SL: bytes of every row and query per K slab.  128: two 64 KB slab buffers, the DMA one slab ahead (round 2).  64 (round 3):
-// FOUR 32 KB buffers, the DMA THREE slabs ahead.  The ablations of DESIGN 5.3 say why: requesting a slab and waiting for it
-// takes ~5000 cycles per slab and CU with nothing else going on (latency of the L2 / Infinity-Cache / HBM path under this
-// load), the MFMAs of a slab 2048; with one 64 KB slab in flight a CU can take in 64 KB per 5000 cycles = 41 % of what the
-// matrix pipes consume -- which is the 0.41-0.42 of peak the kernel ran at.  96 KB in flight raise that bound to 61 %.
-template <int METRIC, int PREC, int SL>
+template <int METRIC, int PREC>
 __global__ void __launch_bounds__(512, 2)
 flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb bytes per row */,
                      const unsigned char *__restrict__ q8 /* [n_qt*256][rowb] prepared queries, same encoding */, FsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t PP = SL / 16;                  // 16-byte pieces of a row per slab
-    constexpr uint32_t NJ = FB_T / (512u / PP);       // DMA requests per thread, operand and slab
-    constexpr uint32_t STG = 2u * FB_T * SL;          // one slab buffer: rows | queries
-    constexpr uint32_t NSTG = FB_STAGES_BYTES / STG;  // 2 | 4
-    constexpr uint32_t AHEAD = NSTG - 1u;             // slabs requested ahead of the one being multiplied
-    constexpr int KS = SL / 32;                       // 16-deep K steps per slab
-    constexpr int REQ = 2 * (int)NJ;                  // DMA instructions per thread and slab
-    constexpr uint32_t DUMPS = STG / 8u / 80u / 16u * 16u; // 16-score blocks a wave can park in its share of an idle slab buffer (96 | 48)
-    unsigned char *stage = smem;                                                // [NSTG][A | B]
-    float *tau = reinterpret_cast<float *>(smem + FB_STAGES_BYTES);             // [256] current kl-th best key of a query
+    unsigned char *stage = smem;                                                // [2][A 32 KB | B 32 KB]
+    float *tau = reinterpret_cast<float *>(smem + 2u * FB_STAGE);               // [256] current kl-th best key of a query
     uint32_t *tau_id = reinterpret_cast<uint32_t *>(tau + FB_T);                // [256] its id
     uint32_t *l_cnt = tau_id + FB_T;                                            // [256] entries in the query's list
     uint32_t *sel_id = l_cnt + FB_T;                                            // [2][256] row ids of a tile (by tile parity)
@@ -152,7 +119,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     if (FB_DBG & 128u) q0 = 0;                                             // measurement: every workgroup uses query tile 0
     const uint32_t qstride = p.n_qtiles * FS_TQ;
     const uint32_t rowb = PREC == KDB_PREC_I8 ? v.ld : v.ld * 2u;
-    const uint32_t nslab = rowb / SL;
+    const uint32_t nslab = rowb / FB_SLAB;
     const uint32_t cap = p.cap;
     const size_t list0 = ((size_t)stripe * qstride + q0) * cap; // first entry of query q0's list
     const uint32_t pub_rank = (p.kl + geo.n_stripes - 1u) / geo.n_stripes; // >= 1
@@ -170,49 +137,46 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     if (tid < 2) flags[tid] = 0u;
     __syncthreads();
 
-    // ---- staging map: thread t moves 16-byte slot t % PP of rows j*(512/PP) + t/PP (j < NJ) of both operands; the slot holds
-    //      piece slot ^ swizzle(row) of the row (swizzle on the SOURCE side: the LDS side of the DMA is lane-linear)
-    const uint32_t st_row = (uint32_t)tid / PP;
-    const uint32_t st_piece = ((uint32_t)tid % PP) ^ (SL == 128 ? (st_row >> 1) & 7u : (st_row >> 2) & 3u);
-    const unsigned char *qptr[NJ];
-    const unsigned char *aptr[NJ];
+    // ---- staging map: thread t moves piece (t & 7) ^ swizzle of rows j*64 + t/8 (j < 4) of both operands
+    const uint32_t st_row = (uint32_t)tid >> 3;
+    const uint32_t st_piece = ((uint32_t)tid & 7u) ^ (((uint32_t)tid >> 4) & 7u);
+    const unsigned char *qptr[4];
+    const unsigned char *aptr[4];
 #pragma unroll
-    for (uint32_t j = 0; j < NJ; j++) {
-        qptr[j] = q8 + (size_t)(q0 + j * (512u / PP) + st_row) * rowb + st_piece * 16u;
-        aptr[j] = rows8 + (size_t)sel_id[j * (512u / PP) + st_row] * rowb + st_piece * 16u;
+    for (int j = 0; j < 4; j++) {
+        qptr[j] = q8 + (size_t)(q0 + (uint32_t)j * 64u + st_row) * rowb + st_piece * 16u;
+        aptr[j] = rows8 + (size_t)sel_id[(uint32_t)j * 64u + st_row] * rowb + st_piece * 16u;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     // the DMA of a slab is issued in two halves (rows, then queries) between MFMA groups, so that its issue cost
-    // (the M0 writes and the requests) hides behind matrix-pipe time instead of preceding it
+    // (the M0 writes and 4 requests per half) hides behind matrix-pipe time instead of preceding it
     auto issue_rows = [&](uint32_t buf, uint32_t slab) {
-        const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * STG + (uint32_t)wave * 1024u);
-        const uint32_t so = slab * SL;
-        if constexpr (NJ == 4) fb_glds4(aptr[0] + so, aptr[1] + so, aptr[2] + so, aptr[3] + so, la);
-        else fb_glds2(aptr[0] + so, aptr[1] + so, la);
+        const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * FB_STAGE + (uint32_t)wave * 1024u);
+        const uint32_t so = slab * FB_SLAB;
+        fb_glds4(aptr[0] + so, aptr[1] + so, aptr[2] + so, aptr[3] + so, la);
     };
     auto issue_queries = [&](uint32_t buf, uint32_t slab) {
-        const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * STG + (uint32_t)wave * 1024u);
-        const uint32_t so = slab * SL;
-        if constexpr (NJ == 4) fb_glds4(qptr[0] + so, qptr[1] + so, qptr[2] + so, qptr[3] + so, la + FB_T * SL);
-        else fb_glds2(qptr[0] + so, qptr[1] + so, la + FB_T * SL);
+        const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + buf * FB_STAGE + (uint32_t)wave * 1024u);
+        const uint32_t so = slab * FB_SLAB;
+        fb_glds4(qptr[0] + so, qptr[1] + so, qptr[2] + so, qptr[3] + so, la + FB_T * FB_SLAB);
     };
     // ---- fragment map: lane (l31, hi) reads the 16 bytes k-piece kq*2+hi of row l31 of each 32-row block
-    const uint32_t swz = SL == 128 ? ((uint32_t)lane >> 1) & 7u : ((uint32_t)lane >> 2) & 3u;
-    const uint32_t a_off = (uint32_t)(wm * 128 + l31) * SL;
-    const uint32_t b_off = FB_T * SL + (uint32_t)(wn * 64 + l31) * SL;
-    uint32_t slot_off[KS];
+    const uint32_t swz = ((uint32_t)lane >> 1) & 7u;
+    const uint32_t a_off = (uint32_t)(wm * 128 + l31) * FB_SLAB;
+    const uint32_t b_off = FB_T * FB_SLAB + (uint32_t)(wn * 64 + l31) * FB_SLAB;
+    uint32_t slot_off[4];
 #pragma unroll
-    for (int kq = 0; kq < KS; kq++) slot_off[kq] = (((uint32_t)kq * 2u + (uint32_t)hi) ^ swz) * 16u;
+    for (int kq = 0; kq < 4; kq++) slot_off[kq] = (((uint32_t)kq * 2u + (uint32_t)hi) ^ swz) * 16u;
 
     f32x16 acc[4][2];
     // fragments of one 16-deep K step: 4 row blocks + 2 query blocks; two sets alternate (software pipeline)
     float4 fa[2][4], fb[2][2];
     auto read_frags = [&](int set, uint32_t buf, int kq) {
-        const unsigned char *sb = stage + buf * STG;
+        const unsigned char *sb = stage + buf * FB_STAGE;
 #pragma unroll
-        for (int ab = 0; ab < 4; ab++) fa[set][ab] = *reinterpret_cast<const float4 *>(sb + a_off + ab * (32 * SL) + slot_off[kq]);
+        for (int ab = 0; ab < 4; ab++) fa[set][ab] = *reinterpret_cast<const float4 *>(sb + a_off + ab * 4096 + slot_off[kq]);
 #pragma unroll
-        for (int bb = 0; bb < 2; bb++) fb[set][bb] = *reinterpret_cast<const float4 *>(sb + b_off + bb * (32 * SL) + slot_off[kq]);
+        for (int bb = 0; bb < 2; bb++) fb[set][bb] = *reinterpret_cast<const float4 *>(sb + b_off + bb * 4096 + slot_off[kq]);
     };
     auto mfma_step = [&](int set) {
         if (FB_DBG & 4u) return;
@@ -230,19 +194,12 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             }
     };
 
-    // Slab positions: position g = slab s of tile t (g = t * nslab + s) lives in buffer g % NSTG; while it is multiplied, the
-    // DMA of position g + AHEAD is requested (same tile, or the first slabs of the next one).  Odd tiles walk their slabs
-    // backwards: the query slabs the previous tile used last are requested first, while they are still in the XCD's L2 (a
-    // tile period streams more bytes through an XCD than its L2 holds).
-    const uint32_t ntiles = row_begin < row_end ? (row_end - row_begin + FB_T - 1u) / FB_T : 0u;
-    const uint32_t total = ntiles * nslab;
-    auto slab_of = [&](uint32_t tt, uint32_t ss) { return (tt & p.fb_alt) ? nslab - 1u - ss : ss; };
-    uint32_t g = 0; // slabs computed so far
-    for (uint32_t a = 0; a < AHEAD && a < total; a++) { // (nslab >= AHEAD + 1: the launcher's rule)
-        issue_rows(a % NSTG, slab_of(0u, a));
-        issue_queries(a % NSTG, slab_of(0u, a));
+    uint32_t g = 0; // slabs computed so far: buffer parity
+    if (row_begin < row_end) {
+        issue_rows(0, 0);
+        issue_queries(0, 0);
     }
-    fb_dma_wait<REQ>(total > 1u ? (total - 1u < AHEAD - 1u ? total - 1u : AHEAD - 1u) : 0u);
+    fb_dma_wait();
     __syncthreads();
 
     unsigned long long tm_sel = 0, tm_cmp = 0;
@@ -264,47 +221,54 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             for (int bb = 0; bb < 2; bb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
-        read_frags(0, g % NSTG, 0); // the tile's first slab landed behind the last barrier
+        read_frags(0, g & 1u, 0); // the tile's first slab landed behind the last barrier
 
-        // One slab of KS K steps: the fragments of step 0 are already in set 0 (read behind the previous slab's barrier).
-        //   step k < KS-1: read step k+1 -> the other set | request rows (k = 0) / queries (k = 1; k = 0 when KS = 2) of position g + AHEAD | MFMAs
-        //   last step:     wait for position g + 1, barrier (every LDS read of this slab has returned: its buffer may be
-        //                  refilled), read step 0 of the NEXT slab | MFMAs
+        // One slab: the fragments of its first K step are already in set 0 (read behind the previous slab's barrier).
+        //   step 0: read step 1 -> set 1 | request the next slab's rows    | MFMAs of set 0
+        //   step 1: read step 2 -> set 0 | request the next slab's queries | MFMAs of set 1
+        //   step 2: read step 3 -> set 1 |                                 | MFMAs of set 0
+        //   drain the DMA, barrier (every LDS read of this slab has returned: the buffer may be refilled)
+        //   step 3: read step 0 of the NEXT slab -> set 0                  | MFMAs of set 1
         for (uint32_t s = 0; s < nslab; s++, g++) {
-            const uint32_t buf = g % NSTG;
-            const bool dma = g + AHEAD < total && !(FB_DBG & 2u);
-            const bool cross = s + AHEAD >= nslab; // the position requested now belongs to the next tile
-            const uint32_t d_slab = cross ? slab_of(t + 1u, s + AHEAD - nslab) : slab_of(t, s + AHEAD);
-            const uint32_t d_buf = (g + AHEAD) % NSTG;
-            if (dma && s + AHEAD == nslab) { // from here on the requests read the next tile's rows
+            const uint32_t buf = g & 1u;
+            const bool dma_same = s + 1 < nslab, dma_next = !dma_same && has_next;
+            const bool dma = (dma_same || dma_next) && !(FB_DBG & 2u);
+            // odd tiles walk their slabs backwards: the query slabs the previous tile used last are requested first, while
+            // they are still in the XCD's L2 (a tile period streams more bytes through an XCD than its L2 holds)
+            const uint32_t odd = t & p.fb_alt;
+            const uint32_t nslab_i = dma_same ? (odd ? nslab - 2u - s : s + 1u) : ((odd || !p.fb_alt) ? 0u : nslab - 1u);
+            if (dma_next) {
 #pragma unroll
-                for (uint32_t j = 0; j < NJ; j++)
-                    aptr[j] = rows8 + (size_t)sel_id[(tp ^ 1u) * FB_T + j * (512u / PP) + st_row] * rowb + st_piece * 16u;
+                for (int j = 0; j < 4; j++)
+                    aptr[j] = rows8 + (size_t)sel_id[(tp ^ 1u) * FB_T + (uint32_t)j * 64u + st_row] * rowb + st_piece * 16u;
             }
-            // positions g+2 .. g+AHEAD that exist: their requests are newer than position g+1's and may stay in flight
-            const uint32_t newer = g + 2u < total ? (total - (g + 2u) < AHEAD - 1u ? total - (g + 2u) : AHEAD - 1u) : 0u;
             // FB_SB: the phases stay in this order.  Left alone, the scheduler hoists the LDS reads of later steps above
             // the MFMAs that still use the set they overwrite, keeps a third fragment set alive, runs out of registers and
             // reloads spilled fragments inside this loop -- behind an s_waitcnt vmcnt(0) that also waits for the slab DMA.
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                if (ks < KS - 1) {
-                    read_frags((ks + 1) & 1, buf, ks + 1);
-                } else {
-                    fb_dma_wait<REQ>(AHEAD > 1u ? newer : 0u);
-                    __syncthreads(); // position g+1 has landed (every wave drained its own requests), nobody reads position g any more
-                    if (s + 1 < nslab) read_frags(0, (g + 1u) % NSTG, 0); // (the next tile reads its first fragments after the selection: kept across it, they spill)
-                    if (s == 0 && has_next && tid < FB_T) {
-                        sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
-                        if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
-                    }
-                }
-                if (ks == 0 && dma) issue_rows(d_buf, d_slab);
-                if (ks == (KS == 2 ? 0 : 1) && dma) issue_queries(d_buf, d_slab); // (KS = 2: both before the wait, which counts whole slabs)
-                FB_SB();
-                mfma_step(ks & 1);
-                FB_SB();
+            read_frags(1, buf, 1);
+            if (dma) issue_rows(buf ^ 1u, nslab_i);
+            FB_SB();
+            mfma_step(0);
+            FB_SB();
+            read_frags(0, buf, 2);
+            if (dma) issue_queries(buf ^ 1u, nslab_i);
+            FB_SB();
+            mfma_step(1);
+            FB_SB();
+            read_frags(1, buf, 3);
+            FB_SB();
+            mfma_step(0);
+            FB_SB();
+            fb_dma_wait();
+            __syncthreads(); // slab s+1 has landed (every wave drained its own DMA), nobody reads slab s any more
+            if (dma_same) read_frags(0, buf ^ 1u, 0); // (the next tile reads its first fragments after the selection: kept across it, they spill)
+            if (s == 0 && has_next && tid < FB_T) {
+                sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
+                if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
             }
+            FB_SB();
+            mfma_step(1);
+            FB_SB();
         }
 
         // ---- selection.  acc[ab][bb][r]: query wn*64 + bb*32 + l31, row wm*128 + ab*32 + (r&3) + 8*(r>>2) + 4*hi.
@@ -319,9 +283,9 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         bool appended = false;
         const unsigned long long tm0 = (FB_DBG & 32u) ? __builtin_readcyclecounter() : 0ull;
         {
-            unsigned char *scratch = stage + ((g - 1u) % NSTG) * STG + (uint32_t)wave * (STG / 8u);
-            float *dump = reinterpret_cast<float *>(scratch);                               // [DUMPS][16] scores
-            uint4 *dsc = reinterpret_cast<uint4 *>(scratch + DUMPS * 64u);                  // [DUMPS] {t_k, t_id, code}
+            unsigned char *scratch = stage + ((g - 1u) & 1u) * FB_STAGE + (uint32_t)wave * 8192u;
+            float *dump = reinterpret_cast<float *>(scratch);                               // [FB_DUMPS][16] scores
+            uint4 *dsc = reinterpret_cast<uint4 *>(scratch + FB_DUMPS * 64u);               // [FB_DUMPS] {t_k, t_id, code}
             uint32_t n_dump = 0; // wave-uniform
             auto phase_b = [&]() {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -393,26 +357,17 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                     const bool pass = m >= thr[bb]; // false for NaN
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
                     if (bal == 0ull) continue;
-                    // a block may dump one entry per lane; with room for fewer than 96 entries (the 4 KB share of a 32 KB slab
-                    // buffer) the two halves of the wave dump one after the other, with a flush in between when needed
-                    constexpr uint32_t GRP = DUMPS >= 96u ? 64u : 32u;
+                    if (pass) {
+                        const uint32_t slot = n_dump + kdb_mbcnt(bal);
+                        float4 *dst = reinterpret_cast<float4 *>(dump + slot * 16u);
 #pragma unroll
-                    for (uint32_t h0 = 0; h0 < 64u; h0 += GRP) {
-                        const bool mine = pass && (GRP == 64u || ((uint32_t)lane & 32u) == h0);
-                        const unsigned long long hb = GRP == 64u ? bal : __builtin_amdgcn_ballot_w64(mine);
-                        if (hb == 0ull) continue;
-                        if (mine) {
-                            const uint32_t slot = n_dump + kdb_mbcnt(hb);
-                            float4 *dst = reinterpret_cast<float4 *>(dump + slot * 16u);
-#pragma unroll
-                            for (int gq = 0; gq < 4; gq++)
-                                dst[gq] = make_float4(acc[ab][bb][gq * 4 + 0], acc[ab][bb][gq * 4 + 1], acc[ab][bb][gq * 4 + 2], acc[ab][bb][gq * 4 + 3]);
-                            dsc[slot] = make_uint4(__float_as_uint(t_k[bb]), t_id[bb], (uint32_t)lane | ((uint32_t)ab << 6) | ((uint32_t)bb << 8), 0u);
-                        }
-                        n_dump += (uint32_t)__builtin_popcountll(hb);
-                        if ((FB_DBG & 256u) && lane == 0) n_dmp += (uint32_t)__builtin_popcountll(hb);
-                        if (n_dump + GRP > DUMPS) phase_b(); // the next group may dump GRP more
+                        for (int gq = 0; gq < 4; gq++)
+                            dst[gq] = make_float4(acc[ab][bb][gq * 4 + 0], acc[ab][bb][gq * 4 + 1], acc[ab][bb][gq * 4 + 2], acc[ab][bb][gq * 4 + 3]);
+                        dsc[slot] = make_uint4(__float_as_uint(t_k[bb]), t_id[bb], (uint32_t)lane | ((uint32_t)ab << 6) | ((uint32_t)bb << 8), 0u);
                     }
+                    n_dump += (uint32_t)__builtin_popcountll(bal);
+                    if ((FB_DBG & 256u) && lane == 0) n_dmp += (uint32_t)__builtin_popcountll(bal);
+                    if (n_dump + 64u > FB_DUMPS) phase_b(); // the next block may dump 64 more
                 }
             }
             if (n_dump) phase_b();
