@@ -311,6 +311,14 @@ KDB_API int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B, ui
                               uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
                               float *d_out_dist, uint32_t *d_out_count, void *stream);
 
+/* The same for int8 shards, whose distances the reference computes and ORDERS as float64 (hnsw_index.go:2429-2454): shard
+ * g's block holds dist64[B][k] (doubles, as KDB_SEARCH_DIST_F64 writes them) | ids[B][k] | count[B]; stride_words even and
+ * >= 3*B*k + B; d_out_dist receives doubles.  (A merge over floats would rank two distinct doubles that round to one float
+ * by id.)                                                                                                        */
+KDB_API int kdb_merge_topk_packed_f64_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_packed,
+                                          uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
+                                          double *d_out_dist, uint32_t *d_out_count, void *stream);
+
 /* ---- the id-range shards of one node behind one handle (single-process callers: the Go shim) ------------------------
  * shards[g]: an index created on its device (kdb_index_desc.device_id) that owns the global ids id_base[g]+1 ...
  * id_base[g]+count_g (local id i <-> global id id_base[g]+i); bases ascend, shards of one device are consecutive and

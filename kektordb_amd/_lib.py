@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
     "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
     "kdb_index_sync", "kdb_test_select_neighbors", "kdb_cluster_create", "kdb_cluster_destroy", "kdb_cluster_info",
-    "kdb_sharded_search_batch", "kdb_sharded_flat_scan_batch", "kdb_index_compress", "kdb_index_get_quantizer", "kdb_index_add_batch",
+    "kdb_sharded_search_batch", "kdb_sharded_flat_scan_batch", "kdb_index_compress", "kdb_index_get_quantizer", "kdb_index_add_batch", "kdb_merge_topk_packed_f64_dev",
 ]
 
 
@@ -116,6 +116,7 @@ def load():
     L.kdb_merge_topk.argtypes = [u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_packed_dev.argtypes = [vp, u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, vp]
+    L.kdb_merge_topk_packed_f64_dev.argtypes = [vp, u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.kdb_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.kdb_get_launch_stats.argtypes = [vp, u32, C.POINTER(Counters)]
     L.kdb_index_sync.argtypes = [vp]

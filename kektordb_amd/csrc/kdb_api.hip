@@ -1327,6 +1327,26 @@ extern "C" int kdb_merge_topk_packed_dev(kdb_index *idx, uint32_t G, uint32_t B,
                                  (size_t)stride_words, (size_t)stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count, s);
 }
 
+// int8 shards: the block one all-gather delivers carries float64 distances -- dist64[B][k] | ids[B][k] | count[B], stride in
+// 32-bit words (even, >= 3*B*k + B) -- and the merge orders doubles; d_out_dist receives doubles
+extern "C" int kdb_merge_topk_packed_f64_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_packed,
+                                             uint64_t stride_words, const uint32_t *d_id_base, uint32_t *d_out_ids,
+                                             double *d_out_dist, uint32_t *d_out_count, void *stream) {
+    KDB_CHECK_IDX(idx);
+    const uint64_t block = 3ull * B * k + B;
+    if (!d_packed || !d_out_ids || !d_out_dist || !d_out_count || k == 0 || stride_words < block || (stride_words & 1ull)) {
+        kdb_set_error("merge_topk_packed_f64: null buffer, k == 0, odd stride or stride %llu < 3*B*k+B = %llu", (unsigned long long)stride_words,
+                      (unsigned long long)block);
+        return KDB_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    const size_t bk = (size_t)B * k;
+    return kdb_launch_merge_topk_f64(G, B, k, d_packed + 2 * bk, reinterpret_cast<const double *>(d_packed), d_packed + 3 * bk, (size_t)stride_words,
+                                     (size_t)stride_words / 2, (size_t)stride_words, d_id_base, d_out_ids, d_out_dist, 1, d_out_count, s);
+}
+
 static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     unsigned long long c[4] = {0, 0, 0, 0};
     float ms = 0.f;

@@ -265,12 +265,13 @@ class HipIndex:
         return ids, dist, cnt
 
     def search_batch_dev(self, d_queries, k: int, ef: int, d_out_ids, d_out_dist, d_out_count, d_allow=None,
-                         stream=None, prepared=False):
-        """torch device tensors in, asynchronous on `stream` (a raw hipStream_t int or None)."""
+                         stream=None, prepared=False, dist64=False):
+        """torch device tensors in, asynchronous on `stream` (a raw hipStream_t int or None).
+        dist64 (int8 indexes): d_out_dist is a float64 tensor (KDB_SEARCH_DIST_F64)"""
         self._live()
         _ready(stream)
         B = d_queries.shape[0]
-        check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared),
+        check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared) | (SEARCH_DIST_F64 if dist64 else 0),
                                           _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                           C.c_void_p(stream) if stream else None), "kdb_search_batch_dev")
 
@@ -286,11 +287,11 @@ class HipIndex:
                                          _ptr(cnt)), "kdb_flat_scan_batch")
         return ids, dist, cnt
 
-    def flat_scan_batch_dev(self, d_queries, k, d_out_ids, d_out_dist, d_out_count, d_allow=None, stream=None):
+    def flat_scan_batch_dev(self, d_queries, k, d_out_ids, d_out_dist, d_out_count, d_allow=None, stream=None, dist64=False):
         self._live()
         _ready(stream)
         B = d_queries.shape[0]
-        check(self.L.kdb_flat_scan_batch_dev(self.h, _tptr(d_queries), B, k, _tptr(d_allow), self._flags(),
+        check(self.L.kdb_flat_scan_batch_dev(self.h, _tptr(d_queries), B, k, _tptr(d_allow), self._flags() | (SEARCH_DIST_F64 if dist64 else 0),
                                              _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                              C.c_void_p(stream) if stream else None), "kdb_flat_scan_batch_dev")
 
@@ -366,6 +367,12 @@ class HipIndex:
         check(self.L.kdb_merge_topk_packed_dev(self.h, G, B, k, _tptr(d_packed), stride_words, _tptr(d_id_base),
                                                _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                                C.c_void_p(stream) if stream else None), "kdb_merge_topk_packed_dev")
+
+    def merge_topk_packed_f64_dev(self, G, B, k, d_packed, stride_words, d_id_base, d_out_ids, d_out_dist, d_out_count, stream=None):
+        """int8 shards: blocks of dist64[B][k] | ids[B][k] | count[B]; d_out_dist is a float64 tensor"""
+        check(self.L.kdb_merge_topk_packed_f64_dev(self.h, G, B, k, _tptr(d_packed), stride_words, _tptr(d_id_base),
+                                                   _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
+                                                   C.c_void_p(stream) if stream else None), "kdb_merge_topk_packed_f64_dev")
 
     # ---- the reference's per-query API --------------------------------------------------------------
     def score(self, raw: float) -> float:

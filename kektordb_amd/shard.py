@@ -88,22 +88,31 @@ class ShardedSearch:
         self._turn = (self._turn + 1) % len(self.streams)
         stream = self.streams[self._turn]
         key = (B, k, self._turn)
-        L = 2 * B * k + B  # packed block: ids[B][k] | dist[B][k] (f32 bits) | count[B], 32-bit words
+        i8 = self.precision == _index.I8
+        # packed block, 32-bit words: ids[B][k] | dist[B][k] (f32 bits) | count[B]; int8 shards carry the reference's float64
+        # distances (ordered as doubles in the merge): dist64[B][k] | ids[B][k] | count[B], even length
+        L = ((3 * B * k + B + 1) & ~1) if i8 else 2 * B * k + B
         if key not in self._bufs:
             self._bufs[key] = (torch.zeros((L,), dtype=torch.int32, device=dev),
                                torch.zeros((self.world, L), dtype=torch.int32, device=dev))
         local, gathered = self._bufs[key]
-        l_ids = local[:B * k].view(B, k)
-        l_dist = local[B * k:2 * B * k].view(torch.float32).view(B, k)
-        l_cnt = local[2 * B * k:]
+        if i8:
+            l_dist = local[:2 * B * k].view(torch.float64).view(B, k)
+            l_ids = local[2 * B * k:3 * B * k].view(B, k)
+            l_cnt = local[3 * B * k:3 * B * k + B]
+        else:
+            l_ids = local[:B * k].view(B, k)
+            l_dist = local[B * k:2 * B * k].view(torch.float32).view(B, k)
+            l_cnt = local[2 * B * k:]
         stream.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         with torch.cuda.stream(stream):
             raw = stream.cuda_stream
             tgt = (out_ids, out_dist, out_cnt) if self.world == 1 and not self.force_exchange else (l_ids, l_dist, l_cnt)
+            d64 = bool(i8 and tgt[1].dtype == torch.float64)
             if flat:
-                idx.flat_scan_batch_dev(d_queries, k, *tgt, d_allow, stream=raw)
+                idx.flat_scan_batch_dev(d_queries, k, *tgt, d_allow, stream=raw, dist64=d64)
             else:
-                idx.search_batch_dev(d_queries, k, ef, *tgt, d_allow, stream=raw)
+                idx.search_batch_dev(d_queries, k, ef, *tgt, d_allow, stream=raw, dist64=d64)
             if self.world == 1 and not self.force_exchange:
                 return
             # the one exchange step: ONE all-gather of the packed per-shard top-k (RCCL over xGMI)
@@ -118,8 +127,11 @@ class ShardedSearch:
                 gathered.copy_(torch.stack(parts).to(dev))
             if self._dev_bases is None:
                 self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
-            idx.merge_topk_packed_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt,
-                                      stream=raw)
+            if i8:  # out_dist: float64 tensor
+                idx.merge_topk_packed_f64_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt, stream=raw)
+            else:
+                idx.merge_topk_packed_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt,
+                                          stream=raw)
 
     # ---- host path (what a Go shim does with host buffers; also the gloo test path) -------------------
     def merge_host(self, l_ids: np.ndarray, l_dist: np.ndarray, l_cnt: np.ndarray, k: int

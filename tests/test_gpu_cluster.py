@@ -131,6 +131,27 @@ def test_sharded_int8_merges_float64_distances(oracle, hip):
             tie = (f[1:] == f[:-1]) & (wd[1:] != wd[:-1])
             cross += int(np.sum(tie & (shard_of[1:] != shard_of[:-1]) & (wi[1:] < wi[:-1])))
     assert cross >= 1, "no float32 collision between distinct doubles of different shards in id-descending order: the case does not test the merge"
+    # the one-process-per-GPU route (kektordb_amd/shard.py) exchanges the same float64 block: dist64 | ids | count per shard,
+    # merged by kdb_merge_topk_packed_f64_dev
+    import torch
+    dev = torch.device("cuda:0")
+    B = Q.shape[0]
+    L = (3 * B * k + B + 1) & ~1
+    gathered = torch.zeros((2, L), dtype=torch.int32, device=dev)
+    dq = torch.from_numpy(Q).to(dev)
+    for g, ix in enumerate(shards):
+        blk = gathered[g]
+        ix.flat_scan_batch_dev(dq, k, blk[2 * B * k:3 * B * k].view(B, k), blk[:2 * B * k].view(torch.float64).view(B, k),
+                               blk[3 * B * k:3 * B * k + B], dist64=True)
+        ix.sync()
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    od = torch.zeros((B, k), dtype=torch.float64, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    shards[0].merge_topk_packed_f64_dev(2, B, k, gathered, L, torch.tensor(bases, dtype=torch.int32, device=dev), oi, od, oc)
+    shards[0].sync()
+    cids, cdist, ccnt = cl.flat_scan_batch(Q, k, flags=F64)
+    assert np.array_equal(oi.cpu().numpy().view(np.uint32), cids) and np.array_equal(od.cpu().numpy(), cdist)
+    assert np.array_equal(oc.cpu().numpy().view(np.uint32), ccnt)
     with pytest.raises(hip.KdbError):
         f32 = hip.HipIndex(16, 0, 0, 8, 20, capacity=64)
         hip.Cluster([f32], [0]).search_batch(np.zeros((1, 16), np.float32), 1, 10, flags=F64)   # float64 distances are an int8 option
