@@ -105,9 +105,10 @@ typedef struct {
     int32_t device_id;   /* HIP device ordinal */
     uint32_t reserved;   /* flags: KDB_INDEX_NO_F16_SHADOW */
 } kdb_index_desc;
-/* float32 indexes keep a second copy of the rows as halfs (+50 % row memory): the exact scan RANKS on it (half the
+/* float32 indexes that are scanned exactly keep a second copy of the rows as halfs (+50 % row memory), made by the
+ * FIRST kdb_flat_scan_* call (an index that is only walked never allocates it): the exact scan RANKS on it (half the
  * HBM bytes for small batches, the f16 MFMA for large ones) inside a rigorous error band and settles on the float32
- * rows, so answers are unchanged.  Set this bit to do without the copy.                                        */
+ * rows, so answers are unchanged.  Set this bit to do without the copy for good.                               */
 #define KDB_INDEX_NO_F16_SHADOW 1u
 
 /* Per-level CSR adjacency.  offsets[l] has count+2 entries: node i's neighbours at level l are

@@ -282,10 +282,7 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     idx->ev1 = idx->ring_ev1[0];
     KDB_TRY(hipMalloc(&idx->d_rows, n1 * idx->ld * idx->elem));
     KDB_TRY(hipMemsetAsync(idx->d_rows, 0, (size_t)idx->ld * idx->elem, idx->stream)); // row 0
-    if (idx->desc.precision == KDB_PREC_F32 && !(idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW)) {
-        KDB_TRY(hipMalloc(&idx->d_rows16, n1 * idx->ld * 2));
-        KDB_TRY(hipMemsetAsync(idx->d_rows16, 0, (size_t)idx->ld * 2, idx->stream));
-    }
+    // (the half-precision ranking copy of float32 rows is made by the first exact scan that can use it: ensure_rows16)
     KDB_TRY(hipMalloc(&idx->d_norms, n1 * 4));
     KDB_TRY(hipMemsetAsync(idx->d_norms, 0, n1 * 4, idx->stream));
     KDB_TRY(hipMalloc(&idx->d_adj0, n1 * idx->deg0 * 4));
@@ -1027,6 +1024,20 @@ extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, u
     return KDB_OK;
 }
 
+// float32 indexes: the half-precision RANKING copy of the rows (+50 % row memory) exists from the first exact scan on -- an
+// index that is only ever walked never pays for it; KDB_INDEX_NO_F16_SHADOW keeps it away for good.  Called under idx->mu;
+// every row uploaded so far is in HBM (add_vectors returns after its copies), later uploads convert their own rows.
+static int ensure_rows16(kdb_index *idx, hipStream_t s) {
+    if (idx->d_rows16 || idx->desc.precision != KDB_PREC_F32 || (idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW)) return KDB_OK;
+    const size_t n1 = (size_t)idx->desc.capacity + 1;
+    if (hipMalloc(&idx->d_rows16, n1 * idx->ld * 2) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->d_rows16 = nullptr; // no room: the scan ranks on the float32 rows (same answers)
+        return KDB_OK;
+    }
+    return kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, 0, idx->count + 1, s);
+}
+
 static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, const uint64_t *d_allow_bits,
                            uint32_t flags, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, hipStream_t s) {
     KdbView v = kdb_make_view(idx);
@@ -1046,7 +1057,9 @@ static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, u
     const uint32_t Bpad = (B + 255u) & ~255u; // whole query tiles of either tile kernel (128 / 256 queries), zero rows behind B
     void *d_q = nullptr;
     float *d_qnorm = nullptr;
-    int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
+    int rc = ensure_rows16(idx, s);
+    if (rc) return rc;
+    rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
     if ((flags & KDB_SEARCH_DIST_F64) && idx->desc.precision != KDB_PREC_I8) {
         kdb_set_error("flat scan: KDB_SEARCH_DIST_F64 applies to int8 indexes (the other precisions compute float32 distances)");
@@ -1090,7 +1103,9 @@ extern "C" int kdb_flat_scan_groups_dev(kdb_index *idx, const float *d_queries, 
     const uint32_t Bpad = (B + 127u) & ~127u;
     void *d_q = nullptr;
     float *d_qnorm = nullptr;
-    int rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
+    int rc = ensure_rows16(idx, s);
+    if (rc) return rc;
+    rc = prepare_queries(idx, v, d_queries, B, Bpad, flags, &d_q, &d_qnorm, s);
     if (rc) return rc;
     return kdb_launch_flat_scan_groups(idx, v, d_q, d_qnorm, B, k, G, group_offsets,
                                        reinterpret_cast<const uint32_t *>(d_allow_lists), (uint32_t)(words_per_list * 2),

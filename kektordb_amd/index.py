@@ -56,8 +56,8 @@ def _ready(stream):
 class HipIndex:
     def __init__(self, dim: int, metric: int = COSINE, precision: int = F32, m: int = 16,
                  ef_construction: int = 200, capacity: int = 1 << 20, device_id: int = 0, f16_shadow: bool = True):
-        """f16_shadow: float32 indexes keep a half-precision RANKING copy of the rows for the exact scan (+50 % row
-        memory, answers unchanged); False sets KDB_INDEX_NO_F16_SHADOW."""
+        """f16_shadow: float32 indexes make a half-precision RANKING copy of the rows at their first exact scan (+50 % row
+        memory from then on, answers unchanged); False sets KDB_INDEX_NO_F16_SHADOW (never)."""
         self.L = _lib.load()
         self.dim, self.metric, self.precision = int(dim), int(metric), int(precision)
         self.m = m if m > 0 else 16

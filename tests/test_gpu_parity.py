@@ -997,6 +997,35 @@ def test_flat_scan_without_ranking_copy(oracle, hip):
             assert np.array_equal(raw_to_score(idx, dist[b, :int(cnt[b])]), od)
 
 
+def test_ranking_copy_is_made_by_the_first_exact_scan(hip):
+    """A float32 index allocates its half-precision ranking copy (+50 % row memory) when it is first scanned exactly,
+    not at creation: walking it leaves the device memory as it was, rows added AFTER the copy exists are ranked too
+    (the answer is the new row itself)."""
+    import torch
+    n, dim, cap = 20000, 768, 200000
+    shadow = (cap + 1) * dim * 2
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    idx = hip.HipIndex(dim, 0, 0, 8, 40, capacity=cap)
+    idx.upload_rows(X, 1)
+    idx.build(n, seed=1)
+    Q = X[:64] + 1e-3
+    idx.search_batch(Q, 5, 32)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    idx.search_batch(Q, 5, 32)
+    assert free0 - torch.cuda.mem_get_info()[0] < shadow // 4
+    ids, _, cnt = idx.flat_scan_batch(Q, 5)
+    assert free0 - torch.cuda.mem_get_info()[0] >= shadow
+    assert np.array_equal(ids[:, 0], np.arange(1, 65))
+    Y = rng.standard_normal((300, dim)).astype(np.float32)
+    idx.upload_rows(Y, n + 1)
+    idx.set_count(n + 300)
+    for B in (5, 300):
+        ids, _, cnt = idx.flat_scan_batch(Y[:B] + 1e-3, 3)
+        assert np.array_equal(ids[:, 0], np.arange(n + 1, n + 1 + B))
+
+
 @pytest.mark.parametrize("B", [3, 70])
 @pytest.mark.parametrize("case", ["f32_l2", "f32_cosine", "f16_l2", "f32_l2_filtered", "f32_l2_wide"])
 def test_flat_scan_rounding_band_rescue(oracle, hip, case, B):
