@@ -101,6 +101,8 @@ struct kdb_index {
     size_t qbuf_bytes = 0;
     void *d_iobuf = nullptr;        // staging for the host-pointer entry points
     size_t iobuf_bytes = 0;
+    void *h_pin = nullptr;          // page-locked twin of the staging buffer: small host-pointer calls copy through it
+    size_t h_pin_bytes = 0;
     uint32_t *d_gentry = nullptr;    // entry point per allow list of a search batch (hnsw_index.go:437-447), chosen on the device
     uint32_t gentry_cap = 0;
     void *d_build = nullptr;        // graph-construction workspace
