@@ -24,7 +24,10 @@
 #define KDB_F32_DUAL 1
 #endif
 #ifndef KDB_WIDE4_ROWS
-#define KDB_WIDE4_ROWS 1 // rows per 16-lane group and trip of a helper wave of the four-wave mode (three helpers: 12 rows per trip)
+#define KDB_WIDE4_ROWS 1
+#ifndef KDB_LDS_MERGE
+#define KDB_LDS_MERGE 1 // one merge per hop into the LDS beam (0: the sequential form, for A/B measurements)
+#endif // rows per 16-lane group and trip of a helper wave of the four-wave mode (three helpers: 12 rows per trip)
 #endif
 #ifndef KDB_F16_ROWS
 #define KDB_F16_ROWS 2
@@ -1094,6 +1097,89 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
                 b.n_res = ncount;
                 b.worst = ncount >= ef ? readlane_f(b.d[0], ncount - 1u) : INFINITY;
                 b.worst_lo = 0u;
+                KDB_T(ctr.n_ins += npass;)
+                return;
+            }
+        }
+    }
+    if constexpr (BeamT::kSlots == 0 && KDB_LDS_MERGE) {
+        // The LDS beam (ef > 384), same idea: one merge per hop instead of one shift of half the beam per candidate.  Every
+        // candidate finds its lower bound in the sorted beam by binary search (all lanes at once) and its rank among the
+        // candidates; beam entries from the lowest landing point up move by the number of candidates that land at or before
+        // them -- top chunk first, so nothing is overwritten before it has been read; then the candidates drop into the gaps.
+        const uint32_t npass = (uint32_t)__builtin_popcountll(pass);
+        if (npass >= 2u && !v.has_deleted) {
+            const uint32_t m = b.count;
+            const bool in_pass = ((pass >> lane) & 1ull) != 0ull;
+            uint32_t rank = 0u;
+            bool tie = false;
+            for (unsigned long long rest = pass; rest;) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                const float cd = readlane_f(my_d, j);
+                const uint32_t clo = WK ? readlane_u(my_lo, j) : 0u;
+                if (in_pass && (uint32_t)lane != j) {
+                    rank += key_lt<WK>(cd, clo, my_d, my_lo) ? 1u : 0u;
+                    tie = tie || key_eq<WK>(cd, clo, my_d, my_lo);
+                }
+            }
+            wave_lds_fence();
+            uint32_t lo = 0u, hi = in_pass ? m : 0u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const float e = b.bd[mid];
+                const uint32_t elo = WK ? b.bl[mid] : 0u;
+                if (key_lt<WK>(e, elo, my_d, my_lo)) lo = mid + 1u;
+                else hi = mid;
+            }
+            if (in_pass && lo < m) tie = tie || key_eq<WK>(b.bd[lo], WK ? b.bl[lo] : 0u, my_d, my_lo);
+            if (__ballot(tie) == 0ull) {
+                uint32_t pmin = m;
+                for (unsigned long long rest = pass; rest;) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    const uint32_t pj = readlane_u(lo, j);
+                    pmin = pj < pmin ? pj : pmin;
+                }
+                for (int top = (int)m - 1; top >= (int)pmin; top -= 64) {
+                    const int i = top - lane;
+                    const bool act = i >= (int)pmin;
+                    float e = 0.f;
+                    uint32_t x = 0u, l = 0u;
+                    if (act) {
+                        e = b.bd[i];
+                        x = b.bi[i];
+                        if (WK) l = b.bl[i];
+                    }
+                    uint32_t sh = 0u;
+                    for (unsigned long long rest = pass; rest;) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                        rest &= rest - 1ull;
+                        sh += (act && readlane_u(lo, j) <= (uint32_t)i) ? 1u : 0u;
+                    }
+                    wave_lds_fence();
+                    if (act && (uint32_t)i + sh < ef) {
+                        b.bd[(uint32_t)i + sh] = e;
+                        b.bi[(uint32_t)i + sh] = x;
+                        if (WK) b.bl[(uint32_t)i + sh] = l;
+                    }
+                    wave_lds_fence();
+                }
+                const uint32_t place = lo + rank;
+                if (in_pass && place < ef) {
+                    b.bd[place] = my_d;
+                    b.bi[place] = my_id;
+                    if (WK) b.bl[place] = my_lo;
+                }
+                wave_lds_fence();
+                const uint32_t total = m + npass;
+                const uint32_t ncount = total < ef ? total : ef;
+                b.count = ncount;
+                b.n_res = ncount;
+                const bool full = ncount >= ef;
+                b.worst = full ? unif(b.bd[ncount - 1u]) : INFINITY;
+                b.worst_lo = (WK && full) ? uni(b.bl[ncount - 1u]) : 0u;
+                if (pmin < b.scan_from) b.scan_from = pmin;
                 KDB_T(ctr.n_ins += npass;)
                 return;
             }
