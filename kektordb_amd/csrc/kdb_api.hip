@@ -307,6 +307,8 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     }
     KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 32));
     KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 32, idx->stream));
+    KDB_TRY(hipMalloc(&idx->d_acc, kdb_index::RING * 32));
+    KDB_TRY(hipMemsetAsync(idx->d_acc, 0, kdb_index::RING * 32, idx->stream));
     KDB_TRY(hipStreamSynchronize(idx->stream));
 #undef KDB_TRY
     *out = idx;
@@ -320,7 +322,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     (void)hipDeviceSynchronize(); // callers' streams may still run kernels of this index
     lane_store(idx);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
-                    idx->d_deleted, idx->d_ctr, idx->d_iobuf, idx->d_build, idx->d_rows16};
+                    idx->d_deleted, idx->d_ctr, idx->d_acc, idx->d_iobuf, idx->d_build, idx->d_rows16};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (kdb_lane &l : idx->lanes) {

@@ -111,6 +111,7 @@ struct kdb_index {
     uint32_t last_B = 0, last_C = 0;
     uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words)
     unsigned long long *d_ctr = nullptr; // n_dist, n_hops
+    unsigned long long *d_acc = nullptr; // graph search: accumulator slots beside d_ctr's (self-resetting, search.hip)
     // trace
     uint32_t *trace_ndist = nullptr, *trace_nhops = nullptr;
     int trace_on_device = 0;

@@ -254,10 +254,25 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         wave_lds_fence();
     }
     if constexpr (WIDE > 1) wide_request<WIDE>(s, wc, KDB_W_EXIT, 0u);
-    if (lane == 0 && gctr) {
-        atomicAdd(&gctr[0], tot_dist);
-        atomicAdd(&gctr[1], tot_hops);
-        if (tot_dropped) atomicAdd(&gctr[3], tot_dropped);
+    // Counters and the work counter re-arm themselves (no fill of the slot ahead of every launch: 5 us of a 150 us call).
+    // `work` is the third word pair of the launch's ACCUMULATOR slot {n_dist, n_hops, work | done, dropped}; every
+    // workgroup adds its sums and counts itself done; the last one publishes the totals to the statistics slot the host
+    // reads and leaves the accumulators at zero for the launch that gets the slot next.
+    if (lane == 0) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(work) - 2;
+        // (no __threadfence: a device-scope fence writes back and invalidates the XCD's L2 under the walks still running --
+        // measured +5 % on a 1024-query launch.  Only atomics touch these words; they are performed at the device's
+        // coherence point, and a returned value means the operation is done: the sums are in before `done` counts.)
+        const unsigned long long r0 = atomicAdd(&acc[0], tot_dist);
+        const unsigned long long r1 = atomicAdd(&acc[1], tot_hops);
+        const unsigned long long r3 = tot_dropped ? atomicAdd(&acc[3], tot_dropped) : 0ull;
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(r3) : "memory");
+        if (atomicAdd(work + 1, 1u) == gridDim.x - 1u) {
+            gctr[0] = atomicExch(&acc[0], 0ull);
+            gctr[1] = atomicExch(&acc[1], 0ull);
+            gctr[3] = atomicExch(&acc[3], 0ull);
+            atomicExch(&acc[2], 0ull); // work and done
+        }
     }
 }
 
@@ -611,10 +626,10 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         int rc = kdb_ensure_visited(idx, grid, s);
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
-        KDB_HIP(hipMemsetAsync(d_ctr, 0, 32, s)); // counters + the launch's work counter in one fill
+        unsigned long long *d_acc = idx->d_acc + (d_ctr - idx->d_ctr); // the slot's accumulators: zero between launches (see the kernel's end)
         KDB_HIP(hipEventRecord(idx->ev0, s));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
-                           idx->d_visited, reinterpret_cast<uint32_t *>(d_ctr + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
+                           idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
         KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
