@@ -14,7 +14,9 @@
 // Calls of several threads overlap (round 3).  A cluster keeps KDB_CLANES = 2 lanes: per device a stream, query / send /
 // receive buffers and allow-list slices of its own; a call takes the next lane (and holds it to its end), enqueues under one
 // short lock and then waits -- outside that lock -- for ONE event on its root device's stream: the copy of the answers is
-// the last operation of the call, and everything else of the call precedes it through stream order and events.  So while
+// the last operation of the call, and everything else of the call precedes it through stream order and events.  Queries,
+// sliced allow lists and answers pass through a page-locked buffer of the lane (copies from / to the caller's pageable
+// memory would hold the enqueuing thread -- and with it the enqueue lock -- until the device gets there).  So while
 // call i is in its all-gather / merge / D2H, call i+1 (other lane) is already walking the shards (every kdb_index keeps two
 // scratch sets for exactly this).  The collectives of BOTH lanes go through ONE communicator and ONE collective stream per
 // device, in the order the calls were enqueued -- the same order on every device, which is what RCCL needs to be
@@ -111,7 +113,10 @@ struct DevSlot {
 struct Lane {
     std::mutex mu;                  // held by the call that uses the lane, from its first enqueue to its last wait
     uint32_t root = 0;              // index into devs: where this lane's calls merge
-    hipEvent_t done = nullptr;      // on the root's lane stream: the answers have reached the caller's buffers
+    hipEvent_t done = nullptr;      // on the root's lane stream: the answers have reached the lane's page-locked buffer
+    unsigned char *h_pin = nullptr; // page-locked (portable): queries | sliced allow lists | merged answers of the call in
+    size_t h_pin_bytes = 0;         // flight -- every copy of a call is truly asynchronous, nothing waits under `enq`
+    size_t h_out = 0;               // offset of the answers (dist | ids | count) of the call in flight
 };
 
 } // namespace
@@ -145,11 +150,11 @@ extern "C" void kdb_cluster_destroy(kdb_cluster *c) {
         }
         if (d.coll) (void)hipStreamDestroy(d.coll);
     }
-    for (Lane &l : c->lanes)
-        if (l.done) {
-            if (!c->devs.empty()) (void)hipSetDevice(c->devs[l.root].device);
-            (void)hipEventDestroy(l.done);
-        }
+    for (Lane &l : c->lanes) {
+        if (!c->devs.empty()) (void)hipSetDevice(c->devs[l.root].device);
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.h_pin) (void)hipHostFree(l.h_pin);
+    }
     delete c;
 }
 
@@ -220,10 +225,12 @@ extern "C" int kdb_cluster_create(kdb_index *const *shards, const uint32_t *id_b
             return fail(KDB_ERR_HIP);
         }
     }
+    for (size_t i = 0; i < dev_of.size(); i++) { // every communicator has an owner before anything else can fail
+        c->devs[i].device = dev_of[i];
+        c->devs[i].comm = comms[i];
+    }
     for (size_t i = 0; i < dev_of.size(); i++) {
         DevSlot &d = c->devs[i];
-        d.device = dev_of[i];
-        d.comm = comms[i];
         bool ok = hipSetDevice(d.device) == hipSuccess && hipStreamCreateWithFlags(&d.coll, hipStreamNonBlocking) == hipSuccess;
         for (LaneDev &l : d.lane) {
             l.d_allow.assign(c->spd, nullptr);
@@ -266,9 +273,9 @@ static int ensure_bytes(void **p, size_t *have, size_t want) {
 }
 
 // bits [base+1, base+count] of a dense GLOBAL bitset -> the shard's local bitset (local id i <-> global id base+i)
-static void slice_allow(const uint64_t *g, size_t g_words, uint32_t base, uint32_t count, std::vector<uint64_t> &out) {
-    out.assign(((size_t)count >> 6) + 1, 0ull);
-    for (size_t w = 0; w < out.size(); w++) {
+static void slice_allow(const uint64_t *g, size_t g_words, uint32_t base, uint32_t count, uint64_t *out) {
+    const size_t n_out = ((size_t)count >> 6) + 1;
+    for (size_t w = 0; w < n_out; w++) {
         // local bits 64w .. 64w+63 = global bits base + 64w ..
         const uint64_t gb = (uint64_t)base + 64ull * w;
         const size_t gw = (size_t)(gb >> 6);
@@ -279,13 +286,23 @@ static void slice_allow(const uint64_t *g, size_t g_words, uint32_t base, uint32
     }
     out[0] &= ~1ull; // local id 0 does not exist
     const uint32_t last = count & 63u; // ids above count
-    out.back() &= last == 63u ? ~0ull : ((2ull << last) - 1ull);
+    out[n_out - 1] &= last == 63u ? ~0ull : ((2ull << last) - 1ull);
+}
+
+// an RCCL group that is closed on every path
+template <typename F>
+static int rccl_group(F body) {
+    KDB_NCCL(rccl().GroupStart());
+    const int rc = body();
+    const ncclResult_t e = rccl().GroupEnd();
+    if (rc) return rc;
+    KDB_NCCL(e);
+    return KDB_OK;
 }
 
 // everything of one call that is queued on the devices; the caller then waits for lane.done
 static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
-                           const uint64_t *allow_bits, size_t allow_words, uint32_t flags, uint32_t *out_ids, void *out_dist,
-                           uint32_t *out_count, std::vector<std::vector<uint64_t>> &host_bits) {
+                           const uint64_t *allow_bits, size_t allow_words, uint32_t flags) {
     Lane &lane = c->lanes[li];
     const uint32_t G = (uint32_t)c->shards.size(), nd = (uint32_t)c->devs.size(), spd = c->spd;
     const bool i8 = c->precision == KDB_PREC_I8; // distances travel as float64
@@ -305,19 +322,38 @@ static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queri
     }
     DevSlot &rdev = c->devs[lane.root];
     LaneDev &root = rdev.lane[li];
-    // 1. queries: H2D to the root, RCCL broadcast to the others (collective stream; the lanes' streams wait for it)
+    // the call's page-locked buffer: queries | allow slices | answers.  The lane is ours (its last call has waited for
+    // `done`), so nothing in flight uses the old one when it has to grow.
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t allow_total = 0;
+    if (allow_bits)
+        for (uint32_t g = 0; g < G; g++) allow_total += al((((size_t)c->shards[g]->count >> 6) + 1) * 8);
+    const size_t out_span = bk * 8 + bk * 4 + (size_t)B * 4;
+    const size_t pin_need = al(qbytes) + allow_total + al(out_span);
     KDB_HIP(hipSetDevice(rdev.device));
-    KDB_HIP(hipMemcpyAsync(root.d_q, queries, qbytes, hipMemcpyHostToDevice, root.stream));
+    if (lane.h_pin_bytes < pin_need) {
+        if (lane.h_pin) (void)hipHostFree(lane.h_pin);
+        lane.h_pin = nullptr;
+        lane.h_pin_bytes = 0;
+        KDB_HIP(hipHostMalloc((void **)&lane.h_pin, pin_need + pin_need / 4, hipHostMallocPortable));
+        lane.h_pin_bytes = pin_need + pin_need / 4;
+    }
+    lane.h_out = al(qbytes) + allow_total;
+    memcpy(lane.h_pin, queries, qbytes);
+    // 1. queries: H2D to the root, RCCL broadcast to the others (collective stream; the lanes' streams wait for it)
+    KDB_HIP(hipMemcpyAsync(root.d_q, lane.h_pin, qbytes, hipMemcpyHostToDevice, root.stream));
     if (nd > 1) {
         KDB_HIP(hipEventRecord(root.ev_ready, root.stream));
         KDB_HIP(hipStreamWaitEvent(rdev.coll, root.ev_ready, 0));
-        KDB_NCCL(rccl().GroupStart());
-        for (uint32_t i = 0; i < nd; i++) {
-            KDB_HIP(hipSetDevice(c->devs[i].device));
-            LaneDev &d = c->devs[i].lane[li];
-            KDB_NCCL(rccl().Broadcast(d.d_q, d.d_q, qbytes / 4, KDB_NCCL_INT32, (int)lane.root, c->devs[i].comm, c->devs[i].coll)); // in place at the root
-        }
-        KDB_NCCL(rccl().GroupEnd());
+        rc = rccl_group([&]() -> int {
+            for (uint32_t i = 0; i < nd; i++) {
+                KDB_HIP(hipSetDevice(c->devs[i].device));
+                LaneDev &d = c->devs[i].lane[li];
+                KDB_NCCL(rccl().Broadcast(d.d_q, d.d_q, qbytes / 4, KDB_NCCL_INT32, (int)lane.root, c->devs[i].comm, c->devs[i].coll)); // in place at the root
+            }
+            return KDB_OK;
+        });
+        if (rc) return rc;
         for (uint32_t i = 0; i < nd; i++) {
             KDB_HIP(hipSetDevice(c->devs[i].device));
             LaneDev &d = c->devs[i].lane[li];
@@ -326,8 +362,8 @@ static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queri
         }
     }
     // 2. every shard searches on its device, into its slot of the send buffer (no host wait anywhere in this loop: the
-    //    sliced allow lists stay alive in host_bits until the call's final wait)
-    if (allow_bits) host_bits.resize(G);
+    //    sliced allow lists sit in the lane's page-locked buffer until the call's final wait)
+    unsigned char *h_allow = lane.h_pin + al(qbytes);
     const uint32_t sflags = i8 ? (flags | KDB_SEARCH_DIST_F64) : flags;
     for (uint32_t g = 0; g < G; g++) {
         LaneDev &d = c->devs[g / spd].lane[li];
@@ -336,9 +372,11 @@ static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queri
         KDB_HIP(hipSetDevice(c->devs[g / spd].device));
         const uint64_t *d_allow = nullptr;
         if (allow_bits) {
-            slice_allow(allow_bits, allow_words, c->id_base[g], idx->count, host_bits[g]);
-            if ((rc = ensure_bytes((void **)&d.d_allow[ls], &d.allow_bytes[ls], host_bits[g].size() * 8))) return rc;
-            KDB_HIP(hipMemcpyAsync(d.d_allow[ls], host_bits[g].data(), host_bits[g].size() * 8, hipMemcpyHostToDevice, d.stream));
+            const size_t ab = (((size_t)idx->count >> 6) + 1) * 8;
+            slice_allow(allow_bits, allow_words, c->id_base[g], idx->count, reinterpret_cast<uint64_t *>(h_allow));
+            if ((rc = ensure_bytes((void **)&d.d_allow[ls], &d.allow_bytes[ls], ab))) return rc;
+            KDB_HIP(hipMemcpyAsync(d.d_allow[ls], h_allow, ab, hipMemcpyHostToDevice, d.stream));
+            h_allow += al(ab);
             d_allow = d.d_allow[ls];
         }
         uint32_t *blk = d.d_send + (size_t)ls * L;
@@ -353,19 +391,20 @@ static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queri
         KDB_HIP(hipEventRecord(d.ev_ready, d.stream));
         KDB_HIP(hipStreamWaitEvent(c->devs[i].coll, d.ev_ready, 0));
     }
-    KDB_NCCL(rccl().GroupStart());
-    for (uint32_t i = 0; i < nd; i++) {
-        KDB_HIP(hipSetDevice(c->devs[i].device));
-        LaneDev &d = c->devs[i].lane[li];
-        KDB_NCCL(rccl().AllGather(d.d_send, d.d_recv, (size_t)spd * L, KDB_NCCL_INT32, c->devs[i].comm, c->devs[i].coll));
-    }
-    KDB_NCCL(rccl().GroupEnd());
+    rc = rccl_group([&]() -> int {
+        for (uint32_t i = 0; i < nd; i++) {
+            KDB_HIP(hipSetDevice(c->devs[i].device));
+            LaneDev &d = c->devs[i].lane[li];
+            KDB_NCCL(rccl().AllGather(d.d_send, d.d_recv, (size_t)spd * L, KDB_NCCL_INT32, c->devs[i].comm, c->devs[i].coll));
+        }
+        return KDB_OK;
+    });
+    if (rc) return rc;
     // 4. merge on the root, answers home
     KDB_HIP(hipSetDevice(rdev.device));
     KDB_HIP(hipEventRecord(root.ev_coll, rdev.coll));
     KDB_HIP(hipStreamWaitEvent(root.stream, root.ev_coll, 0));
-    const size_t dist_b = out64 ? 8 : 4;
-    if ((rc = ensure_bytes((void **)&root.d_out, &root.out_bytes, bk * 8 + bk * 4 + (size_t)B * 4 + 16))) return rc;
+    if ((rc = ensure_bytes((void **)&root.d_out, &root.out_bytes, out_span + 16))) return rc;
     unsigned char *ob = reinterpret_cast<unsigned char *>(root.d_out);
     void *m_dist = ob; // (8-byte distances first)
     uint32_t *m_ids = reinterpret_cast<uint32_t *>(ob + bk * 8);
@@ -379,9 +418,8 @@ static int sharded_enqueue(kdb_cluster *c, int li, bool flat, const float *queri
                                    root.d_recv + o_cnt, L, L, root.d_bases, m_ids, reinterpret_cast<float *>(m_dist), m_cnt, root.stream);
     }
     if (rc) return rc;
-    KDB_HIP(hipMemcpyAsync(out_ids, m_ids, bk * 4, hipMemcpyDeviceToHost, root.stream));
-    KDB_HIP(hipMemcpyAsync(out_dist, m_dist, bk * dist_b, hipMemcpyDeviceToHost, root.stream));
-    KDB_HIP(hipMemcpyAsync(out_count, m_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, root.stream));
+    (void)m_cnt;
+    KDB_HIP(hipMemcpyAsync(lane.h_pin + lane.h_out, ob, out_span, hipMemcpyDeviceToHost, root.stream)); // dist | ids | count, one copy
     KDB_HIP(hipEventRecord(lane.done, root.stream));
     return KDB_OK;
 }
@@ -409,13 +447,12 @@ static int sharded_call(kdb_cluster *c, bool flat, const float *queries, uint32_
     }
     Lane &lane = c->lanes[li];
     std::lock_guard<std::mutex> hold(lane.mu); // the lane's buffers belong to this call until its answers are home
-    std::vector<std::vector<uint64_t>> host_bits;
     int rc;
     {
         std::lock_guard<std::mutex> lk(c->enq);
-        rc = sharded_enqueue(c, li, flat, queries, B, k, ef, allow_bits, allow_words, flags, out_ids, out_dist, out_count, host_bits);
+        rc = sharded_enqueue(c, li, flat, queries, B, k, ef, allow_bits, allow_words, flags);
     }
-    if (rc != KDB_OK) { // whatever was queued still reads the caller's and this frame's buffers: drain before returning
+    if (rc != KDB_OK) { // whatever was queued still uses the lane's buffers: drain before the lane is handed on
         for (DevSlot &d : c->devs) {
             (void)hipSetDevice(d.device);
             (void)hipStreamSynchronize(d.lane[li].stream);
@@ -428,6 +465,11 @@ static int sharded_call(kdb_cluster *c, bool flat, const float *queries, uint32_
     // blocks into THEIR receive buffers; the lane's next call orders itself behind them through the collective stream.
     KDB_HIP(hipSetDevice(c->devs[lane.root].device));
     KDB_HIP(hipEventSynchronize(lane.done));
+    const size_t bk = (size_t)B * k;
+    const unsigned char *h = lane.h_pin + lane.h_out;
+    memcpy(out_dist, h, bk * ((flags & KDB_SEARCH_DIST_F64) ? 8 : 4));
+    memcpy(out_ids, h + bk * 8, bk * 4);
+    memcpy(out_count, h + bk * 8 + bk * 4, (size_t)B * 4);
     return KDB_OK;
 }
 
