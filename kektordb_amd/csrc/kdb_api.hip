@@ -65,6 +65,7 @@ KdbView kdb_make_view(const kdb_index *idx) {
     v.adj0 = idx->d_adj0;
     v.adj_up = idx->d_adj_up;
     v.up_idx = idx->d_up_idx;
+    v.adj_up_slot = nullptr; // search_dev_locked hands the table over once it is known to be current
     v.levels = idx->d_levels;
     v.deleted = idx->d_deleted;
     v.dim = idx->desc.dim;
@@ -322,7 +323,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     (void)hipDeviceSynchronize(); // callers' streams may still run kernels of this index
     lane_store(idx);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
-                    idx->d_deleted, idx->d_ctr, idx->d_acc, idx->d_iobuf, idx->d_build, idx->d_rows16};
+                    idx->d_deleted, idx->d_ctr, idx->d_acc, idx->d_iobuf, idx->d_build, idx->d_rows16, idx->d_adj_up_slot};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (kdb_lane &l : idx->lanes) {
@@ -458,6 +459,7 @@ extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
+    idx->graph_epoch++; // (every writer of levels / up_idx / upper lists: the derived slot table is rebuilt by the next search)
     KDB_HIP(hipSetDevice(idx->device));
     const uint32_t n = g->count;
     const size_t n1 = (size_t)n + 1;
@@ -540,6 +542,7 @@ extern "C" int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_
     KDB_CHECK_IDX(idx);
     if (n == 0) return KDB_OK;
     std::lock_guard<std::mutex> lk(idx->mu);
+    idx->graph_epoch++;
     if (!levels || first_id != idx->count + 1 || (uint64_t)first_id + n - 1 > idx->cap) {
         kdb_set_error("append_nodes: ids must continue at count+1 = %u and stay within capacity %u", idx->count + 1, idx->cap);
         return KDB_ERR_INVALID;
@@ -594,6 +597,7 @@ extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
+    idx->graph_epoch++;
     if (idx->h_levels.size() != (size_t)idx->count + 1) {
         kdb_set_error("patch_adjacency: no graph to patch");
         return KDB_ERR_STATE;
@@ -778,6 +782,11 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         return KDB_ERR_STATE;
     }
     uint32_t entry = idx->entry;
+    {
+        int rc = kdb_ensure_up_slots(idx, s); // (a host compare unless the graph changed since the last search)
+        if (rc) return rc;
+        v.adj_up_slot = idx->d_adj_up_slot;
+    }
     const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
     KdbMultiAllow ma;
     if (ml && ml->G) { // one entry point per list, chosen on the device: no host round trip for any of the G lists
@@ -1253,6 +1262,7 @@ extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t
 extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params) {
     KDB_CHECK_IDX(idx);
     std::lock_guard<std::mutex> lk(idx->mu);
+    idx->graph_epoch++;
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);
     if (lane.rc) return lane.rc;
@@ -1267,6 +1277,7 @@ extern "C" int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
+    idx->graph_epoch++;
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);
     if (lane.rc) return lane.rc;

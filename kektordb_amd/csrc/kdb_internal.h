@@ -15,12 +15,16 @@
 #define KDB_UP_MARK_CAP 256u        // upper-layer visited un-mark list (per wave, LDS); overflow -> full clear
 
 // Device view of one index (passed by value to kernels).
+constexpr uint32_t KDB_NO_SLOT = 0xffffffffu;
+
 struct KdbView {
     const void *rows;        // (cap+1) rows of `ld` elements; row 0 and the pad columns are zero
     const float *norms;      // int8: quantizedNorms[id];  f32/L2: ||x||^2 for the flat scan; else null
     const uint32_t *adj0;    // (cap+1) * deg0 neighbour ids at level 0, 0 = empty slot (packed from the front)
     const uint32_t *adj_up;  // upper pool: slot s holds `deg_up` ids
     const uint32_t *up_idx;  // (cap+1): first upper slot of a node (valid when levels[id] >= 1)
+    const uint32_t *adj_up_slot; // beside adj_up: the upper slot of every listed neighbour AT THE LIST'S LEVEL (KDB_NO_SLOT: it lacks
+                                 // that level); null = not available (builder views, stale table): look levels / up_idx up
     const uint8_t *levels;   // (cap+1)
     const uint32_t *deleted; // bitset words, bit id
     uint32_t dim, ld;        // ld = row stride in elements (dim rounded up to 16)
@@ -81,6 +85,9 @@ struct kdb_index {
     uint8_t *d_levels = nullptr;
     uint32_t *d_deleted = nullptr;
     size_t up_slots = 0, up_slots_cap = 0;
+    uint32_t *d_adj_up_slot = nullptr;   // derived from levels / up_idx / adj_up by kdb_ensure_up_slots (latency-mode search)
+    size_t up_slot_cap = 0;              // slots it has room for
+    uint64_t graph_epoch = 1, up_slot_epoch = 0; // every writer of levels / up_idx / adj_up bumps graph_epoch
     uint16_t *d_rows16 = nullptr; // float32 indexes: the rows once more as halfs (ranking copy of the exact scan: half the bytes)
     float max_norm2 = 0.f; // largest ||x||^2 among the float32 rows uploaded so far (error band of the f16-ranked scan)
     // host copies of the per-node level and first upper slot (incremental refresh validates and places lists with them)
@@ -183,6 +190,7 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
                          float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s);
+int kdb_ensure_up_slots(kdb_index *idx, hipStream_t s);
 int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s);
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,

@@ -377,6 +377,13 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
     const uint32_t lane = (uint32_t)kdb_lane();
     uint32_t seen = 0u;
     uint32_t pf_node = 0u, pf_nb = 0u; // the list of the node wave 0 will most likely ask for next: requested a hop early
+    // upper layers: where the next node's list lies is known from the list it was found in (KdbView::adj_up_slot) or from the
+    // node visited last (its slots of consecutive levels are consecutive) -- levels[] / up_idx[] are looked up only when
+    // neither knows (a layer's very first node, traversal-only candidates)
+    uint32_t up_ids = 0u, up_sl = KDB_NO_SLOT; // per lane: the upper list visited last and its neighbours' slots
+    int up_level = -1;                          // ... and its level
+    uint32_t known_id = 0u, known_slot = 0u;    // the node visited last, its slot at known_level
+    int known_level = -1;
     uint32_t lvw = 0u;                 // of the layer search in progress (told with its BEGIN)
     int level = 0;
     const uint32_t *allow = nullptr;
@@ -410,11 +417,38 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
             if (level == 0) {
                 nb = pf_nb; // on its way since the hop before, when the guess was right
                 if (node != pf_node) nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
-            } else { // the node's level and its first upper slot are requested together
-                const int lv = (int)v.levels[node];
-                const uint32_t upi = v.up_idx[node];
-                has_level = lv >= level;
-                if (has_level) nb = lane < v.deg_up ? v.adj_up[((size_t)upi + (size_t)(level - 1)) * v.deg_up + lane] : 0u;
+            } else {
+                uint32_t slot = KDB_NO_SLOT;
+                bool slot_known = false;
+                if (v.adj_up_slot) {
+                    if (node == known_id && known_level >= level) {
+                        slot = known_slot - (uint32_t)(known_level - level);
+                        slot_known = true;
+                    } else if (up_level == level) {
+                        const unsigned long long hit = __ballot(lane < v.deg_up && up_ids == node);
+                        if (hit) {
+                            slot = readlane_u(up_sl, (uint32_t)__builtin_ctzll(hit)); // KDB_NO_SLOT: the node lacks this level
+                            slot_known = true;
+                        }
+                    }
+                }
+                if (!slot_known) { // the node's level and its first upper slot are requested together
+                    const int lv = (int)v.levels[node];
+                    const uint32_t upi = v.up_idx[node];
+                    slot = lv >= level ? upi + (uint32_t)(level - 1) : KDB_NO_SLOT;
+                }
+                has_level = slot != KDB_NO_SLOT;
+                if (has_level) {
+                    nb = lane < v.deg_up ? v.adj_up[(size_t)slot * v.deg_up + lane] : 0u;
+                    if (v.adj_up_slot) {
+                        up_sl = lane < v.deg_up ? v.adj_up_slot[(size_t)slot * v.deg_up + lane] : KDB_NO_SLOT;
+                        up_ids = nb;
+                        up_level = level;
+                        known_id = node;
+                        known_slot = slot;
+                        known_level = level;
+                    }
+                }
             }
             if (!has_level) {
                 n = KDB_W_N_SKIP;

@@ -572,6 +572,51 @@ int kdb_launch_adj_scatter(uint32_t *d_dst, uint32_t deg, uint32_t n, const uint
     return KDB_OK;
 }
 
+// The upper slot of every neighbour in an upper list, AT THE LIST'S LEVEL (KdbView::adj_up_slot): an upper hop of the
+// latency-mode walk then knows the list address of the node it goes to from the list it comes from -- levels[] and up_idx[]
+// need not be fetched (one dependent round trip to HBM less per upper hop).  Pure function of levels / up_idx / adj_up.
+__global__ void up_slot_kernel(const uint8_t *__restrict__ levels, const uint32_t *__restrict__ up_idx, const uint32_t *__restrict__ adj_up,
+                               uint32_t deg_up, uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t node = t / 16u + 1u, part = t % 16u; // 16 threads share a node's lists
+    if (node > count) return;
+    const uint32_t L = levels[node];
+    if (L == 0u) return;
+    const uint32_t first = up_idx[node];
+    for (uint32_t l = 1; l <= L; l++)
+        for (uint32_t j = part; j < deg_up; j += 16u) {
+            const size_t at = ((size_t)first + (l - 1u)) * deg_up + j;
+            const uint32_t e = adj_up[at];
+            out[at] = (e != 0u && e <= count && levels[e] >= l) ? up_idx[e] + (l - 1u) : KDB_NO_SLOT;
+        }
+}
+
+int kdb_ensure_up_slots(kdb_index *idx, hipStream_t s) {
+    if (idx->up_slot_epoch == idx->graph_epoch) return KDB_OK;
+    if (idx->up_slots == 0 || !idx->d_adj_up) { // no upper layer: nothing a walk could look up
+        idx->up_slot_epoch = idx->graph_epoch;
+        return KDB_OK;
+    }
+    if (idx->up_slot_cap < idx->up_slots) {
+        if (idx->d_adj_up_slot) {
+            KDB_HIP(hipDeviceSynchronize()); // walks of other streams may still read the old table
+            KDB_HIP(hipFree(idx->d_adj_up_slot));
+            idx->d_adj_up_slot = nullptr;
+            idx->up_slot_cap = 0;
+        }
+        const size_t cap = idx->up_slots_cap > idx->up_slots ? idx->up_slots_cap : idx->up_slots;
+        KDB_HIP(hipMalloc(&idx->d_adj_up_slot, (cap * idx->deg_up + 4) * 4));
+        idx->up_slot_cap = cap;
+    }
+    const unsigned long long threads = (unsigned long long)idx->count * 16ull;
+    hipLaunchKernelGGL(up_slot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, idx->d_levels, idx->d_up_idx, idx->d_adj_up,
+                       idx->deg_up, idx->count, idx->d_adj_up_slot);
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipStreamSynchronize(s)); // once per graph change: a walk of ANOTHER stream may be the next reader
+    idx->up_slot_epoch = idx->graph_epoch;
+    return KDB_OK;
+}
+
 int kdb_launch_first_allowed(const uint32_t *d_allow, uint32_t words, uint32_t *d_out, hipStream_t s) {
     KDB_HIP(hipMemsetAsync(d_out, 0xff, 4, s));
     uint32_t blocks = (words + 255) / 256;
