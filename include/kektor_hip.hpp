@@ -54,8 +54,10 @@ class Index {
         kdb_index_desc d{dim, metric, precision, m, efConstruction, capacity, device, 0};
         int rc = kdb_index_create(&d, &h_);
         if (rc) throw Error(rc, "hnsw.New");
+        (void)kdb_index_set_launch_timing(h_, 0); // a serving mirror never reads last_kernel_ms: two queue packets less per call
     }
     ~Index() { Close(); }
+    void SetLaunchTiming(bool on) { (void)kdb_index_set_launch_timing(h_, on ? 1 : 0); } // measurement harnesses
     // DB.Compress (core.go:1128-1290) on the device: a new index of `precision` (KDB_PREC_F16 / KDB_PREC_I8) over the same
     // graph (or re-inserted by the GPU builder when rebuildGraph); this index stays as it is
     std::unique_ptr<Index> Compress(uint32_t precision, bool rebuildGraph = false) const {
@@ -150,7 +152,9 @@ class Index {
     }
 
   private:
-    Index(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {}
+    Index(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {
+        (void)kdb_index_set_launch_timing(h_, 0);
+    }
     // distances of one call: floats, or -- int8 indexes -- the float64 values the reference computes (hnsw_index.go:2429-2454),
     // asked for with KDB_SEARCH_DIST_F64
     struct DistBuf {

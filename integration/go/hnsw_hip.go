@@ -105,6 +105,7 @@ func (m *gpuMirror) refresh(h *Index) error {
 		if rc := C.kdb_index_create(&desc, &m.h); rc != 0 {
 			return hipErr("kdb_index_create")
 		}
+		C.kdb_index_set_launch_timing(m.h, 0) // nobody reads last_kernel_ms here: two queue packets less per search
 	}
 	if err := m.uploadRows(h, nodes, count); err != nil {
 		return err

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "kdb_index_download_graph", "kdb_index_download_rows", "kdb_search_batch", "kdb_search_batch_dev",
     "kdb_search_set_trace", "kdb_flat_scan_batch", "kdb_flat_scan_batch_dev", "kdb_distance_batch",
     "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
-    "kdb_index_sync", "kdb_test_select_neighbors", "kdb_cluster_create", "kdb_cluster_destroy", "kdb_cluster_info",
+    "kdb_index_sync", "kdb_index_set_launch_timing", "kdb_test_select_neighbors", "kdb_cluster_create", "kdb_cluster_destroy", "kdb_cluster_info",
     "kdb_sharded_search_batch", "kdb_sharded_flat_scan_batch", "kdb_index_compress", "kdb_index_get_quantizer", "kdb_index_add_batch", "kdb_merge_topk_packed_f64_dev",
 ]
 
@@ -120,6 +120,7 @@ def load():
     L.kdb_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.kdb_get_launch_stats.argtypes = [vp, u32, C.POINTER(Counters)]
     L.kdb_index_sync.argtypes = [vp]
+    L.kdb_index_set_launch_timing.argtypes = [vp, C.c_int]
     L.kdb_test_select_neighbors.argtypes = [vp, u32, u32, vp, vp, vp, u32, vp, vp]
     L.kdb_index_compress.argtypes = [vp, u32, u32, C.POINTER(vp)]
     L.kdb_index_get_quantizer.argtypes = [vp, C.POINTER(C.c_float)]

@@ -170,6 +170,7 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
     idx->ev0 = idx->ring_ev0[slot];
     idx->ev1 = idx->ring_ev1[slot];
     idx->ring_kind[slot] = kind;
+    idx->ring_timed[slot] = kind != 1 || idx->time_launches;
     idx->ring_B[slot] = B;
     idx->ring_C[slot] = C;
     idx->last_kind = kind;
@@ -1419,7 +1420,7 @@ extern "C" int kdb_merge_topk_packed_f64_dev(kdb_index *idx, uint32_t G, uint32_
 static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     unsigned long long c[4] = {0, 0, 0, 0};
     float ms = 0.f;
-    if (hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
+    if (!idx->ring_timed[slot] || hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
         hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess)
         ms = 0.f;
     KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 4, 32, hipMemcpyDeviceToHost));
@@ -1471,6 +1472,13 @@ extern "C" int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counter
         int rc = stats_of_slot(idx, (uint32_t)(seq % kdb_index::RING), out + i);
         if (rc) return rc;
     }
+    return KDB_OK;
+}
+
+extern "C" int kdb_index_set_launch_timing(kdb_index *idx, int on) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->time_launches = on != 0;
     return KDB_OK;
 }
 

@@ -128,6 +128,8 @@ struct kdb_index {
     static constexpr uint32_t RING = 64;
     hipEvent_t ring_ev0[RING] = {}, ring_ev1[RING] = {};
     int ring_kind[RING] = {};
+    bool ring_timed[RING] = {};
+    bool time_launches = true;  // HIP events around the graph-search kernel (kdb_index_set_launch_timing)
     uint32_t ring_B[RING] = {}, ring_C[RING] = {};
     uint64_t launch_seq = 0;
     std::mutex mu;

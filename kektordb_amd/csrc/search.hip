@@ -672,11 +672,11 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         unsigned long long *d_acc = idx->d_acc + (d_ctr - idx->d_ctr); // the slot's accumulators: zero between launches (see the kernel's end)
-        KDB_HIP(hipEventRecord(idx->ev0, s));
+        if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev0, s));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
         KDB_HIP(hipGetLastError());
-        KDB_HIP(hipEventRecord(idx->ev1, s));
+        if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
     };
     if constexpr (BS == 1 || BS == 2) {

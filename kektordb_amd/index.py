@@ -134,6 +134,10 @@ class HipIndex:
     def set_quantizer(self, abs_max: float):
         check(self.L.kdb_index_set_quantizer(self.h, float(abs_max)), "set_quantizer")
 
+    def set_launch_timing(self, on: bool):
+        """HIP events around the graph-search launches (launch_stats' kernel_ms); off saves two queue packets per call"""
+        check(self.L.kdb_index_set_launch_timing(self.h, 1 if on else 0), "kdb_index_set_launch_timing")
+
     def set_count(self, count: int):
         check(self.L.kdb_index_set_count(self.h, int(count)), "set_count")
 

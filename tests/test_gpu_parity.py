@@ -997,6 +997,33 @@ def test_flat_scan_without_ranking_copy(oracle, hip):
             assert np.array_equal(raw_to_score(idx, dist[b, :int(cnt[b])]), od)
 
 
+def test_launch_timing_switch(oracle, hip):
+    """kdb_index_set_launch_timing(0): no HIP events around the search launches -- same answers, same counters (the kernel
+    publishes them itself), last_kernel_ms reads 0; back on, it is measured again"""
+    O = oracle
+    n, dim, k, ef = 3000, 64, 10, 40
+    X = make_corpus(n, dim, "normal", seed=7)
+    orc = O.OracleIndex(dim, 0, O.F32, 8, 40, seed=2)
+    orc.add_many(X)
+    idx = hip.HipIndex(dim, 0, 0, 8, 40, capacity=n + 4)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_graph_obj(orc.export_graph())
+    Q = make_corpus(33, dim, "normal", seed=8)
+    a = idx.search_batch(Q, k, ef)
+    ca = idx.counters()
+    assert ca["kernel_ms"] > 0
+    idx.set_launch_timing(False)
+    for _ in range(3):  # (consecutive launches re-use nothing of the one before: the counters re-arm themselves)
+        b = idx.search_batch(Q, k, ef)
+        cb = idx.counters()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert cb["kernel_ms"] == 0 and cb["n_dist"] == ca["n_dist"] and cb["n_hops"] == ca["n_hops"]
+    idx.set_launch_timing(True)
+    idx.search_batch(Q, k, ef)
+    cc = idx.counters()
+    assert cc["kernel_ms"] > 0 and cc["n_dist"] == ca["n_dist"]
+
+
 def test_ranking_copy_is_made_by_the_first_exact_scan(hip):
     """A float32 index allocates its half-precision ranking copy (+50 % row memory) when it is first scanned exactly,
     not at creation: walking it leaves the device memory as it was, rows added AFTER the copy exists are ranked too
