@@ -863,7 +863,8 @@ extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint
 // host-pointer wrapper: stage in, run, stage out (inputs consumed before return)
 template <typename F>
 static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits,
-                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run, size_t dist_bytes = 4) {
+                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run, size_t dist_bytes = 4,
+                          bool direct_out = false) {
     const size_t qbytes = (size_t)B * idx->desc.dim * 4;
     const size_t aw = allow_bits ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
     const size_t obytes = (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 16;
@@ -905,12 +906,24 @@ static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint
         if (allow_bits) memcpy(h_allow, allow_bits, aw);
         // queries and allow list sit side by side on both sides: one copy
         KDB_HIP(hipMemcpyAsync(d_q, h, allow_bits ? al(qbytes) + aw : qbytes, hipMemcpyHostToDevice, s));
-        rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
+        // Graph search, a few queries: the kernel writes its answers straight into the page-locked buffer (posted writes over
+        // PCIe; the end of the kernel makes them visible) -- no device-to-host copy command behind the kernel.  (Reading the
+        // QUERIES from there as well was measured slower: 1 query 0.180 against 0.171 ms.)
+        static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
+        const bool direct = direct_out && out_span <= direct_max;
+        if (direct) {
+            const size_t o_dist = (size_t)(reinterpret_cast<unsigned char *>(d_dist) - reinterpret_cast<unsigned char *>(d_ids));
+            const size_t o_cnt = (size_t)(reinterpret_cast<unsigned char *>(d_cnt) - reinterpret_cast<unsigned char *>(d_ids));
+            rc = run(d_q, d_allow, reinterpret_cast<uint32_t *>(h_out), reinterpret_cast<float *>(h_out + o_dist),
+                     reinterpret_cast<uint32_t *>(h_out + o_cnt), s);
+        } else {
+            rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
+        }
         if (rc) {
             (void)hipStreamSynchronize(s);
             return rc;
         }
-        KDB_HIP(hipMemcpyAsync(h_out, d_ids, out_span, hipMemcpyDeviceToHost, s));
+        if (!direct) KDB_HIP(hipMemcpyAsync(h_out, d_ids, out_span, hipMemcpyDeviceToHost, s));
         KDB_HIP(hipStreamSynchronize(s));
         memcpy(out_ids, h_out, (size_t)B * k * 4);
         memcpy(out_dist, h_out + (reinterpret_cast<unsigned char *>(d_dist) - reinterpret_cast<unsigned char *>(d_ids)), (size_t)B * k * dist_bytes);
@@ -1054,7 +1067,7 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     int rc = with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
                             [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
                                 return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                            }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4);
+                            }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4, true);
     if (rc == KDB_OK && (flags & KDB_SEARCH_FAIL_ON_DROP) && idx->n_deleted > 2047u && idx->launch_seq > 0 && idx->last_kind == 1) {
         // (the call is complete: with_staged_io synchronised the stream)
         unsigned long long c[4] = {0, 0, 0, 0};
