@@ -1094,11 +1094,13 @@ extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, u
 // index that is only ever walked never pays for it; KDB_INDEX_NO_F16_SHADOW keeps it away for good.  Called under idx->mu;
 // every row uploaded so far is in HBM (add_vectors returns after its copies), later uploads convert their own rows.
 static int ensure_rows16(kdb_index *idx, hipStream_t s) {
-    if (idx->d_rows16 || idx->desc.precision != KDB_PREC_F32 || (idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW)) return KDB_OK;
+    if (idx->d_rows16 || idx->rows16_refused || idx->desc.precision != KDB_PREC_F32 || (idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW))
+        return KDB_OK;
     const size_t n1 = (size_t)idx->desc.capacity + 1;
     if (hipMalloc(&idx->d_rows16, n1 * idx->ld * 2) != hipSuccess) {
         (void)hipGetLastError();
-        idx->d_rows16 = nullptr; // no room: the scan ranks on the float32 rows (same answers)
+        idx->d_rows16 = nullptr;    // no room: the scan ranks on the float32 rows (same answers) ...
+        idx->rows16_refused = true; // ... and does not ask again on every call
         return KDB_OK;
     }
     return kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, 0, idx->count + 1, s);

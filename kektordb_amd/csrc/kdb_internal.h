@@ -89,6 +89,7 @@ struct kdb_index {
     size_t up_slot_cap = 0;              // slots it has room for
     uint64_t graph_epoch = 1, up_slot_epoch = 0; // every writer of levels / up_idx / adj_up bumps graph_epoch
     uint16_t *d_rows16 = nullptr; // float32 indexes: the rows once more as halfs (ranking copy of the exact scan: half the bytes)
+    bool rows16_refused = false;  // its allocation failed once (no room): not retried
     float max_norm2 = 0.f; // largest ||x||^2 among the float32 rows uploaded so far (error band of the f16-ranked scan)
     // host copies of the per-node level and first upper slot (incremental refresh validates and places lists with them)
     std::vector<uint8_t> h_levels;
