@@ -1435,9 +1435,12 @@ extern "C" int kdb_merge_topk_packed_f64_dev(kdb_index *idx, uint32_t G, uint32_
 static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
     unsigned long long c[4] = {0, 0, 0, 0};
     float ms = 0.f;
-    if (!idx->ring_timed[slot] || hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
-        hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess)
+    if (!idx->ring_timed[slot]) {
+        KDB_HIP(hipDeviceSynchronize()); // no event to wait for: the launch may still be running on a stream of the caller
+    } else if (hipEventSynchronize(idx->ring_ev1[slot]) != hipSuccess ||
+               hipEventElapsedTime(&ms, idx->ring_ev0[slot], idx->ring_ev1[slot]) != hipSuccess) {
         ms = 0.f;
+    }
     KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)slot * 4, 32, hipMemcpyDeviceToHost));
     kdb_counters r{};
     r.last_kernel_ms = ms;
