@@ -476,12 +476,15 @@ def pcie_inclusive(idx, Q, k, ef):
         idx.search_batch(q, k, ef)
         reps = 5 if B >= 8192 else 21
         ts = []
-        for _ in range(reps):  # every call is complete when it returns: the median call (one slow call must not set the figure)
+        for _ in range(reps):  # every call is complete when it returns: the median call (one slow call must not set the figure:
+            # ~30 calls after batch_sweep one call takes 30-50 ms -- the sweep's two torch streams being destroyed when Python
+            # collects them (scripts/host_jitter_probe2.py: once, and only after the sweep))
             t0 = time.perf_counter()
             idx.search_batch(q, k, ef)
             ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
-        out[str(B)] = {"ms_per_batch": round(t * 1e3, 4), "qps": round(B / t, 1), "slowest_call_ms": round(max(ts) * 1e3, 4)}
+        out[str(B)] = {"ms_per_batch": round(t * 1e3, 4), "qps": round(B / t, 1), "slowest_call_ms": round(max(ts) * 1e3, 4),
+                       "slowest_call_index": int(np.argmax(ts))}
     return out
 
 
