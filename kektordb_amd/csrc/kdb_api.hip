@@ -309,8 +309,6 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     }
     KDB_TRY(hipMalloc(&idx->d_ctr, kdb_index::RING * 32));
     KDB_TRY(hipMemsetAsync(idx->d_ctr, 0, kdb_index::RING * 32, idx->stream));
-    KDB_TRY(hipMalloc(&idx->d_acc, kdb_index::RING * 32));
-    KDB_TRY(hipMemsetAsync(idx->d_acc, 0, kdb_index::RING * 32, idx->stream));
     KDB_TRY(hipStreamSynchronize(idx->stream));
 #undef KDB_TRY
     *out = idx;
@@ -324,7 +322,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     (void)hipDeviceSynchronize(); // callers' streams may still run kernels of this index
     lane_store(idx);
     void *bufs[] = {idx->d_rows,  idx->d_norms,   idx->d_adj0,    idx->d_adj_up, idx->d_up_idx, idx->d_levels,
-                    idx->d_deleted, idx->d_ctr, idx->d_acc, idx->d_iobuf, idx->d_build, idx->d_rows16, idx->d_adj_up_slot};
+                    idx->d_deleted, idx->d_ctr, idx->d_iobuf, idx->d_build, idx->d_rows16, idx->d_adj_up_slot};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (kdb_lane &l : idx->lanes) {
@@ -445,6 +443,7 @@ extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
+    if (count != idx->count) idx->graph_epoch++; // the derived upper-slot table tests ids against count
     idx->count = count;
     return KDB_OK;
 }
@@ -543,7 +542,6 @@ extern "C" int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_
     KDB_CHECK_IDX(idx);
     if (n == 0) return KDB_OK;
     std::lock_guard<std::mutex> lk(idx->mu);
-    idx->graph_epoch++;
     if (!levels || first_id != idx->count + 1 || (uint64_t)first_id + n - 1 > idx->cap) {
         kdb_set_error("append_nodes: ids must continue at count+1 = %u and stay within capacity %u", idx->count + 1, idx->cap);
         return KDB_ERR_INVALID;
@@ -559,6 +557,13 @@ extern "C" int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_
     KDB_HIP(hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
     size_t slots = idx->up_slots;
+    // the derived upper-slot table (kdb_ensure_up_slots) is a function of levels / up_idx / the upper lists: nodes that
+    // only exist at level 0 change none of its inputs, so the first search after such an append pays no rebuild
+    for (uint32_t i = 0; i < n; i++)
+        if (levels[i]) {
+            idx->graph_epoch++;
+            break;
+        }
     std::vector<uint32_t> up_new(n);
     for (uint32_t i = 0; i < n; i++) {
         up_new[i] = (uint32_t)slots;
@@ -598,7 +603,7 @@ extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_
         return KDB_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(idx->mu);
-    idx->graph_epoch++;
+    if (level >= 1) idx->graph_epoch++; // level-0 lists are no input of the derived upper-slot table
     if (idx->h_levels.size() != (size_t)idx->count + 1) {
         kdb_set_error("patch_adjacency: no graph to patch");
         return KDB_ERR_STATE;
@@ -1096,14 +1101,26 @@ extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, u
 static int ensure_rows16(kdb_index *idx, hipStream_t s) {
     if (idx->d_rows16 || idx->rows16_refused || idx->desc.precision != KDB_PREC_F32 || (idx->desc.reserved & KDB_INDEX_NO_F16_SHADOW))
         return KDB_OK;
-    const size_t n1 = (size_t)idx->desc.capacity + 1;
-    if (hipMalloc(&idx->d_rows16, n1 * idx->ld * 2) != hipSuccess) {
+    const size_t n1 = (size_t)idx->cap + 1;
+    uint16_t *copy = nullptr;
+    if (hipMalloc(&copy, n1 * idx->ld * 2) != hipSuccess) {
         (void)hipGetLastError();
-        idx->d_rows16 = nullptr;    // no room: the scan ranks on the float32 rows (same answers) ...
-        idx->rows16_refused = true; // ... and does not ask again on every call
+        idx->rows16_refused = true; // no room: the scan ranks on the float32 rows (same answers) and does not ask again
         return KDB_OK;
     }
-    return kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, 0, idx->count + 1, s);
+    // The copy is published only once it is COMPLETE: scans of other streams (the cluster's second lane, a second caller)
+    // and later uploads on idx->stream order against nothing but this wait -- a one-time cost of the first exact scan.
+    int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), copy, idx->ld, 0, idx->count + 1, s);
+    if (rc == KDB_OK && hipStreamSynchronize(s) != hipSuccess) {
+        kdb_set_error("half-precision ranking copy: conversion failed");
+        rc = KDB_ERR_HIP;
+    }
+    if (rc) {
+        (void)hipFree(copy);
+        return rc;
+    }
+    idx->d_rows16 = copy;
+    return KDB_OK;
 }
 
 static int flat_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, const uint64_t *d_allow_bits,

@@ -117,9 +117,8 @@ struct kdb_index {
     size_t build_bytes = 0;
     int last_kind = 0;              // 1 search, 2 flat scan, 3 distance tile
     uint32_t last_B = 0, last_C = 0;
-    uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words)
+    uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words; 32..39 = the graph search's self-resetting accumulators)
     unsigned long long *d_ctr = nullptr; // n_dist, n_hops
-    unsigned long long *d_acc = nullptr; // graph search: accumulator slots beside d_ctr's (self-resetting, search.hip)
     // trace
     uint32_t *trace_ndist = nullptr, *trace_nhops = nullptr;
     int trace_on_device = 0;

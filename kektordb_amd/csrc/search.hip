@@ -671,7 +671,11 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         int rc = kdb_ensure_visited(idx, grid, s);
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
-        unsigned long long *d_acc = idx->d_acc + (d_ctr - idx->d_ctr); // the slot's accumulators: zero between launches (see the kernel's end)
+        // the launch's accumulators {n_dist, n_hops, work | done, dropped}: zero between launches (see the kernel's end).  They
+        // belong to the call's SCRATCH LANE (words 32..39 of its d_work), not to the statistics ring: two launches that share
+        // a lane are ordered by the lane protocol (same stream, or an event wait on the previous user), so a launch never
+        // finds the words of another one that is still running -- whatever the number of launches in flight on other streams
+        unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(idx->d_work + 32);
         if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev0, s));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);

@@ -127,8 +127,23 @@ class ShardedSearch:
                 gathered.copy_(torch.stack(parts).to(dev))
             if self._dev_bases is None:
                 self._dev_bases = torch.from_numpy(self.bases.view(np.int32)).to(dev)
-            if i8:  # out_dist: float64 tensor
-                idx.merge_topk_packed_f64_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt, stream=raw)
+            if i8:
+                # the merge writes B*k DOUBLES (the reference's float64 order): a float64 out_dist takes them as they are,
+                # a float32 one gets their rounding through a temporary (never written past its end)
+                if out_dist.dtype == torch.float64:
+                    m_dist = out_dist
+                elif out_dist.dtype == torch.float32:
+                    mkey = ("m64", B, k, self._turn)
+                    if mkey not in self._bufs:
+                        self._bufs[mkey] = torch.zeros((B, k), dtype=torch.float64, device=dev)
+                    m_dist = self._bufs[mkey]
+                else:
+                    raise TypeError(f"out_dist must be float64 or float32 for int8 shards, got {out_dist.dtype}")
+                if out_dist.numel() < B * k or not out_dist.is_contiguous():
+                    raise ValueError("out_dist must be a contiguous tensor of at least B*k elements")
+                idx.merge_topk_packed_f64_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, m_dist, out_cnt, stream=raw)
+                if m_dist is not out_dist:
+                    out_dist.view(-1)[:B * k].copy_(m_dist.view(-1))
             else:
                 idx.merge_topk_packed_dev(self.world, B, k, gathered, L, self._dev_bases, out_ids, out_dist, out_cnt,
                                           stream=raw)

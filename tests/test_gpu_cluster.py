@@ -156,6 +156,40 @@ def test_sharded_int8_merges_float64_distances(oracle, hip):
         f32 = hip.HipIndex(16, 0, 0, 8, 20, capacity=64)
         hip.Cluster([f32], [0]).search_batch(np.zeros((1, 16), np.float32), 1, 10, flags=F64)   # float64 distances are an int8 option
     cl.close()
+    # ShardedSearch (shard.py) over an int8 shard with the exchange forced at one rank: a float64 out_dist takes the merge's
+    # doubles, a float32 one their rounding -- and is never written past its end (it used to be overrun)
+    import socket
+    import torch.distributed as tdist
+    from kektordb_amd.shard import ShardedSearch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tdist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        sh = ShardedSearch(1, O.I8, id_base=0, hip_index=shards[0], force_exchange=True)
+        for flat in (True, False):
+            o64 = torch.zeros((B, k), dtype=torch.float64, device=dev)
+            guard = torch.full((2 * B * k,), 7.0, dtype=torch.float32, device=dev)   # out_dist = its FIRST half
+            o32 = guard[:B * k].view(B, k)
+            i64, i32 = (torch.zeros((B, k), dtype=torch.int32, device=dev) for _ in range(2))
+            c64, c32 = (torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(2))
+            sh.search_dev(dq, k, 200, i64, o64, c64, flat=flat)
+            sh.search_dev(dq, k, 200, i32, o32, c32, flat=flat)
+            torch.cuda.synchronize()
+            assert torch.all(guard[B * k:] == 7.0), "a float32 out_dist was written past its end"
+            for b in range(B):
+                wi, wd = (orcs[0].flat_scan(Q[b], k) if flat else orcs[0].search(Q[b], k, ef=200))
+                c = int(c64[b])
+                assert c == len(wi) == int(c32[b])
+                assert np.array_equal(i64[b, :c].cpu().numpy().view(np.uint32), wi)
+                assert np.array_equal(i32[b, :c].cpu().numpy().view(np.uint32), wi)
+                assert np.array_equal(o64[b, :c].cpu().numpy(), wd)
+                assert np.array_equal(o32[b, :c].cpu().numpy(), wd.astype(np.float32))
+        with pytest.raises(TypeError):
+            sh.search_dev(dq, k, 200, i32, o32.to(torch.float16), c32)
+    finally:
+        tdist.destroy_process_group()
 
 
 def test_sharded_calls_of_two_threads_overlap_and_agree(oracle, hip):
