@@ -3,6 +3,8 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: the script starts its own N ranks under torch.distributed.run)
+    python bench.py --gpus N --cluster ...  (ONE process: kdb_cluster_create over N shards, ncclCommInitAll inside the library)
 
 A "step" is one pass of the hot path (kdb_search_batch_dev: query prep + batched HNSW traversal
 [+ RCCL all-gather of per-shard top-k + merge when N > 1]) over one batch of B synthetic queries that
@@ -62,6 +64,19 @@ def gen_corpus(n, dim, law, seed, dev, centers=None):
         x = centers[lab] + 0.3 * torch.randn((n, dim), device=dev, generator=g)
     x = x / x.norm(dim=1, keepdim=True)  # cosine: rows are stored normalised (hnsw_index.go:485-493)
     return x.contiguous()
+
+
+def upload_corpus(idx, n, dim, law, seed, dev, centers=None, chunk=2_000_000):
+    """rows 1..n of a shard, generated and uploaded chunk by chunk (12.5M x 768 rows are 38 GB: never held twice);
+    returns the rows themselves when they fit one chunk (the ground-truth cross-check wants them), else None"""
+    if n <= chunk:
+        X = gen_corpus(n, dim, law, seed, dev, centers)
+        idx.upload_rows(X, 1)
+        return X
+    for c, s0 in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - s0)
+        idx.upload_rows(gen_corpus(m, dim, law, seed * 1000 + c, dev, centers), 1 + s0)
+    return None
 
 
 def recall_at_k(ids, gt, k):
@@ -141,14 +156,41 @@ def main():
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # counter pass: fixed ef, timed launches only
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL all-gather + merge even with one rank (plumbing check on a 1-GPU box)")
+    ap.add_argument("--cluster", action="store_true",
+                    help="single-process route: --gpus shards behind ONE kdb_cluster handle (what the Go shim uses), host buffers")
+    ap.add_argument("--preset", default="", choices=["", "config4"],
+                    help="config4 = BASELINE configs[3]: 12.5M x 768 cosine rows PER RANK (100M over 8 GPUs), clustered law (ii), 8192 queries")
     a = ap.parse_args()
+    if a.preset == "config4":
+        a.n, a.dim, a.batch, a.corpus = 12_500_000, 768, 8192, "clustered"
+        a.no_extras = True
+
+    # ---- N > 1 from the plain command line: `python bench.py --gpus N` with no launcher around it starts its own N ranks
+    #      (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and relays their output
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.cluster and not a.inner:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd)}")
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
+    if a.cluster:
+        return cluster_main(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        log(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if world != a.gpus and not a.inner:
+        # a line that says n_gpus = N must come from N ranks: never bench fewer GPUs than asked for under the asked-for label
+        log(f"[bench] ERROR: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to continue")
+        sys.exit(2)
     ngpu = torch.cuda.device_count()
+    if a.backend == "nccl" and world > ngpu:
+        log(f"[bench] ERROR: {world} RCCL ranks need {world} visible GPUs, {ngpu} found (test rigs: --backend gloo shares one GPU)")
+        sys.exit(2)
     local_rank = local_rank % max(ngpu, 1) if a.backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -163,6 +205,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(a.backend)
+        # the communicator's own view: its world size, and one all-reduce in which every rank that really joined counts itself
+        one = torch.ones(1, dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if dist.get_world_size() != a.gpus or ranks_seen != a.gpus:
+            log(f"[bench] ERROR: {ranks_seen} ranks joined the communicator (world size {dist.get_world_size()}), --gpus {a.gpus}")
+            sys.exit(2)
+    else:
+        ranks_seen = 1
 
     import kektordb_amd as K
     from kektordb_amd.shard import ShardedSearch
@@ -175,14 +226,16 @@ def main():
         gc = torch.Generator(device=dev)
         gc.manual_seed(2)
         centers = torch.randn((4096, dim), device=dev, generator=gc)
-    X = gen_corpus(n, dim, a.corpus, 1000 + rank, dev, centers)         # this rank's shard
     Q = gen_corpus(B, dim, a.corpus, 11, dev, centers)                  # timed queries (same on all ranks)
     Qh = gen_corpus(4096, dim, a.corpus, 12, dev, centers)              # held-out queries: ef is chosen on these
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
     idx = K.HipIndex(dim, K.COSINE, K.F32, 16, a.efc, capacity=n, device_id=local_rank)
-    idx.upload_rows(X, 1)
+    t0 = time.time()
+    X = upload_corpus(idx, n, dim, a.corpus, 1000 + rank, dev, centers)  # this rank's shard
+    torch.cuda.synchronize()
+    t_gen += time.time() - t0
     t0 = time.time()
     idx.build(n, batch=a.build_batch, ef_construction=a.efc, seed=1 + rank)     # GPU batched construction
     t_build = time.time() - t0
@@ -277,6 +330,8 @@ def main():
         "value_pcie_inclusive": None,
         "unit": "queries/s",
         "n_gpus": world,
+        "rccl_ranks_seen": ranks_seen,   # counted BY the communicator (an all-reduce of ones over it), not taken from the command line
+        "collective_backend": (("rccl" if a.backend == "nccl" else a.backend) if use_dist else None),
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 4),
@@ -317,7 +372,7 @@ def main():
     }
 
     extras = rank == 0 and world == 1 and not a.no_extras
-    if extras:
+    if extras and X is not None:
         try:
             res["ground_truth_check"] = check_ground_truth(X, Q, gt, gt_o[1], k)
         except Exception as e:
@@ -391,6 +446,124 @@ def main():
     flush_all()
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def cluster_main(a):
+    """--cluster: the single-process route (kdb_cluster_create / kdb_sharded_search_batch, what the Go shim calls).  ONE
+    process owns --gpus id-range shards, shard g on device g // (shards per device); the library's own RCCL communicator
+    (ncclCommInitAll) broadcasts the queries and all-gathers the per-shard top-k; queries and answers are HOST buffers (the
+    C ABI of that route takes nothing else), so every figure of this mode includes the PCIe copies."""
+    import threading
+    import kektordb_amd as K
+    G = a.gpus
+    ngpu = torch.cuda.device_count()
+    n_dev = min(ngpu, G)
+    while G % n_dev:
+        n_dev -= 1
+    spd = G // n_dev
+    k, B, dim, n = a.k, a.batch, a.dim, a.n
+    shards, bases = [], []
+    t_gen = t_build = 0.0
+    Q = Qh = None
+    for g in range(G):
+        d = g // spd
+        dev = torch.device("cuda", d)
+        torch.cuda.set_device(d)
+        centers = None
+        if a.corpus == "clustered":
+            gc = torch.Generator(device=dev)
+            gc.manual_seed(2)
+            centers = torch.randn((4096, dim), device=dev, generator=gc)
+        if Q is None:
+            Q = gen_corpus(B, dim, a.corpus, 11, dev, centers).cpu().numpy()
+            Qh = gen_corpus(4096, dim, a.corpus, 12, dev, centers).cpu().numpy()
+        idx = K.HipIndex(dim, K.COSINE, K.F32, 16, a.efc, capacity=n, device_id=d)
+        t0 = time.time()
+        upload_corpus(idx, n, dim, a.corpus, 1000 + g, dev, centers)
+        torch.cuda.synchronize()
+        t_gen += time.time() - t0
+        t0 = time.time()
+        idx.build(n, batch=a.build_batch, ef_construction=a.efc, seed=1 + g)
+        t_build += time.time() - t0
+        shards.append(idx)
+        bases.append(g * n)
+        torch.cuda.empty_cache()
+    cl = K.Cluster(shards, bases)
+    info, comm = cl.info(), cl.comm_info()
+    if info["shards"] != G or comm["ranks_in_communicator"] != n_dev:
+        log(f"[bench] ERROR: cluster reports {info} / {comm}, expected {G} shards on {n_dev} devices")
+        sys.exit(2)
+    log(f"[bench] cluster: {G} shards x {n} rows on {n_dev} device(s), corpus {t_gen:.1f}s, GPU graph builds {t_build:.1f}s")
+    gt = cl.flat_scan_batch(Q, k)[0]
+    gth = cl.flat_scan_batch(Qh, k)[0]
+    sweep, ef = {}, a.ef
+    if ef == 0:
+        for cand in EF_GRID:
+            r = recall_at_k(cl.search_batch(Qh, k, cand)[0], gth, k)
+            sweep[cand] = round(r, 4)
+            if r >= a.recall + 0.001:
+                ef = cand
+                break
+        if ef == 0:
+            ef = max(sweep)
+            log(f"[bench] WARNING: recall target {a.recall} not reached; best {sweep[ef]} at ef={ef}")
+    log(f"[bench] ef sweep on {Qh.shape[0]} held-out queries {sweep} -> ef={ef}")
+    for _ in range(a.warmup):
+        ids = cl.search_batch(Q, k, ef)[0]
+    for d in range(n_dev):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ids = cl.search_batch(Q, k, ef)[0]     # returns when the merged answers are in host memory
+    elapsed = time.perf_counter() - t0
+    recall = recall_at_k(ids, gt, k)
+    st = [s.launch_stats(min(a.steps, 64)) for s in shards]
+    kernel_ms = float(np.mean([c["kernel_ms"] for c in st[0]]))
+    alg_bytes = float(np.mean([c["bytes"] for c in st[0]]))
+    # two callers in flight (the cluster keeps two lanes: call i+1 walks while call i exchanges / merges / copies)
+    def loop(m):
+        for _ in range(m):
+            cl.search_batch(Q, k, ef)
+    th = [threading.Thread(target=loop, args=(max(1, a.steps // 2),)) for _ in range(2)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    t2 = (time.perf_counter() - t0) / (2 * max(1, a.steps // 2))
+    res = {
+        "metric": "QPS at recall@10>=0.95, 1Mx768 cosine k=10",
+        "value": round(B * a.steps / elapsed, 1),
+        "value_definition": "queries answered per second over the whole corpus by ONE process driving every shard through kdb_sharded_search_batch: host "
+                            "buffers in, host buffers out (H2D of the queries, RCCL broadcast, per-shard walks, RCCL all-gather, merge, D2H inside the timed region)",
+        "unit": "queries/s", "n_gpus": G, "devices_used": n_dev, "shards_per_device": spd,
+        "rccl_ranks_seen": comm["ranks_in_communicator"], "collective_backend": "rccl (ncclCommInitAll inside the library)",
+        "route": "single process, kdb_cluster_create / kdb_sharded_search_batch",
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "recall_at_10": round(recall, 4),
+        "two_callers_in_flight": {"ms_per_batch": round(t2 * 1e3, 4), "qps": round(B / t2, 1)},
+        "config": {
+            "workload": f"{G} id-range shards of {n}x{dim} cosine k={k} (corpus {G * n} rows), batched-query HNSW per shard + RCCL all-gather of the "
+                        f"per-shard top-k + merge (M=16, efConstruction={a.efc}, efSearch={ef}, batch {B} queries/step)",
+            "corpus": ("clustered-4096 + 0.3*N(0,1), L2-normalised (SURVEY 8d C2-ii)" if a.corpus == "clustered" else "iid N(0,1), L2-normalised (SURVEY 8d C2-i)"),
+            "rows_per_gpu": n, "total_rows": n * G, "dim": dim, "k": k, "ef_search": ef, "queries_per_step": B,
+            "graph": f"built on the GPU by kdb_index_build, {t_build:.1f}s for all shards", "preset": a.preset or None,
+            "ef_sweep_recall_heldout": sweep,
+        },
+        "roofline": {"kernel": "hnsw_search_kernel<f32,cosine> (shard 0; every shard runs its own launch on its own device)", "bound": "hbm",
+                     "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": int(alg_bytes)},
+        "cpu_baseline": None,
+    }
+    if n_dev < G:
+        res["note"] = f"{G} shards share {n_dev} device(s) on this box: n_gpus names the shards asked for, devices_used the GPUs that ran them"
+    cl.close()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(res), flush=True)
 
 
 def check_ground_truth(X, Q, gt, gt_dots, k, nq=1024):

@@ -340,6 +340,16 @@ KDB_API int kdb_sharded_search_batch(kdb_cluster *c, const float *queries, uint3
 KDB_API int kdb_sharded_flat_scan_batch(kdb_cluster *c, const float *queries, uint32_t B, uint32_t k,
                                         const uint64_t *allow_bits, uint64_t allow_words, uint32_t flags, uint32_t *out_ids,
                                         float *out_dist, uint32_t *out_count);
+/* Failure model of a cluster: an error BEFORE anything was queued (bad argument, allocation) or BETWEEN two collectives (a
+ * shard's search refuses its arguments) leaves the handle usable.  A failure INSIDE an RCCL group -- a collective queued on
+ * some devices and not on others, after which the next collective would wait for ever -- POISONS the handle: every
+ * communicator is aborted (ncclCommAbort), the failing call returns its error, and every later call returns KDB_ERR_STATE
+ * at once (never a hang); destroy the cluster and create a new one.  kdb_cluster_comm_info: the number of ranks the
+ * communicator itself reports (ncclCommCount: the devices ncclCommInitAll joined) and whether the handle is poisoned.  */
+KDB_API int kdb_cluster_comm_info(const kdb_cluster *c, uint32_t *ranks_in_communicator, uint32_t *poisoned);
+/* TEST HOOK -- the next sharded call fails inside the RCCL group of stage 1 (query broadcast) or 2 (all-gather), with the
+ * collective queued on every device but the last: exercises the poisoning path without broken hardware.  0 disarms.  */
+KDB_API int kdb_cluster_debug_fail_next(kdb_cluster *c, uint32_t stage);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each

@@ -39,6 +39,16 @@ class Cluster:
         check(self.L.kdb_cluster_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "kdb_cluster_info")
         return {"shards": a.value, "devices": b.value, "shards_per_device": c.value}
 
+    def comm_info(self):
+        """what the communicator itself reports: its number of ranks (ncclCommCount), and whether the handle is poisoned"""
+        a, b = C.c_uint32(), C.c_uint32()
+        check(self.L.kdb_cluster_comm_info(self.h, C.byref(a), C.byref(b)), "kdb_cluster_comm_info")
+        return {"ranks_in_communicator": a.value, "poisoned": bool(b.value)}
+
+    def debug_fail_next(self, stage: int):
+        """test hook: the next call fails inside the RCCL group of stage 1 (broadcast) / 2 (all-gather)"""
+        check(self.L.kdb_cluster_debug_fail_next(self.h, stage), "kdb_cluster_debug_fail_next")
+
     def _call(self, fn, name, queries, k, ef, allow_bits, flags):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         B = q.shape[0]
