@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 1
+#define KDB_ABI_VERSION 2 /* 2: kdb_counters.n_tied; KDB_SEARCH_TIE_FLAG / KDB_SEARCH_HEAP_ORDER; kdb_index_reserve; cluster poisoning */
 #if defined(__GNUC__)
 #define KDB_API __attribute__((visibility("default")))
 #else
@@ -91,7 +91,23 @@ enum {
                                         * DOUBLES and receives the reference's float64 distances (hnsw_index.go:2429-2454 computes and *
                                         * orders them as float64).  Without the flag the same doubles are rounded to float on the way  *
                                         * out; the ORDER of the results is the float64 order either way.  Other precisions: INVALID.   */
+    ,
+    /* Equal distances.  The reference keeps candidates and results in two binary heaps (hnsw_heap.go): when two DIFFERENT nodes
+     * are at exactly the same distance from the query (duplicate vectors), which one it expands first, evicts from a full
+     * result set or reports first depends on the history of those heaps.  The walk of this library orders such nodes by id, so
+     * ids, their order and the walk's counters can differ from the reference's on exactly those queries -- and ONLY on those:
+     * a walk that never holds two nodes at one distance is the reference's walk step for step.                            */
+    KDB_SEARCH_TIE_FLAG = 1u << 4,    /* out_count[b] carries bit 31 (KDB_COUNT_TIED) when query b's walk met such a tie and *
+                                       * was not re-walked: mask the count with KDB_COUNT_MASK.  A shim can route exactly    *
+                                       * those queries to the reference's own Go walk.                                        */
+    KDB_SEARCH_HEAP_ORDER = 1u << 5   /* every such query is walked again, in the same call, with the reference's two heaps and  *
+                                       * their sift rules (hnsw_heap.go:53-82,122-151; search_heap.hip): ids, order, distances  *
+                                       * and counters are then the reference's, ties included.  The fast path is untouched; a   *
+                                       * tied query costs one slow walk.  With KDB_SEARCH_TIE_FLAG the bit stays set only on a   *
+                                       * query whose candidate heap outgrew its scratch (counted in kdb_counters.n_dropped).    */
 };
+#define KDB_COUNT_TIED 0x80000000u
+#define KDB_COUNT_MASK 0x7fffffffu
 
 typedef struct kdb_index kdb_index;
 
@@ -134,7 +150,11 @@ typedef struct {
     double last_kernel_ms; /* HIP-event duration of the dominant kernel of the last call */
     uint64_t n_dropped;    /* graph search: pending traversal-only candidates (deleted    *
                             * nodes) discarded because more than 2048 were waiting; 0 =   *
-                            * the walk was the reference's, step for step                 */
+                            * the walk was the reference's, step for step (under         *
+                            * KDB_SEARCH_HEAP_ORDER also: tied walks left unresolved)     */
+    uint64_t n_tied;       /* graph search: queries whose walk met two different nodes at  *
+                            * EQUAL distance (the reference's order then depends on its    *
+                            * heaps' history: KDB_SEARCH_TIE_FLAG / KDB_SEARCH_HEAP_ORDER)  */
 } kdb_counters;
 
 typedef struct {
@@ -151,6 +171,14 @@ KDB_API const char *kdb_last_error(void);
 
 KDB_API int kdb_index_create(const kdb_index_desc *desc, kdb_index **out);
 KDB_API void kdb_index_destroy(kdb_index *idx);
+/* growNodes (pkg/core/hnsw/hnsw_index.go:2732-2768: the reference doubles its node table when an id outgrows it): raise the
+ * capacity of a live index.  Rows, ranking copy, norms, lists, levels and deleted bits move to larger allocations ON THE DEVICE
+ * (nothing is re-uploaded; the graph stays); a capacity at or below the current one is a no-op; KDB_ERR_OOM leaves the index as
+ * it was.  The call waits for the device (walks in flight read the arrays that move).                                       */
+KDB_API int kdb_index_reserve(kdb_index *idx, uint32_t new_capacity);
+/* Give back the half-precision ranking copy of a float32 index (see KDB_INDEX_NO_F16_SHADOW); the next exact scan makes it
+ * again unless refuse_for_good != 0.                                                                                        */
+KDB_API int kdb_index_drop_f16_shadow(kdb_index *idx, int refuse_for_good);
 
 /* Incremental refresh of the mirror after writers (Add / AddBatch / optimizer) touched a FEW nodes, instead of a full
  * kdb_index_upload_graph:
@@ -264,7 +292,9 @@ KDB_API int kdb_distance_batch_dev(kdb_index *idx, const float *d_queries, uint3
 KDB_API int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t flags, kdb_index **out);
 KDB_API int kdb_index_get_quantizer(kdb_index *idx, float *abs_max);
 
-/* GPU batched graph construction over rows 1..count already uploaded.                             */
+/* GPU batched graph construction over rows 1..count already uploaded (efConstruction up to 512).  Deterministic: two builds
+ * of the same rows with the same parameters give the same graph, list for list (a target that more new nodes ask for a
+ * reverse link than it has request slots keeps the NEAREST requesters, not the first to arrive).                       */
 KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params);
 
 /* AddBatch -> addBatchInternal (hnsw_index.go:1479-2088) for rows ALREADY uploaded at ids first_id .. first_id+n-1 (phase 0 /
@@ -277,14 +307,16 @@ KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_para
  * (randomLevel, :2616-2625; capped at maxLevel+1 like there).  first_id = count+1 appends; first_id = count re-uses the last
  * slot, which is what the reference's id arithmetic does for the first batch after single Adds (:1620 vs :590).  The index
  * must hold a graph (the reference inserts its first efConstruction nodes one by one, :1505-1516: upload those).
- * At most 4096 - mMax0 nodes per call.  KDB_ERR_UNSUPPORTED (lists still consistent) when a re-used slot would have to grow
- * a level.  float32 / float16 / int8.                                                                              */
+ * Any number of nodes per call (the reference's Compress re-inserts 5000 at a time, core.go:1240): a target whose union of links
+ * and requests outgrows LDS (4096 entries) is sorted in HBM scratch.  A re-used slot that is asked for links above its new
+ * level GROWS, as the reference's node does (:2049-2053): afterwards its level is the highest one asked for.  efConstruction
+ * up to 512.  A failure leaves the index as it was (same count, entry point, levels).  float32 / float16 / int8.      */
 #define KDB_ADD_REFERENCE_LINKS 1u /* (the only linking this entry point has; accepted for symmetry with kdb_build_params.flags) */
 KDB_API int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction,
                                 uint32_t flags);
 
 /* TEST HOOK -- selectNeighbors (hnsw_index.go:2629-2701) exactly as the GPU builder runs it (build_select_kernel's
- * workgroup routine), on caller-supplied candidate lists: list t holds cand_cnt[t] <= stride <= 320 entries at
+ * workgroup routine), on caller-supplied candidate lists: list t holds cand_cnt[t] <= stride <= 576 entries at
  * cand_ids / cand_keys + t*stride, ids of rows already uploaded, keys = distance of the candidate to the centre in the
  * library's ordering form, ASCENDING: FLOATS for float32 / float16 indexes (squared L2; MINUS the dot product for cosine),
  * DOUBLES for int8 indexes (the reference's float64 cosine distance, hnsw_index.go:317-336).  out_ids: [n_lists][maxm],
@@ -350,6 +382,13 @@ KDB_API int kdb_cluster_comm_info(const kdb_cluster *c, uint32_t *ranks_in_commu
 /* TEST HOOK -- the next sharded call fails inside the RCCL group of stage 1 (query broadcast) or 2 (all-gather), with the
  * collective queued on every device but the last: exercises the poisoning path without broken hardware.  0 disarms.  */
 KDB_API int kdb_cluster_debug_fail_next(kdb_cluster *c, uint32_t stage);
+
+/* MEASUREMENT HOOKS (probe.hip) -- what this device delivers on the two access patterns of the hot path, on the index's own row
+ * array: a uniform random whole-row gather (16 lanes per row, best of four launch shapes) and one coalesced streaming pass.
+ * which: 0 = the stored rows, 1 = the half-precision ranking copy.  *ms = duration of the best launch, *bytes = what it read.
+ * bench.py reports its roofline fractions against these beside the nominal HBM peak.  Blocking.              */
+KDB_API int kdb_probe_gather(kdb_index *idx, int which, uint64_t n_reads, float *ms, uint64_t *bytes);
+KDB_API int kdb_probe_stream(kdb_index *idx, int which, float *ms, uint64_t *bytes);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each

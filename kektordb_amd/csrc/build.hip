@@ -30,6 +30,7 @@
 #include "kdb_search_core.cuh"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 using namespace kdbcore;
@@ -41,7 +42,8 @@ constexpr int PR_STRIDE = PR_KC + 4;  // LDS row stride: 33 sixteen-byte slots -
 constexpr int PR_BLK = 32;            // candidates resolved per step
 constexpr int PR_U = 10;              // pair slots per thread: 32*63 + 496 pairs <= 10*256
 constexpr int PR_MAXSEL = 64;         // maxM <= 64
-constexpr int PR_MAXC = 320;          // max candidates per prune task (efC <= 256, 64 existing + requests)
+constexpr int PR_MAXC = 576;          // max candidates per prune task (efC <= 512, 64 existing + requests)
+constexpr uint32_t KDB_MAX_EFC = 512;  // BENCHMARKS.md:84 publishes M=32, efConstruction=400
 constexpr uint32_t RCAP = 16;         // reverse requests kept per (target, level) per batch
 constexpr uint32_t UP_FLAG = 0x80000000u;
 
@@ -66,6 +68,13 @@ struct BuildViewT {
     KT *cand_key;
     uint32_t *cand_cnt;  // [tasks]
     uint32_t *up_task;   // [batch] first upper task of a batch node
+    // reverse requests beyond the RCAP slots of their target (hubs): appended here, so that the commit can keep the RCAP NEAREST
+    // requesters whatever order they arrived in (two builds of the same rows then give the same graph)
+    uint32_t *ov_code;   // [ov_cap] target code (level-0 id, or UP_FLAG | upper slot)
+    uint32_t *ov_id;     // [ov_cap] requester
+    KT *ov_key;          // [ov_cap] its distance to the target
+    uint32_t *ov_cnt;    // entries appended this batch
+    uint32_t ov_cap;
     uint32_t efc;
     uint32_t first;      // first id of the batch
     uint32_t nb;         // batch size
@@ -85,13 +94,23 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
     s.beam_d = nullptr;
     s.beam_id = nullptr;
     s.beam_cap = 0;
+    s.beam_lo = nullptr;
+    if constexpr (BS == 0) { // efConstruction above 384: the beam lives in LDS
+        s.beam_d = reinterpret_cast<float *>(smem + off);
+        off += (size_t)beam_cap * 4;
+        s.beam_id = reinterpret_cast<uint32_t *>(smem + off);
+        off += (size_t)beam_cap * 4;
+        if (I8) {
+            s.beam_lo = reinterpret_cast<uint32_t *>(smem + off);
+            off += (size_t)beam_cap * 4;
+        }
+        s.beam_cap = beam_cap;
+    }
     s.nr_d = nullptr; // construction never meets a deleted node or a filter
     s.nr_id = nullptr;
     s.nr_cap = 0;
-    s.beam_lo = nullptr;
     s.nr_lo = nullptr;
     s.ctl = nullptr;
-    (void)beam_cap;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
     s.nb_d = reinterpret_cast<float *>(smem + off);
@@ -131,7 +150,9 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
         }
         __threadfence_block();
         wave_lds_fence();
-        RegBeam<BS, I8> b;
+        typename std::conditional<BS == 0, LdsBeamT<I8>, RegBeam<(BS == 0 ? 1 : BS), I8>>::type b;
+        b.bind(s);
+        b.tied = 0u;
         QCtr ctr{};
         uint32_t ep = v.entry;
         EpKnown epk; // the next level's entry point is this level's nearest candidate: its distance is known
@@ -466,6 +487,13 @@ build_select_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv) {
         if (slot < RCAP) {
             rid[slot] = node;
             rkey[slot] = p.s_key[tid];
+        } else { // a hub: parked; the commit picks the RCAP nearest of ALL its requesters
+            const uint32_t o = atomicAdd(bv.ov_cnt, 1u);
+            if (o < bv.ov_cap) {
+                bv.ov_code[o] = code;
+                bv.ov_id[o] = node;
+                bv.ov_key[o] = p.s_key[tid];
+            }
         }
         if (slot == 0) bv.touched[atomicAdd(bv.n_touched, 1u)] = code;
     }
@@ -501,17 +529,76 @@ build_reverse_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t 
         rkey = bv.rev0_key + (size_t)code * RCAP;
         maxm = v.deg0;
     }
-    uint32_t &sh_ne = p.misc[2], &sh_nr = p.misc[3];
+    uint32_t &sh_ne = p.misc[2], &sh_nr = p.misc[3], &sh_all = p.misc[4], &sh_g = p.misc[5];
     if (tid == 0) {
         uint32_t ne = 0;
         while (ne < maxm && adj[ne] != 0u) ne++;
-        uint32_t nr = *cnt;
-        if (nr > RCAP) nr = RCAP;
+        const uint32_t all = *cnt;
         sh_ne = ne;
-        sh_nr = nr;
+        sh_nr = all > RCAP ? RCAP : all;
+        sh_all = all;
+        sh_g = 0u;
         *cnt = 0; // ready for the next batch
     }
     __syncthreads();
+    if (sh_all > RCAP) {
+        // A hub: more requesters than slots.  Which RCAP of them reached the slots first is an accident of scheduling; the ones
+        // that stay are the RCAP NEAREST by (distance, id): the slot entries and the target's parked requests are gathered into
+        // LDS (the row tile is idle here), sorted, and the first RCAP written back to the slots.
+        constexpr uint32_t GCAP = 4096u; // a power of two (the sort pads to one); 48 KB of the 50 KB row tile with 8-byte keys
+        static_assert((size_t)GCAP * (sizeof(KT) + 4) <= (size_t)(PR_BLK + PR_MAXSEL) * PR_STRIDE * 4, "hub scratch must fit the row tile");
+        KT *g_key = reinterpret_cast<KT *>(p.rows);
+        uint32_t *g_id = reinterpret_cast<uint32_t *>(g_key + GCAP);
+        if ((uint32_t)tid < RCAP) {
+            g_key[tid] = rkey[tid];
+            g_id[tid] = rid[tid];
+        }
+        if (tid == 0) sh_g = RCAP;
+        __syncthreads();
+        const uint32_t n_ov = *bv.ov_cnt < bv.ov_cap ? *bv.ov_cnt : bv.ov_cap;
+        for (uint32_t i = (uint32_t)tid; i < n_ov; i += 256)
+            if (bv.ov_code[i] == code) {
+                const uint32_t at = atomicAdd(&sh_g, 1u);
+                if (at < GCAP) { // (a target with more than GCAP = 4096 requesters in ONE batch keeps the first GCAP found)
+                    g_key[at] = bv.ov_key[i];
+                    g_id[at] = bv.ov_id[i];
+                }
+            }
+        __syncthreads();
+        const uint32_t ng = sh_g < GCAP ? sh_g : GCAP;
+        uint32_t P = 64;
+        while (P < ng) P <<= 1;
+        for (uint32_t i = ng + (uint32_t)tid; i < P; i += 256) {
+            g_key[i] = (KT)INFINITY;
+            g_id[i] = 0xffffffffu;
+        }
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= P; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = (uint32_t)tid; i < P; i += 256) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k2) == 0u;
+                        const KT kx = g_key[i], ky = g_key[l];
+                        const uint32_t ix = g_id[i], iy = g_id[l];
+                        const bool gt = kx > ky || (kx == ky && ix > iy);
+                        if (gt == up) {
+                            g_key[i] = ky;
+                            g_key[l] = kx;
+                            g_id[i] = iy;
+                            g_id[l] = ix;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        if ((uint32_t)tid < RCAP) {
+            rid[tid] = g_id[tid];
+            rkey[tid] = g_key[tid];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     const uint32_t ne = sh_ne, nr = sh_nr;
     const uint32_t n = ne + nr;
     // gather E then R; requesters ordered by id so the result does not depend on atomic order
@@ -567,13 +654,17 @@ build_reverse_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t 
 //     as (distance, id), as in the oracle -- and pruned by selectNeighbors (:2015-2040).
 // A target is one workgroup; its union (<= maxM + batch size entries) is sorted in LDS.
 // =====================================================================================================================
-constexpr uint32_t RL_UCAP = 4096; // union entries per (target, level): batches of at most RL_UCAP - mMax0 nodes
+constexpr uint32_t RL_UCAP = 4096; // union entries per (target, level) sorted in LDS; longer unions go through HBM scratch (rl_commit_big_kernel)
 
 // combined request counters: [0, n1) level-0 targets by id, [n1, n1 + slots] upper targets by slot
+// reuse_id / reuse_levels: the slot the batch's first node took over (hnsw_index.go:1620; 0 = none) and the number of upper
+// slots it owns = max(its new level, the level of the node it replaced).  Old links still name it at the replaced node's
+// levels, so a walk can meet it ABOVE its new level and ask it for a reverse link there; the reference then grows that node's
+// Connections (:2049-2053).  Its slots are allocated up front; *grew (atomicMax) records the highest level that was asked for.
 template <typename KT>
 __global__ void __launch_bounds__(256)
 rl_count_kernel(KdbView v, BuildViewT<KT> bv, uint32_t n1, uint32_t *cnt, uint32_t *slot_owner, uint32_t *cursor /* null: count; else fill */,
-                const uint32_t *off, uint32_t *req, uint32_t *err) {
+                const uint32_t *off, uint32_t *req, uint32_t *err, uint32_t reuse_id, uint32_t reuse_levels, uint32_t *grew) {
     const uint32_t task = blockIdx.x;
     uint32_t node, level;
     task_owner(bv, task, node, level);
@@ -592,8 +683,11 @@ rl_count_kernel(KdbView v, BuildViewT<KT> bv, uint32_t n1, uint32_t *cnt, uint32
             // a candidate evaluated at a level above its own: only the slot the reference's batch path re-uses (:1620) can be
             // one -- the reference then GROWS that node's Connections; the fixed upper slots here cannot: counted, skipped
             if ((uint32_t)v.levels[c] < level) {
-                if (!cursor) atomicAdd(err, 1u);
-                continue;
+                if (c != reuse_id || level > reuse_levels) { // (cannot happen: only the re-used slot is ever met above its level)
+                    if (!cursor) atomicAdd(err, 1u);
+                    continue;
+                }
+                if (!cursor) atomicMax(grew, level);
             }
             code = n1 + v.up_idx[c] + (level - 1u);
             if (!cursor) slot_owner[code - n1] = c;
@@ -638,61 +732,20 @@ rl_scan_kernel(const uint32_t *cnt, uint32_t L, uint32_t *off, uint32_t *touched
 template <typename T>
 __device__ __forceinline__ void rl_swap(T &a, T &b) { T t = a; a = b; b = t; }
 
+// One (target, level): current links + requests -> the new list (phase 3 as written, :1975-2055).  The union lives in u_id /
+// u_key / u_tmp (`ucap` entries, a power of two): LDS for ordinary targets, HBM scratch for the few whose union outgrows it
+// (rl_commit_big_kernel) -- the code is the same, __syncthreads orders both.
 template <int METRIC, int PREC>
-__global__ void __launch_bounds__(256)
-rl_commit_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const uint32_t *touched, const uint32_t *cnt, const uint32_t *off,
-                 const uint32_t *req, const uint32_t *slot_owner, uint32_t *err) {
+__device__ void rl_commit_body(const KdbView &v, PruneLdsT<typename BKey<PREC>::T> &p, uint32_t *adj, uint32_t maxm, uint32_t t, uint32_t ne,
+                               const uint32_t *req_t, uint32_t nreq, typename BKey<PREC>::T *u_key, uint32_t *u_id, uint32_t *u_tmp, float *w_d,
+                               uint32_t *w_lo, float *tq, uint32_t *sh) {
     using KT = typename BKey<PREC>::T;
     constexpr bool I8 = PREC == KDB_PREC_I8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PruneLdsT<KT> p;
-    prune_carve(smem, p);
-    size_t o = prune_lds_bytes<KT>();
-    KT *u_key = reinterpret_cast<KT *>(smem + o);
-    o += (size_t)RL_UCAP * sizeof(KT);
-    uint32_t *u_id = reinterpret_cast<uint32_t *>(smem + o);
-    o += (size_t)RL_UCAP * 4;
-    uint32_t *u_tmp = reinterpret_cast<uint32_t *>(smem + o); // de-dup scratch
-    o += (size_t)RL_UCAP * 4;
-    float *w_d = reinterpret_cast<float *>(smem + o); // [4][64] distances of a wave's chunk
-    o += 4 * 64 * 4;
-    uint32_t *w_lo = reinterpret_cast<uint32_t *>(smem + o);
-    o += 4 * 64 * 4;
-    float *tq = reinterpret_cast<float *>(smem + o); // the target's row as the query
-    __shared__ uint32_t sh[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t code = touched[blockIdx.x];
-    uint32_t t, level, maxm;
-    uint32_t *adj;
-    if (code < n1) {
-        t = code;
-        level = 0;
-        maxm = v.deg0;
-        adj = adj0 + (size_t)t * v.deg0;
-    } else {
-        const uint32_t ts = code - n1;
-        t = slot_owner[ts];
-        level = ts - v.up_idx[t] + 1u;
-        maxm = v.deg_up;
-        adj = adj_up + (size_t)ts * v.deg_up;
-    }
-    (void)level;
-    if ((v.deleted[t >> 5] >> (t & 31u)) & 1u) return; // "node == nil || node.Deleted: skip" (:1927-1930)
-    const uint32_t nreq = cnt[code];
-    if (tid == 0) {
-        uint32_t ne = 0;
-        while (ne < maxm && adj[ne] != 0u) ne++;
-        sh[0] = ne;
-    }
-    __syncthreads();
-    const uint32_t ne = sh[0], nu = ne + nreq;
-    if (nu > RL_UCAP) {
-        if (tid == 0) atomicAdd(err + 1, 1u);
-        return;
-    }
+    const uint32_t nu = ne + nreq;
     uint32_t P = 64;
     while (P < nu) P <<= 1;
-    for (uint32_t i = tid; i < P; i += 256) u_id[i] = i < ne ? adj[i] : i < nu ? req[off[code] + (i - ne)] : 0xffffffffu;
+    for (uint32_t i = tid; i < P; i += 256) u_id[i] = i < ne ? adj[i] : i < nu ? req_t[i - ne] : 0xffffffffu;
     __syncthreads();
     // slices.Sort(uniqueIDs) (:1985)
     for (uint32_t k = 2; k <= P; k <<= 1)
@@ -761,6 +814,8 @@ rl_commit_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const
         s.q = tq;
         s.nb_d = w_d + wave * 64u;
         s.nb_lo = I8 ? w_lo + wave * 64u : nullptr;
+        uint32_t *w_id = u_tmp + wave * 64u; // (free again: the ids of a wave's chunk, in LDS or scratch alike)
+        (void)w_id;
         for (uint32_t c0 = wave * 64u; c0 < np; c0 += 256u) {
             const uint32_t cn = np - c0 < 64u ? np - c0 : 64u;
             s.nb_id = u_id + c0;
@@ -807,6 +862,105 @@ rl_commit_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const
     if (tid < maxm) adj[tid] = tid < nsel ? p.s_id[tid] : 0u;
 }
 
+// which (target, level) a touched code names
+__device__ __forceinline__ void rl_target(const KdbView &v, uint32_t code, uint32_t n1, const uint32_t *slot_owner, uint32_t *adj0, uint32_t *adj_up,
+                                          uint32_t &t, uint32_t &maxm, uint32_t *&adj) {
+    if (code < n1) {
+        t = code;
+        maxm = v.deg0;
+        adj = adj0 + (size_t)t * v.deg0;
+    } else {
+        const uint32_t ts = code - n1;
+        t = slot_owner[ts];
+        maxm = v.deg_up;
+        adj = adj_up + (size_t)ts * v.deg_up;
+    }
+}
+
+// ucap: union entries the LDS holds (a power of two); targets beyond it are listed for rl_commit_big_kernel (err[1] counts them)
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+rl_commit_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const uint32_t *touched, const uint32_t *cnt, const uint32_t *off,
+                 const uint32_t *req, const uint32_t *slot_owner, uint32_t *err, uint32_t ucap, uint32_t *big_list) {
+    using KT = typename BKey<PREC>::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLdsT<KT> p;
+    prune_carve(smem, p);
+    size_t o = prune_lds_bytes<KT>();
+    KT *u_key = reinterpret_cast<KT *>(smem + o);
+    o += (size_t)ucap * sizeof(KT);
+    uint32_t *u_id = reinterpret_cast<uint32_t *>(smem + o);
+    o += (size_t)ucap * 4;
+    uint32_t *u_tmp = reinterpret_cast<uint32_t *>(smem + o); // de-dup scratch
+    o += (size_t)ucap * 4;
+    float *w_d = reinterpret_cast<float *>(smem + o); // [4][64] distances of a wave's chunk
+    o += 4 * 64 * 4;
+    uint32_t *w_lo = reinterpret_cast<uint32_t *>(smem + o);
+    o += 4 * 64 * 4;
+    float *tq = reinterpret_cast<float *>(smem + o); // the target's row as the query
+    __shared__ uint32_t sh[8];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t code = touched[blockIdx.x];
+    uint32_t t, maxm;
+    uint32_t *adj;
+    rl_target(v, code, n1, slot_owner, adj0, adj_up, t, maxm, adj);
+    if ((v.deleted[t >> 5] >> (t & 31u)) & 1u) return; // "node == nil || node.Deleted: skip" (:1927-1930)
+    const uint32_t nreq = cnt[code];
+    if (tid == 0) {
+        uint32_t ne = 0;
+        while (ne < maxm && adj[ne] != 0u) ne++;
+        sh[0] = ne;
+    }
+    __syncthreads();
+    const uint32_t ne = sh[0];
+    if (ne + nreq > ucap) { // a hub of this batch: its union is sorted in HBM scratch by the second kernel
+        if (tid == 0) big_list[atomicAdd(err + 1, 1u)] = code;
+        return;
+    }
+    rl_commit_body<METRIC, PREC>(v, p, adj, maxm, t, ne, req + off[code], nreq, u_key, u_id, u_tmp, w_d, w_lo, tq, sh);
+}
+
+// the targets rl_commit_kernel passed on: big_list[first + blockIdx.x], union in this workgroup's slice of `scratch`
+// (ucap entries: keys | ids | de-dup scratch)
+template <int METRIC, int PREC>
+__global__ void __launch_bounds__(256)
+rl_commit_big_kernel(KdbView v, uint32_t *adj0, uint32_t *adj_up, uint32_t n1, const uint32_t *big_list, uint32_t first, const uint32_t *cnt,
+                     const uint32_t *off, const uint32_t *req, const uint32_t *slot_owner, uint32_t ucap, unsigned char *scratch, uint32_t *err) {
+    using KT = typename BKey<PREC>::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PruneLdsT<KT> p;
+    prune_carve(smem, p);
+    size_t o = prune_lds_bytes<KT>();
+    float *w_d = reinterpret_cast<float *>(smem + o);
+    o += 4 * 64 * 4;
+    uint32_t *w_lo = reinterpret_cast<uint32_t *>(smem + o);
+    o += 4 * 64 * 4;
+    float *tq = reinterpret_cast<float *>(smem + o);
+    __shared__ uint32_t sh[8];
+    unsigned char *mine = scratch + (size_t)blockIdx.x * ucap * (sizeof(KT) + 8);
+    KT *u_key = reinterpret_cast<KT *>(mine);
+    uint32_t *u_id = reinterpret_cast<uint32_t *>(mine + (size_t)ucap * sizeof(KT));
+    uint32_t *u_tmp = u_id + ucap;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t code = big_list[first + blockIdx.x];
+    uint32_t t, maxm;
+    uint32_t *adj;
+    rl_target(v, code, n1, slot_owner, adj0, adj_up, t, maxm, adj);
+    const uint32_t nreq = cnt[code];
+    if (tid == 0) {
+        uint32_t ne = 0;
+        while (ne < maxm && adj[ne] != 0u) ne++;
+        sh[0] = ne;
+    }
+    __syncthreads();
+    const uint32_t ne = sh[0];
+    if (ne + nreq > ucap) { // (cannot happen: ucap covers maxM + every request a batch can send one target)
+        if (tid == 0) atomicAdd(err + 2, 1u);
+        return;
+    }
+    rl_commit_body<METRIC, PREC>(v, p, adj, maxm, t, ne, req + off[code], nreq, u_key, u_id, u_tmp, w_d, w_lo, tq, sh);
+}
+
 // ---- test hook: selectNeighbors on caller-supplied candidate lists (kdb_test_select_neighbors) -----------------------
 template <int METRIC, int PREC>
 __global__ void __launch_bounds__(256)
@@ -849,8 +1003,8 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     constexpr size_t KB = sizeof(KT);
     hipStream_t s = idx->stream;
     const uint32_t efc = bp && bp->ef_construction ? bp->ef_construction : idx->desc.ef_construction;
-    if (efc > 256 || efc < 1) {
-        kdb_set_error("build: ef_construction must be in 1..256 (got %u)", efc);
+    if (efc > KDB_MAX_EFC || efc < 1) {
+        kdb_set_error("build: ef_construction must be in 1..%u (got %u)", KDB_MAX_EFC, efc);
         return KDB_ERR_UNSUPPORTED;
     }
     const uint32_t max_batch = bp && bp->batch ? bp->batch : 16384u;
@@ -900,6 +1054,9 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     const size_t o_touch = take(((size_t)max_tasks * PR_MAXSEL + 64) * 4), o_ntouch = take(256);
     const size_t o_cid = take(max_tasks * efc * 4), o_ckey = take(max_tasks * efc * KB), o_ccnt = take(max_tasks * 4);
     const size_t o_uptask = take((size_t)max_batch * 4 + 64);
+    // parked reverse requests of hubs: every selected neighbour of a batch could be one (max_tasks * maxM0); in practice a few hundred
+    const size_t ov_cap = max_tasks * (size_t)idx->deg0;
+    const size_t o_ovc = take(ov_cap * 4), o_ovi = take(ov_cap * 4), o_ovk = take(ov_cap * KB), o_ovn = take(256);
     if (idx->build_bytes < off) {
         if (idx->d_build) KDB_HIP(hipFree(idx->d_build));
         idx->d_build = nullptr;
@@ -927,14 +1084,23 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     bv.cand_key = reinterpret_cast<KT *>(w + o_ckey);
     bv.cand_cnt = reinterpret_cast<uint32_t *>(w + o_ccnt);
     bv.up_task = reinterpret_cast<uint32_t *>(w + o_uptask);
+    bv.ov_code = reinterpret_cast<uint32_t *>(w + o_ovc);
+    bv.ov_id = reinterpret_cast<uint32_t *>(w + o_ovi);
+    bv.ov_key = reinterpret_cast<KT *>(w + o_ovk);
+    bv.ov_cnt = reinterpret_cast<uint32_t *>(w + o_ovn);
+    bv.ov_cap = (uint32_t)ov_cap;
     bv.efc = efc;
 
     // ---- launch geometry
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
-    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4;
+    const int bs = kdb_beam_slots(efc) == 0 ? 0 : kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
+    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
+                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0);
     const size_t lds_prune = prune_lds_bytes<KT>();
-    const int bs = kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
-    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
+    auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
+                   : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
+                   : bs == 4 ? build_search_kernel<METRIC, 4, PREC>
+                             : build_search_kernel<METRIC, 6, PREC>;
     auto kselect = build_select_kernel<METRIC, PREC>;
     auto krev = build_reverse_kernel<METRIC, PREC>;
     if (lds_prune > 64 * 1024) {
@@ -982,6 +1148,7 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
         KDB_HIP(hipMemcpyAsync(bv.up_task, up_task.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
         KDB_HIP(hipMemsetAsync(bv.cand_cnt, 0, (size_t)n_tasks * 4, s));
         KDB_HIP(hipMemsetAsync(bv.n_touched, 0, 4, s));
+        KDB_HIP(hipMemsetAsync(bv.ov_cnt, 0, 4, s));
         KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
         KdbView v = kdb_make_view(idx);
         v.count = next + nb - 1;
@@ -1011,7 +1178,8 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     return KDB_OK;
 }
 
-// addBatchInternal for rows already in place (phases 1-4), reference linking.  idx->count etc. are updated on success.
+// addBatchInternal for rows already in place (phases 1-4), reference linking.  Everything that can fail for want of memory is
+// done BEFORE the index is touched; a failure behind that point (a HIP error) rolls the handle back to the state it had.
 template <int METRIC, int PREC>
 int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_t *lv_in, uint32_t efc) {
     using KT = typename BKey<PREC>::T;
@@ -1019,46 +1187,30 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     hipStream_t s = idx->stream;
     const uint32_t new_count = first + nb - 1u;
     const int frozen_max = idx->max_level;
+    const bool reuse = first == idx->count; // the batch's first node takes over the last node's slot (:1620 vs :590)
     // ---- phase 1B bookkeeping: levels (randomLevel's own cap, :2620-2623, against the maxLevel the batch started with) and
-    //      upper slots of the new nodes; a node that takes over a slot (first == count, :1620) gets fresh ones
+    //      upper slots of the new nodes.  A node that takes over a slot gets fresh ones -- as many as the HIGHER of its own level
+    //      and the replaced node's: old links still name it at those levels, and the reference grows it when asked (:2049-2053)
     std::vector<uint8_t> lv(nb);
     std::vector<uint32_t> up_new(nb), up_task(nb);
     size_t slots = idx->up_slots;
-    uint32_t nup = 0;
+    uint32_t nup = 0, reuse_levels = 0;
     for (uint32_t i = 0; i < nb; i++) {
         int l = lv_in[i];
         if (l > frozen_max + 1) l = frozen_max + 1;
         lv[i] = (uint8_t)l;
         up_new[i] = (uint32_t)slots;
-        slots += (size_t)l;
+        uint32_t own = (uint32_t)l;
+        if (i == 0 && reuse) {
+            const uint32_t old_l = idx->h_levels[first];
+            reuse_levels = own > old_l ? own : old_l;
+            own = reuse_levels;
+        }
+        slots += (size_t)own;
         up_task[i] = nup;
         nup += (uint32_t)(l < frozen_max ? l : frozen_max); // links only up to the current top (:1829)
     }
-    if (slots > idx->up_slots_cap || !idx->d_adj_up) { // grow the upper pool, keep what it holds
-        const size_t ncap = slots + slots / 2 + 1024;
-        uint32_t *nbuf = nullptr;
-        KDB_HIP(hipMalloc(&nbuf, (ncap * idx->deg_up + 4) * 4));
-        KDB_HIP(hipMemsetAsync(nbuf, 0, (ncap * idx->deg_up + 4) * 4, s));
-        if (idx->d_adj_up && idx->up_slots) KDB_HIP(hipMemcpyAsync(nbuf, idx->d_adj_up, idx->up_slots * idx->deg_up * 4, hipMemcpyDeviceToDevice, s));
-        KDB_HIP(hipStreamSynchronize(s));
-        if (idx->d_adj_up) KDB_HIP(hipFree(idx->d_adj_up));
-        idx->d_adj_up = nbuf;
-        idx->up_slots_cap = ncap;
-    } else if (slots > idx->up_slots) {
-        KDB_HIP(hipMemsetAsync(idx->d_adj_up + idx->up_slots * idx->deg_up, 0, (slots - idx->up_slots) * idx->deg_up * 4, s));
-    }
-    KDB_HIP(hipMemsetAsync(idx->d_adj0 + (size_t)first * idx->deg0, 0, (size_t)nb * idx->deg0 * 4, s)); // empty Connections (:1742)
-    KDB_HIP(hipMemcpyAsync(idx->d_levels + first, lv.data(), nb, hipMemcpyHostToDevice, s));
-    KDB_HIP(hipMemcpyAsync(idx->d_up_idx + first, up_new.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
-    idx->h_levels.resize((size_t)new_count + 1);
-    idx->h_up_idx.resize((size_t)new_count + 1);
-    for (uint32_t i = 0; i < nb; i++) {
-        idx->h_levels[first + i] = lv[i];
-        idx->h_up_idx[first + i] = up_new[i];
-    }
-    idx->up_slots = slots;
-    idx->count = new_count;
-    // ---- workspace
+    // ---- workspace, kernels, visited pool: every allocation and attribute call of the call, up front
     const size_t n1 = (size_t)idx->cap + 1;
     const size_t L = n1 + slots + 1;
     const uint32_t n_tasks = nb + nup;
@@ -1067,9 +1219,22 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     const size_t o_ckey = take((size_t)n_tasks * efc * KB), o_cid = take((size_t)n_tasks * efc * 4), o_ccnt = take((size_t)n_tasks * 4);
     const size_t o_uptask = take((size_t)nb * 4 + 64), o_cnt = take(L * 4), o_off = take(L * 4), o_cur = take(L * 4);
-    const size_t o_owner = take((slots + 1) * 4), o_touch = take(L * 4), o_out = take(256);
+    const size_t o_owner = take((slots + 1) * 4), o_touch = take(L * 4), o_out = take(256), o_big = take(L * 4);
     const size_t req_max = (size_t)n_tasks * efc * 2;
     const size_t o_req = take(req_max * 4 + 64);
+    // unions too long for LDS (a target named by thousands of the batch's nodes) are sorted in HBM scratch, BIG_WG at a time: a
+    // union holds at most maxM0 links + the node's own efc candidates + one reverse request per task
+    static const uint32_t ucap_lds = [] {
+        const char *e = getenv("KDB_RL_UCAP"); // (tests lower it to push ordinary targets through the HBM path)
+        uint32_t u = e ? (uint32_t)atoi(e) : RL_UCAP;
+        uint32_t p2 = 64;
+        while (p2 < u && p2 < RL_UCAP) p2 <<= 1;
+        return p2;
+    }();
+    uint32_t ucap_big = 64;
+    while (ucap_big < idx->deg0 + efc + n_tasks) ucap_big <<= 1;
+    constexpr uint32_t BIG_WG = 64;
+    const size_t o_bigs = take((size_t)BIG_WG * ucap_big * (KB + 8));
     if (idx->build_bytes < off) {
         if (idx->d_build) KDB_HIP(hipFree(idx->d_build));
         idx->d_build = nullptr;
@@ -1077,6 +1242,95 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
         KDB_HIP(hipMalloc(&idx->d_build, off));
         idx->build_bytes = off;
     }
+    const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
+    const int bs = kdb_beam_slots(efc) == 0 ? 0 : kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
+    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
+                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0);
+    auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
+                   : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
+                   : bs == 4 ? build_search_kernel<METRIC, 4, PREC>
+                             : build_search_kernel<METRIC, 6, PREC>;
+    if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
+    const size_t lds_commit = prune_lds_bytes<KT>() + (size_t)ucap_lds * (KB + 8) + 2048 + (size_t)idx->ld * 4 + 64;
+    const size_t lds_big = prune_lds_bytes<KT>() + 2048 + (size_t)idx->ld * 4 + 64;
+    auto kc = rl_commit_kernel<METRIC, PREC>;
+    auto kbig = rl_commit_big_kernel<METRIC, PREC>;
+    KDB_HIP(hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_commit));
+    KDB_HIP(hipFuncSetAttribute((const void *)kbig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    const uint32_t slots_vis = (uint32_t)idx->n_cu * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
+    int rc = kdb_ensure_visited(idx, slots_vis, s);
+    if (rc) return rc;
+    uint32_t *grown_pool = nullptr;
+    size_t grown_cap = 0;
+    if (slots > idx->up_slots_cap || !idx->d_adj_up) { // a larger upper pool, filled with what the old one holds
+        grown_cap = slots + slots / 2 + 1024;
+        KDB_HIP(hipMalloc(&grown_pool, (grown_cap * idx->deg_up + 4) * 4));
+    }
+    // ---- from here on the index changes; `undo` puts back what the host side knows (the device lists of a batch that failed
+    //      half way may hold some of its links: the nodes behind `count` are simply not part of the graph)
+    const uint32_t old_count = idx->count, old_entry = idx->entry;
+    const int old_max = idx->max_level;
+    const size_t old_slots = idx->up_slots;
+    const uint8_t old_reuse_level = reuse ? idx->h_levels[first] : 0;
+    const uint32_t old_reuse_up = reuse ? idx->h_up_idx[first] : 0;
+    auto undo = [&]() {
+        (void)hipStreamSynchronize(s);
+        idx->count = old_count;
+        idx->entry = old_entry;
+        idx->max_level = old_max;
+        idx->up_slots = old_slots;
+        idx->h_levels.resize((size_t)old_count + 1);
+        idx->h_up_idx.resize((size_t)old_count + 1);
+        if (reuse) {
+            idx->h_levels[first] = old_reuse_level;
+            idx->h_up_idx[first] = old_reuse_up;
+            (void)hipMemcpy(idx->d_levels + first, &old_reuse_level, 1, hipMemcpyHostToDevice);
+            (void)hipMemcpy(idx->d_up_idx + first, &old_reuse_up, 4, hipMemcpyHostToDevice);
+        }
+        idx->graph_epoch++;
+    };
+#define KDB_TRY(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            kdb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            undo();                                                                                     \
+            return _e == hipErrorOutOfMemory ? KDB_ERR_OOM : KDB_ERR_HIP;                               \
+        }                                                                                               \
+    } while (0)
+    if (grown_pool) {
+        KDB_TRY(hipMemsetAsync(grown_pool, 0, (grown_cap * idx->deg_up + 4) * 4, s));
+        if (idx->d_adj_up && idx->up_slots) KDB_TRY(hipMemcpyAsync(grown_pool, idx->d_adj_up, idx->up_slots * idx->deg_up * 4, hipMemcpyDeviceToDevice, s));
+        KDB_TRY(hipStreamSynchronize(s));
+        if (idx->d_adj_up) (void)hipFree(idx->d_adj_up);
+        idx->d_adj_up = grown_pool;
+        idx->up_slots_cap = grown_cap;
+    } else if (slots > idx->up_slots) {
+        KDB_TRY(hipMemsetAsync(idx->d_adj_up + idx->up_slots * idx->deg_up, 0, (slots - idx->up_slots) * idx->deg_up * 4, s));
+    }
+    KDB_TRY(hipMemsetAsync(idx->d_adj0 + (size_t)first * idx->deg0, 0, (size_t)nb * idx->deg0 * 4, s)); // empty Connections (:1742)
+    KDB_TRY(hipMemcpyAsync(idx->d_levels + first, lv.data(), nb, hipMemcpyHostToDevice, s));
+    KDB_TRY(hipMemcpyAsync(idx->d_up_idx + first, up_new.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    if (reuse && idx->n_deleted) { // a node the batch replaces is a NEW node: Deleted starts false (:1742)
+        uint32_t w = 0;
+        KDB_TRY(hipMemcpyAsync(&w, idx->d_deleted + (first >> 5), 4, hipMemcpyDeviceToHost, s));
+        KDB_TRY(hipStreamSynchronize(s));
+        if ((w >> (first & 31u)) & 1u) {
+            w &= ~(1u << (first & 31u));
+            KDB_TRY(hipMemcpyAsync(idx->d_deleted + (first >> 5), &w, 4, hipMemcpyHostToDevice, s));
+            KDB_TRY(hipStreamSynchronize(s));
+            idx->n_deleted--;
+        }
+    }
+    idx->h_levels.resize((size_t)new_count + 1);
+    idx->h_up_idx.resize((size_t)new_count + 1);
+    for (uint32_t i = 0; i < nb; i++) {
+        idx->h_levels[first + i] = lv[i];
+        idx->h_up_idx[first + i] = up_new[i];
+    }
+    idx->up_slots = slots;
+    idx->count = new_count;
+    idx->graph_epoch++;
     unsigned char *w = reinterpret_cast<unsigned char *>(idx->d_build);
     BuildViewT<KT> bv{};
     bv.adj0 = idx->d_adj0;
@@ -1092,62 +1346,64 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     uint32_t *d_cnt = reinterpret_cast<uint32_t *>(w + o_cnt), *d_off = reinterpret_cast<uint32_t *>(w + o_off);
     uint32_t *d_cur = reinterpret_cast<uint32_t *>(w + o_cur), *d_owner = reinterpret_cast<uint32_t *>(w + o_owner);
     uint32_t *d_touch = reinterpret_cast<uint32_t *>(w + o_touch), *d_out = reinterpret_cast<uint32_t *>(w + o_out);
-    uint32_t *d_req = reinterpret_cast<uint32_t *>(w + o_req);
-    KDB_HIP(hipMemcpyAsync(bv.up_task, up_task.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
-    KDB_HIP(hipMemsetAsync(bv.cand_cnt, 0, (size_t)n_tasks * 4, s));
-    KDB_HIP(hipMemsetAsync(d_cnt, 0, L * 4, s));
-    KDB_HIP(hipMemsetAsync(d_cur, 0, L * 4, s));
-    KDB_HIP(hipMemsetAsync(d_out, 0, 256, s));
-    KDB_HIP(hipMemsetAsync(idx->d_work, 0, 4, s));
+    uint32_t *d_req = reinterpret_cast<uint32_t *>(w + o_req), *d_big = reinterpret_cast<uint32_t *>(w + o_big);
+    KDB_TRY(hipMemcpyAsync(bv.up_task, up_task.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    KDB_TRY(hipMemsetAsync(bv.cand_cnt, 0, (size_t)n_tasks * 4, s));
+    KDB_TRY(hipMemsetAsync(d_cnt, 0, L * 4, s));
+    KDB_TRY(hipMemsetAsync(d_cur, 0, L * 4, s));
+    KDB_TRY(hipMemsetAsync(d_out, 0, 256, s)); // [0] requests, [1] touched targets, [2] requests above a node's level, [3] big unions, [4] -, [5] grown level
+    KDB_TRY(hipMemsetAsync(idx->d_work, 0, 4, s));
     // ---- phase 1: every new node searches the graph as it was (entry point / maxLevel frozen, :1796-1801)
-    const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
-    const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4;
-    const int bs = kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
-    auto ksearch = bs == 2 ? build_search_kernel<METRIC, 2, PREC> : bs == 4 ? build_search_kernel<METRIC, 4, PREC> : build_search_kernel<METRIC, 6, PREC>;
-    if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
-    const uint32_t slots_vis = (uint32_t)idx->n_cu * (uint32_t)occupancy_blocks(ksearch, 64, lds_search);
-    int rc = kdb_ensure_visited(idx, slots_vis, s);
-    if (rc) return rc;
     KdbView v = kdb_make_view(idx); // count = new_count: the new ids are valid wherever a walk meets them (the re-used slot)
     hipLaunchKernelGGL(ksearch, dim3(slots_vis < nb ? slots_vis : nb), dim3(64), lds_search, s, v, bv, beam_cap, idx->d_visited, idx->d_work);
-    KDB_HIP(hipGetLastError());
+    KDB_TRY(hipGetLastError());
     // ---- phases 2 + 3
+    const uint32_t reuse_id = reuse ? first : 0u;
     hipLaunchKernelGGL((rl_count_kernel<KT>), dim3(n_tasks), dim3(256), 0, s, v, bv, (uint32_t)n1, d_cnt, d_owner, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       (uint32_t *)nullptr, d_out + 2);
+                       (uint32_t *)nullptr, d_out + 2, reuse_id, reuse_levels, d_out + 5);
     hipLaunchKernelGGL(rl_scan_kernel, dim3(1), dim3(1024), 0, s, d_cnt, (uint32_t)L, d_off, d_touch, d_out);
-    hipLaunchKernelGGL((rl_count_kernel<KT>), dim3(n_tasks), dim3(256), 0, s, v, bv, (uint32_t)n1, d_cnt, d_owner, d_cur, d_off, d_req, d_out + 2);
-    KDB_HIP(hipGetLastError());
-    uint32_t out[4] = {0, 0, 0, 0};
-    KDB_HIP(hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipStreamSynchronize(s));
-    if (out[0] > req_max) {
+    hipLaunchKernelGGL((rl_count_kernel<KT>), dim3(n_tasks), dim3(256), 0, s, v, bv, (uint32_t)n1, d_cnt, d_owner, d_cur, d_off, d_req, d_out + 2, reuse_id,
+                       reuse_levels, d_out + 5);
+    KDB_TRY(hipGetLastError());
+    uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    KDB_TRY(hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, s));
+    KDB_TRY(hipStreamSynchronize(s));
+    if (out[0] > req_max) { // (cannot happen: two requests per (task, candidate) at most)
         kdb_set_error("add_batch: request overflow");
+        undo();
         return KDB_ERR_STATE;
     }
     if (out[1]) {
-        const size_t lds_commit = prune_lds_bytes<KT>() + (size_t)RL_UCAP * (KB + 8) + 2048 + (size_t)idx->ld * 4 + 64;
-        auto kc = rl_commit_kernel<METRIC, PREC>;
-        KDB_HIP(hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_commit));
         hipLaunchKernelGGL(kc, dim3(out[1]), dim3(256), lds_commit, s, v, idx->d_adj0, idx->d_adj_up, (uint32_t)n1, d_touch, d_cnt, d_off, d_req, d_owner,
-                           d_out + 2);
-        KDB_HIP(hipGetLastError());
+                           d_out + 2, ucap_lds, d_big);
+        KDB_TRY(hipGetLastError());
+        KDB_TRY(hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, s));
+        KDB_TRY(hipStreamSynchronize(s));
+        for (uint32_t b0 = 0; b0 < out[3]; b0 += BIG_WG) { // the unions LDS could not hold
+            const uint32_t g = out[3] - b0 < BIG_WG ? out[3] - b0 : BIG_WG;
+            hipLaunchKernelGGL(kbig, dim3(g), dim3(256), lds_big, s, v, idx->d_adj0, idx->d_adj_up, (uint32_t)n1, d_big, b0, d_cnt, d_off, d_req, d_owner, ucap_big,
+                               w + o_bigs, d_out + 2);
+            KDB_TRY(hipGetLastError());
+        }
     }
-    KDB_HIP(hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipStreamSynchronize(s));
+    KDB_TRY(hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, s));
+    KDB_TRY(hipStreamSynchronize(s));
+#undef KDB_TRY
+    // the re-used slot was asked for links above its new level: it has grown, as the reference's node does (:2049-2053)
+    if (reuse && out[5] > (uint32_t)lv[0]) {
+        const uint8_t g8 = (uint8_t)out[5];
+        idx->h_levels[first] = g8;
+        KDB_HIP(hipMemcpy(idx->d_levels + first, &g8, 1, hipMemcpyHostToDevice));
+    }
     // ---- phase 4: entry point / maxLevel (:2066-2080)
     for (uint32_t i = 0; i < nb; i++)
         if ((int)lv[i] > idx->max_level) {
             idx->max_level = (int)lv[i];
             idx->entry = first + i;
         }
-    if (out[3]) {
-        kdb_set_error("add_batch: a target's union of links and requests exceeded %u entries (%u targets skipped): use smaller batches", RL_UCAP, out[3]);
-        return KDB_ERR_UNSUPPORTED;
-    }
-    if (out[2]) {
-        kdb_set_error("add_batch: %u requests asked a node for a level above its own (the slot the reference's batch path re-uses, "
-                      "hnsw_index.go:1620, after its level changed): the reference grows that node, the fixed upper slots here cannot; skipped", out[2]);
-        return KDB_ERR_UNSUPPORTED;
+    if (out[2] || out[4]) { // (neither can happen: see rl_count_kernel / rl_commit_big_kernel)
+        kdb_set_error("add_batch: %u requests above a node's level, %u unions beyond the scratch: skipped", out[2], out[4]);
+        return KDB_ERR_STATE;
     }
     return KDB_OK;
 }
@@ -1219,8 +1475,8 @@ int kdb_add_batch_ref(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8
         kdb_set_error("add_batch: ids must start at count (%u, re-using the last slot) or count+1 and stay within capacity %u", idx->count, idx->cap);
         return KDB_ERR_INVALID;
     }
-    if (efc < 1 || efc > 256 || idx->deg0 > PR_MAXSEL || n + idx->deg0 > RL_UCAP) {
-        kdb_set_error("add_batch: ef_construction in 1..256, mMax0 <= %d, at most %u nodes per batch", PR_MAXSEL, RL_UCAP - idx->deg0);
+    if (efc < 1 || efc > KDB_MAX_EFC || idx->deg0 > PR_MAXSEL) {
+        kdb_set_error("add_batch: ef_construction in 1..%u, mMax0 <= %d", KDB_MAX_EFC, PR_MAXSEL);
         return KDB_ERR_UNSUPPORTED;
     }
     KDB_HIP(hipDeviceSynchronize()); // walks of callers' streams may still read the lists this call rewrites

@@ -109,6 +109,8 @@ static void lane_store(kdb_index *idx) { // the current lane's buffers may have 
     l.d_gentry = idx->d_gentry;
     l.gentry_cap = idx->gentry_cap;
     l.d_work = idx->d_work;
+    l.d_tie = idx->d_tie;
+    l.tie_bytes = idx->tie_bytes;
 }
 static void lane_load(kdb_index *idx, int li) {
     const kdb_lane &l = idx->lanes[li];
@@ -122,6 +124,8 @@ static void lane_load(kdb_index *idx, int li) {
     idx->d_gentry = l.d_gentry;
     idx->gentry_cap = l.gentry_cap;
     idx->d_work = l.d_work;
+    idx->d_tie = l.d_tie;
+    idx->tie_bytes = l.tie_bytes;
 }
 
 int kdb_lane_acquire(kdb_index *idx, hipStream_t s) {
@@ -177,6 +181,19 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
     idx->last_B = B;
     idx->last_C = C;
     return idx->d_ctr + (size_t)slot * 4; // [0] n_dist / rows scanned, [1] n_hops, [2] work counter of the launch
+}
+
+int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes) {
+    if (idx->tie_bytes >= bytes) return KDB_OK;
+    if (idx->d_tie) {
+        KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
+        KDB_HIP(hipFree(idx->d_tie));
+        idx->d_tie = nullptr;
+        idx->tie_bytes = 0;
+    }
+    KDB_HIP(hipMalloc(&idx->d_tie, bytes + bytes / 4));
+    idx->tie_bytes = bytes + bytes / 4;
+    return KDB_OK;
 }
 
 int kdb_ensure_group_entries(kdb_index *idx, uint32_t n) {
@@ -326,7 +343,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (kdb_lane &l : idx->lanes) {
-        void *lb[] = {l.d_visited, l.d_scratch, l.d_qbuf, l.d_gentry, l.d_work};
+        void *lb[] = {l.d_visited, l.d_scratch, l.d_qbuf, l.d_gentry, l.d_work, l.d_tie};
         for (void *b : lb)
             if (b) (void)hipFree(b);
         if (l.done) (void)hipEventDestroy(l.done);
@@ -445,6 +462,94 @@ extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
     std::lock_guard<std::mutex> lk(idx->mu);
     if (count != idx->count) idx->graph_epoch++; // the derived upper-slot table tests ids against count
     idx->count = count;
+    return KDB_OK;
+}
+
+// growNodes (hnsw_index.go:2732-2768): the reference doubles `nodes` and `quantizedNorms` when an id outgrows them.  Here every
+// per-id array of the mirror moves to a larger allocation ON THE DEVICE (rows, ranking copy, norms, level-0 lists, upper-slot
+// index, levels, deleted bits); the upper pool and the graph itself are untouched.  Per-wave visited bitsets are sized by the
+// capacity: they are dropped and re-made by the next search.  No-op when the capacity is already that large.
+extern "C" int kdb_index_reserve(kdb_index *idx, uint32_t new_capacity) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (new_capacity <= idx->cap) return KDB_OK;
+    if (new_capacity > KDB_ID_MASK - 1) {
+        kdb_set_error("reserve: capacity %u exceeds the 2^30-1 ids of an index", new_capacity);
+        return KDB_ERR_INVALID;
+    }
+    KDB_HIP(hipSetDevice(idx->device));
+    // walks of callers' streams may still read the arrays that are about to move
+    KDB_HIP(hipDeviceSynchronize());
+    const size_t o1 = (size_t)idx->cap + 1, n1 = (size_t)new_capacity + 1;
+    const size_t row_b = (size_t)idx->ld * idx->elem;
+    auto words = [](size_t n) { return ((n + 31) / 32 + 3) & ~(size_t)3; };
+    struct Arr {
+        void **p;
+        size_t old_bytes, new_bytes;
+    };
+    void *rows16 = idx->d_rows16;
+    Arr arrs[] = {{&idx->d_rows, o1 * row_b, n1 * row_b},
+                  {&rows16, idx->d_rows16 ? o1 * idx->ld * 2 : 0, idx->d_rows16 ? n1 * idx->ld * 2 : 0},
+                  {reinterpret_cast<void **>(&idx->d_norms), o1 * 4, n1 * 4},
+                  {reinterpret_cast<void **>(&idx->d_adj0), o1 * idx->deg0 * 4, n1 * idx->deg0 * 4},
+                  {reinterpret_cast<void **>(&idx->d_up_idx), o1 * 4, n1 * 4},
+                  {reinterpret_cast<void **>(&idx->d_levels), o1, n1},
+                  {reinterpret_cast<void **>(&idx->d_deleted), words(o1) * 4, words(n1) * 4}};
+    constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
+    void *fresh[NA] = {};
+    for (int i = 0; i < NA; i++) { // every allocation first: a failure leaves the index as it was
+        if (!arrs[i].new_bytes) continue;
+        if (hipMalloc(&fresh[i], arrs[i].new_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; j++)
+                if (fresh[j]) (void)hipFree(fresh[j]);
+            kdb_set_error("reserve: no room for capacity %u (%zu bytes for array %d)", new_capacity, arrs[i].new_bytes, i);
+            return KDB_ERR_OOM;
+        }
+    }
+    hipStream_t s = idx->stream;
+    for (int i = 0; i < NA; i++) {
+        if (!fresh[i]) continue;
+        KDB_HIP(hipMemcpyAsync(fresh[i], *arrs[i].p, arrs[i].old_bytes, hipMemcpyDeviceToDevice, s));
+        KDB_HIP(hipMemsetAsync(reinterpret_cast<unsigned char *>(fresh[i]) + arrs[i].old_bytes, 0, arrs[i].new_bytes - arrs[i].old_bytes, s));
+    }
+    KDB_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < NA; i++) {
+        if (!fresh[i]) continue;
+        (void)hipFree(*arrs[i].p);
+        *arrs[i].p = fresh[i];
+    }
+    idx->d_rows16 = reinterpret_cast<uint16_t *>(rows16);
+    // scratch whose size follows the capacity: visited bitsets of both lanes, the builders' workspace
+    lane_store(idx);
+    for (kdb_lane &l : idx->lanes) {
+        if (l.d_visited) (void)hipFree(l.d_visited);
+        l.d_visited = nullptr;
+        l.vis_slots = 0;
+    }
+    lane_load(idx, idx->cur_lane);
+    if (idx->d_build) (void)hipFree(idx->d_build);
+    idx->d_build = nullptr;
+    idx->build_bytes = 0;
+    idx->cap = new_capacity;
+    idx->desc.capacity = new_capacity;
+    return KDB_OK;
+}
+
+// The half-precision ranking copy of a float32 index (made by its first exact scan, +50 % row memory) can be given back: an
+// index that is mostly walked and scanned once in a while need not keep 19 GB per 12.5M x 768 shard.  The next exact scan makes
+// it again (or never, with refuse_for_good != 0 -- the effect of KDB_INDEX_NO_F16_SHADOW from then on).
+extern "C" int kdb_index_drop_f16_shadow(kdb_index *idx, int refuse_for_good) {
+    KDB_CHECK_IDX(idx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    if (idx->d_rows16) {
+        KDB_HIP(hipDeviceSynchronize()); // scans of callers' streams may still rank on it
+        (void)hipFree(idx->d_rows16);
+        idx->d_rows16 = nullptr;
+    }
+    idx->rows16_refused = false;
+    if (refuse_for_good) idx->desc.reserved |= KDB_INDEX_NO_F16_SHADOW;
     return KDB_OK;
 }
 
@@ -829,6 +934,8 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
         kdb_set_error("search: KDB_SEARCH_DIST_F64 applies to int8 indexes (the other precisions compute float32 distances)");
         return KDB_ERR_INVALID;
     }
+    if (flags & KDB_SEARCH_TIE_FLAG) raw |= 8u;    // bit 31 of out_count: the walk met equal distances
+    if (flags & KDB_SEARCH_HEAP_ORDER) raw |= 16u; // ... and such queries are re-walked in the reference's heap order
     uint32_t *tr_nd = nullptr, *tr_nh = nullptr;
     if (idx->trace_ndist && idx->trace_on_device) {
         tr_nd = idx->trace_ndist;
@@ -1467,6 +1574,7 @@ static int stats_of_slot(kdb_index *idx, uint32_t slot, kdb_counters *out) {
         r.n_dist = c[0];
         r.n_hops = c[1];
         r.n_dropped = c[3];
+        r.n_tied = c[2];
         r.bytes = c[0] * row_bytes + c[1] * (uint64_t)idx->deg0 * 4 + c[0] * 4;
     } else if (kind == 2) { // N_scanned*dim*elem + B*dim*elem + B*k*8 (k*8 added by the caller)
         r.n_dist = c[0] * (uint64_t)idx->ring_B[slot]; // rows scanned (after filter / deletes) x queries

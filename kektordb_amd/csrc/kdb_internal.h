@@ -62,6 +62,8 @@ struct kdb_lane {
     uint32_t *d_gentry = nullptr;
     uint32_t gentry_cap = 0;
     uint32_t *d_work = nullptr;
+    void *d_tie = nullptr;      // heap-order second pass: [count, cursor, tied query indices ...] | candidate-heap tails
+    size_t tie_bytes = 0;
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
     bool used = false;
@@ -113,6 +115,8 @@ struct kdb_index {
     size_t h_pin_bytes = 0;
     uint32_t *d_gentry = nullptr;    // entry point per allow list of a search batch (hnsw_index.go:437-447), chosen on the device
     uint32_t gentry_cap = 0;
+    void *d_tie = nullptr;           // (current lane's) scratch of the heap-order second pass (search_heap.hip)
+    size_t tie_bytes = 0;
     void *d_build = nullptr;        // graph-construction workspace
     size_t build_bytes = 0;
     int last_kind = 0;              // 1 search, 2 flat scan, 3 distance tile
@@ -183,6 +187,14 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
                       uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s);
+// search_heap.hip: the heap-order walk of the queries the search kernel queued in d_tie_list (KDB_SEARCH_HEAP_ORDER)
+size_t kdb_heap_walk_scratch_bytes(uint32_t grid, uint32_t nl_c, uint32_t cap_c);
+uint32_t kdb_heap_walk_lds_entries(const KdbView &v, uint32_t ef, uint32_t k);
+int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B, uint32_t k, uint32_t ef,
+                         const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_tie_list, unsigned char *d_tails, uint32_t grid,
+                         uint32_t nl_c, uint32_t cap_c, unsigned long long *d_ctr, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                         uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s);
+int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes);
 int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                         const uint32_t *d_ids, uint32_t C, float *d_out, hipStream_t s);
 int kdb_launch_adj_scatter(uint32_t *d_dst, uint32_t deg, uint32_t n, const uint32_t *d_slots, const uint32_t *d_src, hipStream_t s);

@@ -307,6 +307,63 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     wave_lds_fence();
 }
 
+// The query of a walk -> LDS, prepared as searchInternal prepares it (hnsw_index.go:404-434); returns the int8 query norm (else 1).
+// int8: the quantised copy + norm made by prep_queries_kernel.  raw & 1: the caller's own [B][dim] f32 buffer -- raw & 2:
+// cosine => normalise (:3030-3045): sequential f32 sum of squares in index order, f64 sqrt, f32 multiply; a zero vector
+// stays untouched (every lane runs the same sequential sum on broadcast LDS reads: no divergence); float16 indexes: the RNE
+// round trip of float16.Fromfloat32 (:425).  Else: a prepared f32 row of `ld` floats.  Shared by the fast walk and the
+// heap-order walk: one preparation, one bit pattern.
+template <int PREC>
+__device__ __forceinline__ float kdb_load_query(const KdbView &v, const WaveLds &s, const void *__restrict__ queries,
+                                                const float *__restrict__ qnorms, uint32_t raw, uint32_t qi) {
+    const int lane = kdb_lane();
+    float qnorm = 1.f;
+    if (PREC == KDB_PREC_I8) {
+        const uint32_t nw = (uint32_t)((((size_t)v.ld + 15) / 16 * 16) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(queries) + (size_t)qi * nw;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
+        for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
+        qnorm = qnorms[qi];
+    } else if (raw & 1u) {
+        const float *src = reinterpret_cast<const float *>(queries) + (size_t)qi * v.dim;
+        for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = i < v.dim ? src[i] : 0.f;
+        wave_lds_fence();
+        if (raw & 2u) {
+            float nsq = 0.f;
+            const uint32_t d4 = v.dim & ~3u;
+            for (uint32_t i = 0; i < d4; i += 4) {
+                const float4 y = *reinterpret_cast<const float4 *>(s.q + i);
+                float sq = y.x * y.x;
+                nsq = nsq + sq;
+                sq = y.y * y.y;
+                nsq = nsq + sq;
+                sq = y.z * y.z;
+                nsq = nsq + sq;
+                sq = y.w * y.w;
+                nsq = nsq + sq;
+            }
+            for (uint32_t i = d4; i < v.dim; i++) {
+                const float y = s.q[i];
+                const float sq = y * y;
+                nsq = nsq + sq;
+            }
+            if (nsq > 0.f) {
+                const float inv = 1.0f / (float)sqrt((double)nsq);
+                for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = s.q[i] * inv;
+            }
+        }
+        if (PREC == KDB_PREC_F16) // RNE round trip, as float16.Fromfloat32 (hnsw_index.go:425)
+            for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = (float)(_Float16)s.q[i];
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) + (size_t)qi * v.ld);
+        float4 *dst = reinterpret_cast<float4 *>(s.q);
+        for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
+    }
+    __threadfence_block();
+    wave_lds_fence();
+    return qnorm;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Latency mode: WIDE waves share one query (round 3: an asynchronous pipeline, no workgroup barriers).
 //   wave 0    walks: pops, decides, inserts -- the reference's walk, step for step (search_layer_wide);
@@ -512,8 +569,25 @@ struct RegBeam {
     uint32_t count, n_res, scan_from;
     float worst;
     uint32_t worst_lo;
+    // The query's walk met two DIFFERENT nodes at EQUAL distance while both were in play (wave-uniform, set by insert and by
+    // the callers' side-list checks, cleared per query).  The reference then pops / evicts / reports them in the order its
+    // two container/heap arrays happen to hold them (hnsw_heap.go:53-82,122-151); this beam orders them by id.  A walk that
+    // never sets the flag is the reference's walk whatever the heap order; one that does is re-walked in heap order by
+    // heap_walk_kernel when the caller asks for it (KDB_SEARCH_HEAP_ORDER), or just reported (KDB_SEARCH_TIE_FLAG).
+    uint32_t tied;
 
     __device__ __forceinline__ void bind(const WaveLds &) {}
+    // some entry of the beam has this key (side-list pushes ask; `insert` checks for itself)
+    __device__ __forceinline__ bool has_key(float dd, uint32_t dlo) const {
+        const uint32_t lane = (uint32_t)kdb_lane();
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (64u * s >= count) continue;
+            m |= __ballot(64u * s + lane < count && key_eq<WK>(d[s], WK ? lo[WK ? s : 0] : 0u, dd, dlo));
+        }
+        return m != 0ull;
+    }
     __device__ __forceinline__ void reset(uint32_t) {
         count = n_res = scan_from = 0;
         worst = INFINITY;
@@ -577,6 +651,7 @@ struct RegBeam {
         const uint32_t lane = (uint32_t)kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
         uint32_t pos = 0;
+        unsigned long long eqm = 0ull;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if (64u * s >= count) continue;
@@ -584,9 +659,12 @@ struct RegBeam {
             const float e = d[s];
             const uint32_t elo = WK ? lo[WK ? s : 0] : 0u;
             const uint32_t eid = id[s] & KDB_ID_MASK;
-            const bool less = i < count && (key_lt<WK>(e, elo, dd, dlo) || (key_eq<WK>(e, elo, dd, dlo) && eid < idm));
+            const bool same = i < count && key_eq<WK>(e, elo, dd, dlo);
+            const bool less = i < count && (key_lt<WK>(e, elo, dd, dlo) || (same && eid < idm));
             pos += (uint32_t)__builtin_popcountll(__ballot(less));
+            eqm |= __ballot(same);
         }
+        if (eqm) tied = 1u; // an entry at the newcomer's distance: heap history, not the id, orders them in the reference
 #pragma unroll
         for (int s = S - 1; s >= 0; s--) {
             if (64u * (s + 1) <= pos || 64u * s > count) continue; // untouched slots
@@ -692,7 +770,16 @@ struct LdsBeamT {
     uint32_t count, n_res, scan_from;
     float worst;
     uint32_t worst_lo;
+    uint32_t tied; // see RegBeam::tied
 
+    __device__ __forceinline__ bool has_key(float dd, uint32_t dlo) const {
+        unsigned long long m = 0ull;
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            m |= __ballot(i < count && key_eq<WK>(bd[i], WK ? bl[i] : 0u, dd, dlo));
+        }
+        return m != 0ull;
+    }
     __device__ __forceinline__ void bind(const WaveLds &s) {
         bd = s.beam_d;
         bl = s.beam_lo;
@@ -728,17 +815,21 @@ struct LdsBeamT {
         const int lane = kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
         uint32_t pos = 0;
+        unsigned long long eqm = 0ull;
         for (uint32_t base = 0; base < count; base += 64) {
             const uint32_t i = base + (uint32_t)lane;
-            bool less = false;
+            bool less = false, same = false;
             if (i < count) {
                 const float e = bd[i];
                 const uint32_t elo = WK ? bl[i] : 0u;
                 const uint32_t eid = bi[i] & KDB_ID_MASK;
-                less = key_lt<WK>(e, elo, dd, dlo) || (key_eq<WK>(e, elo, dd, dlo) && eid < idm);
+                same = key_eq<WK>(e, elo, dd, dlo);
+                less = key_lt<WK>(e, elo, dd, dlo) || (same && eid < idm);
             }
             pos += (uint32_t)__builtin_popcountll(__ballot(less));
+            eqm |= __ballot(same);
         }
+        if (eqm) tied = 1u;
         for (int hi = (int)count - 1; hi >= (int)pos; hi -= 64) {
             const int i = hi - lane;
             const bool act = i >= (int)pos;
@@ -992,6 +1083,14 @@ struct NrListT {
         idv = uni(id[pos]);
         return pos;
     }
+    __device__ __forceinline__ bool has_key(float dd, uint32_t dlo) const { // a pending entry at this distance
+        unsigned long long m = 0ull;
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            m |= __ballot(i < count && key_eq<WK>(d[i], WK ? l[i] : 0u, dd, dlo));
+        }
+        return m != 0ull;
+    }
     __device__ __forceinline__ void remove(uint32_t pos) { // order does not matter: the last entry fills the hole
         if (kdb_lane() == 0) {
             d[pos] = d[count - 1];
@@ -1226,7 +1325,9 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
         const uint32_t dlo = WK ? readlane_u(my_lo, j) : 0u;
         if (!(b.n_res < ef || key_lt<WK>(d, dlo, b.worst, b.worst_lo))) continue;
         const uint32_t id = readlane_u(my_id, j);
+        if (nr.count && nr.has_key(d, dlo)) b.tied = 1u; // (only indexes with deleted nodes keep a side list)
         if (readlane_u((uint32_t)my_nr, j) != 0) { // deleted: a candidate, never a result
+            if (b.has_key(d, dlo)) b.tied = 1u;
             nr.push(d, dlo, id, b.worst, b.worst_lo, b.n_res >= ef);
         } else {
             // heap_push(results) + heap_pop(results) when over ef (:2586-2589): the newcomer is nearer than the
@@ -1276,6 +1377,16 @@ __device__ __forceinline__ bool pop_candidate(BeamT &b, NrT &nr, uint32_t ef, ui
         b.scan_from = (uint32_t)idx + 1;
     }
     return true;
+}
+
+// f32 cosine: the reference orders 1.0 - float64(dot) (distance_go.go:127), this walk orders -dot.  The two orders agree
+// except where the double rounds two DIFFERENT floats to one distance, which takes |dot| < 2^-29 on both sides; a candidate
+// that close to orthogonal simply marks the walk as tied (the heap-order walk compares the doubles).
+template <int PREC, int METRIC, class BeamT>
+__device__ __forceinline__ void kdb_tiny_dot_rule(BeamT &b, unsigned long long pass, float my_d) {
+    if constexpr (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) {
+        if (__ballot(((pass >> kdb_lane()) & 1ull) && fabsf(my_d) < 1.8e-9f)) b.tied = 1u;
+    }
 }
 
 // searchLayerUnlocked (hnsw_index.go:2351-2611) on one layer, ONE wave; leaves the result in the beam.
@@ -1350,6 +1461,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         const unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
+        kdb_tiny_dot_rule<PREC, METRIC>(b, pass, my_d);
         KDB_T(const unsigned long long tq2 = __builtin_readcyclecounter(); if (level == 0) ctr.t_dist += tq2 - tq1;)
         insert_candidates(v, s, b, nr, ef, pass, my_d, my_lo, my_id, my_nr, ctr);
         KDB_T(if (level == 0) ctr.t_ins += __builtin_readcyclecounter() - tq2;)
@@ -1418,6 +1530,7 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         const unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
+        kdb_tiny_dot_rule<PREC, METRIC>(b, pass, my_d);
         if constexpr (!WK) {
             if (!v.has_deleted && nr.count == 0u) {
                 // The next pop, known before the insertion: the first un-expanded entry of the beam as it is, or the nearest
@@ -1461,6 +1574,14 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
 __host__ __device__ inline uint32_t kdb_vis_hash_size(uint32_t ef) {
     if (ef <= 100) return 2048; // the set holds the ~9*ef ids a query evaluates
     if (ef <= 260) return 4096;
+    return 0;
+}
+
+// ... and for walks whose batch leaves LDS free (one round of waves at this footprint): ef 261 .. 1040
+__host__ __device__ inline uint32_t kdb_vis_hash_size_large(uint32_t ef) {
+    if (ef <= 260) return 0;
+    if (ef <= 520) return 8192;   // 32 KB: four waves per CU
+    if (ef <= 1040) return 16384; // 64 KB: two waves per CU
     return 0;
 }
 

@@ -64,7 +64,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
                    unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
-                   uint32_t *tr_ndist, uint32_t *tr_nhops) {
+                   uint32_t *tr_ndist, uint32_t *tr_nhops, uint32_t *tie_list /* [0] count, [1] cursor of the second pass, [2..] queries */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds s;
     size_t off = 0;
@@ -126,7 +126,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         }
     }
     WideCtx wc;
-    unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0;
+    unsigned long long tot_dist = 0, tot_hops = 0, tot_dropped = 0, tot_tied = 0;
     typename BeamSel<BS, PREC == KDB_PREC_I8>::type b;
     b.bind(s);
     for (;;) {
@@ -136,58 +136,11 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         if (qi >= B) break;
 
         vis.begin_query();
-        // query -> LDS
-        float qnorm = 1.f;
-        if (PREC == KDB_PREC_I8) {
-            const uint32_t nw = (uint32_t)(q_lds_bytes<PREC>(v.ld) / 4);
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(queries) + (size_t)qi * nw;
-            uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
-            for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
-            qnorm = qnorms[qi];
-        } else if (raw) {
-            // the caller's own [B][dim] f32 buffer: query preparation (hnsw_index.go:404-434) happens here, no
-            // separate pass over the batch.  raw & 2: cosine => normalise (:3030-3045): sequential f32 sum of
-            // squares in index order, f64 sqrt, f32 multiply; a zero vector stays untouched.  Every lane runs the
-            // same sequential sum on broadcast LDS reads (no divergence, every lane ends with the sum).
-            const float *src = reinterpret_cast<const float *>(queries) + (size_t)qi * v.dim;
-            for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = i < v.dim ? src[i] : 0.f;
-            wave_lds_fence();
-            if (raw & 2u) {
-                float nsq = 0.f;
-                const uint32_t d4 = v.dim & ~3u;
-                for (uint32_t i = 0; i < d4; i += 4) {
-                    const float4 y = *reinterpret_cast<const float4 *>(s.q + i);
-                    float sq = y.x * y.x;
-                    nsq = nsq + sq;
-                    sq = y.y * y.y;
-                    nsq = nsq + sq;
-                    sq = y.z * y.z;
-                    nsq = nsq + sq;
-                    sq = y.w * y.w;
-                    nsq = nsq + sq;
-                }
-                for (uint32_t i = d4; i < v.dim; i++) {
-                    const float y = s.q[i];
-                    const float sq = y * y;
-                    nsq = nsq + sq;
-                }
-                if (nsq > 0.f) {
-                    const float inv = 1.0f / (float)sqrt((double)nsq);
-                    for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = s.q[i] * inv;
-                }
-            }
-            if (PREC == KDB_PREC_F16) // RNE round trip, as float16.Fromfloat32 (hnsw_index.go:425)
-                for (uint32_t i = (uint32_t)lane; i < v.dim; i += 64) s.q[i] = (float)(_Float16)s.q[i];
-        } else {
-            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) +
-                                                                 (size_t)qi * v.ld);
-            float4 *dst = reinterpret_cast<float4 *>(s.q);
-            for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
-        }
-        __threadfence_block();
-        wave_lds_fence();
+        // query -> LDS (prepared in the reference's order: kdb_load_query)
+        const float qnorm = kdb_load_query<PREC>(v, s, queries, qnorms, raw, qi);
 
         QCtr ctr{};
+        b.tied = 0u;
         KDB_T(const unsigned long long tq_start = __builtin_readcyclecounter();)
         // the query's allow list and entry point: one list for the whole batch, or its own (heterogeneous batch)
         const uint32_t *q_allow = allow;
@@ -242,11 +195,17 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (PREC == KDB_PREC_I8 && (raw & 4u)) reinterpret_cast<double *>(out_dist)[(size_t)qi * k + p] = (double)INFINITY;
             else out_dist[(size_t)qi * k + p] = INFINITY;
         }
+        // Equal distances met on the way (RegBeam::tied): raw & 8 -> reported in bit 31 of out_count; raw & 16 -> the query is
+        // queued for the heap-order walk (heap_walk_kernel, same stream), which replaces its answer and supplies ITS counters
+        const bool requeue = b.tied && (raw & 16u) && tie_list != nullptr;
         if (lane == 0) {
-            out_count[qi] = nout;
+            out_count[qi] = nout | ((b.tied && (raw & 8u)) ? 0x80000000u : 0u);
             if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
             if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
+            if (requeue) tie_list[2u + atomicAdd(tie_list, 1u)] = qi;
         }
+        tot_tied += b.tied;
+        if (requeue) ctr.n_dist = ctr.n_hops = ctr.n_dropped = 0u;
         KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu upper-layers %llu | level 0: pop %llu list %llu visited %llu rows %llu predict+post %llu predict+post+insert %llu wait-for-wave-1 %llu | wave 1: visit %llu cycles, hint hits %u\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_upper, ctr.t_pop, ctr.t_adj, ctr.t_vis, ctr.t_dist, ctr.t_pred, ctr.t_ins, ctr.t_wait, WIDE > 1 ? *reinterpret_cast<unsigned long long *>(s.ctl + 12) : 0ull, WIDE > 1 ? s.ctl[14] : 0u);)
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
@@ -255,7 +214,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     }
     if constexpr (WIDE > 1) wide_request<WIDE>(s, wc, KDB_W_EXIT, 0u);
     // Counters and the work counter re-arm themselves (no fill of the slot ahead of every launch: 5 us of a 150 us call).
-    // `work` is the third word pair of the launch's ACCUMULATOR slot {n_dist, n_hops, work | done, dropped}; every
+    // `work` is the third word pair of the launch's ACCUMULATOR slot {n_dist, n_hops, work | done, dropped, tied}; every
     // workgroup adds its sums and counts itself done; the last one publishes the totals to the statistics slot the host
     // reads and leaves the accumulators at zero for the launch that gets the slot next.
     if (lane == 0) {
@@ -266,11 +225,13 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         const unsigned long long r0 = atomicAdd(&acc[0], tot_dist);
         const unsigned long long r1 = atomicAdd(&acc[1], tot_hops);
         const unsigned long long r3 = tot_dropped ? atomicAdd(&acc[3], tot_dropped) : 0ull;
-        asm volatile("" ::"v"(r0), "v"(r1), "v"(r3) : "memory");
+        const unsigned long long r4 = tot_tied ? atomicAdd(&acc[4], tot_tied) : 0ull;
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(r3), "v"(r4) : "memory");
         if (atomicAdd(work + 1, 1u) == gridDim.x - 1u) {
             gctr[0] = atomicExch(&acc[0], 0ull);
             gctr[1] = atomicExch(&acc[1], 0ull);
             gctr[3] = atomicExch(&acc[3], 0ull);
+            gctr[2] = atomicExch(&acc[4], 0ull); // queries whose walk met equal distances
             atomicExch(&acc[2], 0ull); // work and done
         }
     }
@@ -662,13 +623,33 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     // compare-and-swap probe loop that ends when the slowest of 32 lanes has found its slot -- at a load below 7 % that is
     // two rounds, not three
     const uint32_t hsize_w = hsize ? (hsize * 4u > 16384u ? 16384u : hsize * 4u) : 0u;
-    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
-        const size_t lds = lds1 + (waves > 1u ? 64u + 512u + (size_t)(hsize_w - hsize) * 4 : 0u);
+    auto launch_any = [&](auto kern, uint32_t vis_size, uint32_t waves, size_t lds) -> int {
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
         if (grid == 0) return KDB_OK;
-        int rc = kdb_ensure_visited(idx, grid, s);
+        // KDB_SEARCH_HEAP_ORDER (raw & 16): queries whose walk meets equal distances are queued by the kernel and walked again by
+        // heap_walk_kernel (search_heap.hip) behind it -- everything it needs is allocated and armed BEFORE the launch
+        const bool heap_pass = (raw & 16u) != 0u;
+        uint32_t hgrid = 0, nl_c = 0, cap_c = 0;
+        uint32_t *d_tie_list = nullptr;
+        unsigned char *d_tails = nullptr;
+        if (heap_pass) {
+            hgrid = B < 2u * ncu ? B : 2u * ncu;
+            nl_c = kdb_heap_walk_lds_entries(v, eff, k);
+            // the candidate heap holds every accepted neighbour of a layer search: bounded by the nodes, sized for walks of ~64 ef
+            // evaluations (a walk that outgrows it keeps the fast answer and is counted)
+            const uint64_t want = (uint64_t)64u * eff > 65536u ? (uint64_t)64u * eff : 65536u;
+            cap_c = (uint32_t)(want < (uint64_t)v.count + 1u ? want : (uint64_t)v.count + 1u);
+            if (cap_c < nl_c) cap_c = nl_c;
+            const size_t list_bytes = (((size_t)B + 2u) * 4u + 255u) & ~(size_t)255u;
+            int rc0 = kdb_ensure_tie_scratch(idx, list_bytes + kdb_heap_walk_scratch_bytes(hgrid, nl_c, cap_c) + 256u);
+            if (rc0) return rc0;
+            d_tie_list = reinterpret_cast<uint32_t *>(idx->d_tie);
+            d_tails = reinterpret_cast<unsigned char *>(idx->d_tie) + list_bytes;
+            KDB_HIP(hipMemsetAsync(d_tie_list, 0, 8, s));
+        }
+        int rc = kdb_ensure_visited(idx, grid > hgrid ? grid : hgrid, s);
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         // the launch's accumulators {n_dist, n_hops, work | done, dropped}: zero between launches (see the kernel's end).  They
@@ -678,11 +659,23 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(idx->d_work + 32);
         if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev0, s));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
-                           idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops);
+                           idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops,
+                           d_tie_list);
         KDB_HIP(hipGetLastError());
+        if (heap_pass) { // (its workgroups return at once when the search kernel queued nothing; the closing event covers both passes:
+            // the second one adds its counters to the slot the first one published)
+            rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, hgrid, nl_c, cap_c, d_ctr, d_out_ids,
+                                      d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s);
+            if (rc) return rc;
+        }
         if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev1, s));
         return KDB_OK;
     };
+    auto launch = [&](auto kern, uint32_t vis_size, uint32_t waves = 1u) -> int {
+        return launch_any(kern, vis_size, waves, lds1 + (waves > 1u ? 64u + 512u + (size_t)(hsize_w - hsize) * 4 : 0u));
+    };
+    auto launch_lds = [&](auto kern, uint32_t vis_size, size_t lds) -> int { return launch_any(kern, vis_size, 1u, lds); };
+    (void)launch_lds;
     if constexpr (BS == 1 || BS == 2) {
         // latency mode: a batch that leaves most of the chip idle gives every query four waves: wave 0 walks, the other
         // three evaluate a hop's rows (one HBM round trip per hop instead of three), wave 1 prepares the next node while
@@ -705,6 +698,22 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     }
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
+    }
+    if constexpr (BS == 6 || BS == 0) {
+        // ef 261 .. 1040: the visited set of a walk (~9 ef ids) still fits LDS when the batch leaves LDS free -- 32 KB (64 KB above
+        // ef 520) per wave, four (two) waves per CU.  A batch that fits ONE round of such waves takes the LDS hash and loses the HBM
+        // bitset's dependent round trip per hop (atomicOr at the device's coherence point); larger batches keep the bitset, whose
+        // eight waves per CU hide more latency than the hash saves.  (The hash still migrates to the bitset if a walk outgrows it.)
+        const uint32_t hbig = kdb_vis_hash_size_large(eff);
+        if (hbig && !getenv("KDB_NO_LARGE_HASH")) {
+            auto kh = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>;
+            const size_t lds_h = lds_common + (size_t)hbig * 4;
+            if (lds_h + 16 <= 160 * 1024) {
+                KDB_HIP(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+                const uint32_t one_round = ncu * (uint32_t)occupancy_blocks(kh, 64, lds_h);
+                if (B <= one_round) return launch_lds(kh, hbig, lds_h);
+            }
+        }
     }
     return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 0>, 0u);
 }

@@ -23,6 +23,10 @@ F32, F16, I8 = 0, 1, 2
 SEARCH_NEEDS_REFINE = 1
 SEARCH_PREPARED = 2
 SEARCH_DIST_F64 = 8  # int8 indexes: distances come back as the reference's float64 (KDB_SEARCH_DIST_F64)
+SEARCH_TIE_FLAG = 16    # KDB_SEARCH_TIE_FLAG: bit 31 of out_count marks a walk that met equal distances
+SEARCH_HEAP_ORDER = 32  # KDB_SEARCH_HEAP_ORDER: such walks are repeated with the reference's two heaps
+COUNT_TIED = 0x80000000
+COUNT_MASK = 0x7fffffff
 
 _ELEM = {F32: np.float32, F16: np.uint16, I8: np.int8}
 
@@ -138,6 +142,14 @@ class HipIndex:
         """HIP events around the graph-search launches (launch_stats' kernel_ms); off saves two queue packets per call"""
         check(self.L.kdb_index_set_launch_timing(self.h, 1 if on else 0), "kdb_index_set_launch_timing")
 
+    def reserve(self, new_capacity: int):
+        """growNodes (hnsw_index.go:2732-2768): raise the capacity of a live index, on the device"""
+        check(self.L.kdb_index_reserve(self.h, new_capacity), "kdb_index_reserve")
+        self.capacity = max(getattr(self, "capacity", 0), new_capacity)
+
+    def drop_f16_shadow(self, refuse_for_good: bool = False):
+        check(self.L.kdb_index_drop_f16_shadow(self.h, 1 if refuse_for_good else 0), "kdb_index_drop_f16_shadow")
+
     def set_count(self, count: int):
         check(self.L.kdb_index_set_count(self.h, int(count)), "set_count")
 
@@ -241,10 +253,13 @@ class HipIndex:
         return (SEARCH_NEEDS_REFINE if self.needs_refine else 0) | (SEARCH_PREPARED if prepared else 0)
 
     def search_batch(self, queries, k: int, ef: int = 0, allow_bits=None, trace: bool = False, prepared=False,
-                     fail_on_drop: bool = False, dist64: bool = False):
+                     fail_on_drop: bool = False, dist64: bool = False, tie_flag: bool = False, heap_order: bool = False):
         """B queries -> (ids [B,k] u32, raw dist [B,k] f32, count [B] u32[, (n_dist[B], n_hops[B])]).
         fail_on_drop: KDB_SEARCH_FAIL_ON_DROP -- raise KdbError (status -7) when a walk discarded pending deleted candidates
-        dist64 (int8 indexes): dist is float64, the reference's own distances (KDB_SEARCH_DIST_F64)"""
+        dist64 (int8 indexes): dist is float64, the reference's own distances (KDB_SEARCH_DIST_F64)
+        tie_flag: KDB_SEARCH_TIE_FLAG -- count[b] carries COUNT_TIED (bit 31) when query b's walk met equal distances
+        heap_order: KDB_SEARCH_HEAP_ORDER -- such queries are walked again with the reference's two heaps (ids, order and
+        counters are then the reference's, ties included)"""
         self._live()
         q = np.ascontiguousarray(queries, dtype=np.float32)
         assert q.ndim == 2 and q.shape[1] == self.dim
@@ -259,7 +274,8 @@ class HipIndex:
             nh = np.zeros(B, dtype=np.uint32)
             check(self.L.kdb_search_set_trace(self.h, _ptr(nd), _ptr(nh), 0), "set_trace")
         try:
-            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared) | (4 if fail_on_drop else 0) | (SEARCH_DIST_F64 if dist64 else 0),
+            check(self.L.kdb_search_batch(self.h, _ptr(q), B, k, ef, _ptr(ab), self._flags(prepared) | (4 if fail_on_drop else 0) | (SEARCH_DIST_F64 if dist64 else 0)
+                                          | (SEARCH_TIE_FLAG if tie_flag else 0) | (SEARCH_HEAP_ORDER if heap_order else 0),
                                           _ptr(ids), _ptr(dist), _ptr(cnt)), "kdb_search_batch")
         finally:
             if trace:
@@ -269,13 +285,14 @@ class HipIndex:
         return ids, dist, cnt
 
     def search_batch_dev(self, d_queries, k: int, ef: int, d_out_ids, d_out_dist, d_out_count, d_allow=None,
-                         stream=None, prepared=False, dist64=False):
+                         stream=None, prepared=False, dist64=False, tie_flag=False, heap_order=False):
         """torch device tensors in, asynchronous on `stream` (a raw hipStream_t int or None).
         dist64 (int8 indexes): d_out_dist is a float64 tensor (KDB_SEARCH_DIST_F64)"""
         self._live()
         _ready(stream)
         B = d_queries.shape[0]
-        check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared) | (SEARCH_DIST_F64 if dist64 else 0),
+        check(self.L.kdb_search_batch_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow), self._flags(prepared) | (SEARCH_DIST_F64 if dist64 else 0)
+                                          | (SEARCH_TIE_FLAG if tie_flag else 0) | (SEARCH_HEAP_ORDER if heap_order else 0),
                                           _tptr(d_out_ids), _tptr(d_out_dist), _tptr(d_out_count),
                                           C.c_void_p(stream) if stream else None), "kdb_search_batch_dev")
 
@@ -321,16 +338,28 @@ class HipIndex:
         c = _lib.Counters()
         check(self.L.kdb_get_counters(self.h, C.byref(c)), "get_counters")
         return {"n_dist": int(c.n_dist), "n_hops": int(c.n_hops), "bytes": int(c.bytes),
-                "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped)}
+                "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped), "n_tied": int(c.n_tied)}
 
     def launch_stats(self, last_n: int):
         arr = (_lib.Counters * last_n)()
         check(self.L.kdb_get_launch_stats(self.h, last_n, arr), "get_launch_stats")
         return [{"n_dist": int(c.n_dist), "n_hops": int(c.n_hops), "bytes": int(c.bytes),
-                 "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped)} for c in arr]
+                 "kernel_ms": float(c.last_kernel_ms), "n_dropped": int(c.n_dropped), "n_tied": int(c.n_tied)} for c in arr]
 
     def sync(self):
         check(self.L.kdb_index_sync(self.h), "sync")
+
+    def probe_gather(self, n_reads: int = 4_000_000, shadow: bool = False):
+        """measurement hook: GB/s of a uniform random whole-row gather on this index's rows (or its half-precision copy)"""
+        ms, nbytes = C.c_float(), C.c_uint64()
+        check(self.L.kdb_probe_gather(self.h, 1 if shadow else 0, n_reads, C.byref(ms), C.byref(nbytes)), "kdb_probe_gather")
+        return nbytes.value / (ms.value * 1e-3) / 1e9
+
+    def probe_stream(self, shadow: bool = False):
+        """measurement hook: GB/s of one coalesced pass over this index's rows (or its half-precision copy)"""
+        ms, nbytes = C.c_float(), C.c_uint64()
+        check(self.L.kdb_probe_stream(self.h, 1 if shadow else 0, C.byref(ms), C.byref(nbytes)), "kdb_probe_stream")
+        return nbytes.value / (ms.value * 1e-3) / 1e9
 
     def merge_topk_dev(self, G, B, k, d_in_ids, d_in_dist, d_in_count, d_id_base, d_out_ids, d_out_dist, d_out_count,
                        stream=None):
@@ -339,7 +368,7 @@ class HipIndex:
                                         C.c_void_p(stream) if stream else None), "kdb_merge_topk_dev")
 
     def search_batch_multi_dev(self, d_queries, k: int, ef: int, d_allow_lists, d_allow_of_query, d_out_ids, d_out_dist,
-                               d_out_count, stream=None):
+                               d_out_count, stream=None, tie_flag=False, heap_order=False):
         """heterogeneous batch: d_allow_lists [G, words] int64/uint64 dense bitsets, d_allow_of_query [B] int32
         (-1 = no filter); per query the result of search_batch with its own list"""
         self._live()
@@ -347,7 +376,8 @@ class HipIndex:
         B = int(d_queries.shape[0])
         G, words = int(d_allow_lists.shape[0]), int(d_allow_lists.shape[1])
         check(self.L.kdb_search_batch_multi_dev(self.h, _tptr(d_queries), B, k, ef, _tptr(d_allow_lists), G, words,
-                                                _tptr(d_allow_of_query), self._flags(False), _tptr(d_out_ids), _tptr(d_out_dist),
+                                                _tptr(d_allow_of_query), self._flags(False) | (SEARCH_TIE_FLAG if tie_flag else 0)
+                                                | (SEARCH_HEAP_ORDER if heap_order else 0), _tptr(d_out_ids), _tptr(d_out_dist),
                                                 _tptr(d_out_count), C.c_void_p(stream) if stream else None),
               "kdb_search_batch_multi_dev")
 

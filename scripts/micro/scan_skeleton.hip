@@ -151,6 +151,7 @@ skeleton_v2(const unsigned char *__restrict__ rows, const unsigned char *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------- V1
+template <int MODE> // 0 everything, 1 no DMA after the first slab (stale operands), 2 MFMAs only (fragments read once per tile)
 __global__ void __launch_bounds__(512, 2)
 skeleton_v1(const unsigned char *__restrict__ rows, const unsigned char *__restrict__ q, uint32_t rows_per_stripe, float *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -216,29 +217,32 @@ skeleton_v1(const unsigned char *__restrict__ rows, const unsigned char *__restr
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
         read_frags(0, g & 1u, 0);
+        if (MODE == 2) read_frags(1, g & 1u, 1);
         for (uint32_t s = 0; s < NSLAB; s++, g++) {
             const uint32_t buf = g & 1u;
-            const bool dma_same = s + 1 < NSLAB, dma_next = !dma_same && has_next, dma = dma_same || dma_next;
+            const bool dma_same = s + 1 < NSLAB, dma_next = !dma_same && has_next, dma = (dma_same || dma_next) && MODE == 0;
             const uint32_t odd = t & 1u;
             const uint32_t nslab_i = dma_same ? (odd ? NSLAB - 2u - s : s + 1u) : (odd ? 0u : NSLAB - 1u);
             if (dma_next) set_rows(t + 1);
-            read_frags(1, buf, 1);
+            if (MODE != 2) read_frags(1, buf, 1);
             if (dma) issue_rows(buf ^ 1u, nslab_i);
             SB();
             mfma_step(0);
             SB();
-            read_frags(0, buf, 2);
+            if (MODE != 2) read_frags(0, buf, 2);
             if (dma) issue_queries(buf ^ 1u, nslab_i);
             SB();
             mfma_step(1);
             SB();
-            read_frags(1, buf, 3);
+            if (MODE != 2) read_frags(1, buf, 3);
             SB();
             mfma_step(0);
             SB();
-            vm_wait<0>();
-            __syncthreads();
-            if (dma_same) read_frags(0, buf ^ 1u, 0);
+            if (MODE != 2) {
+                vm_wait<0>();
+                __syncthreads();
+            }
+            if (dma_same && MODE != 2) read_frags(0, buf ^ 1u, 0);
             SB();
             mfma_step(1);
             SB();
@@ -287,7 +291,9 @@ int main() {
         free(h);
     }
     CK(hipMalloc(&d_out, 256 * 512 * 4));
-    run("V1 rows+queries shared slab buffers, 1 ahead (today, no selection)", skeleton_v1, 2 * 65536 + 64, d_rows, d_q, d_out, n);
+    run("V1 rows+queries shared slab buffers, 1 ahead (today, no selection)", skeleton_v1<0>, 2 * 65536 + 64, d_rows, d_q, d_out, n);
+    run("V1 without DMA after the first slab (fragment reads + barriers + MFMAs)", skeleton_v1<1>, 2 * 65536 + 64, d_rows, d_q, d_out, n);
+    run("V1 MFMAs only (no DMA, fragments read once per tile, no barrier)", skeleton_v1<2>, 2 * 65536 + 64, d_rows, d_q, d_out, n);
     run("V2 private row rings DR=2, query ring NQ=2", skeleton_v2<2, 2, 0>, 2 * 32768 + 8 * 2 * 4096, d_rows, d_q, d_out, n);
     run("V2 private row rings DR=2, query ring NQ=3 (rows first)", skeleton_v2<3, 2, 0>, 3 * 32768 + 8 * 2 * 4096, d_rows, d_q, d_out, n);
     run("V2 private row rings DR=2, query ring NQ=3 (queries first)", skeleton_v2<3, 2, 1>, 3 * 32768 + 8 * 2 * 4096, d_rows, d_q, d_out, n);

@@ -1,0 +1,96 @@
+// The bench line's micro_batcher leg: T concurrent one-query callers -- the shape of the reference's seam, ONE query per
+// SearchWithScores call (hnsw_index.go:343) -- go through kektor::hnsw::MicroBatcher (include/kektor_hip.hpp: the compiled
+// counterpart of the Go shim's batcher) over the bench's OWN index handle; every call's latency is recorded.  Built by bench.py
+// with g++ into a small shared library and called through ctypes, so the leg measures the C++ batcher, not a Python imitation:
+//   g++ -std=c++17 -O2 -shared -fPIC -I include scripts/micro_batcher_leg.cpp -L kektordb_amd/lib -lkektor_hip -pthread -o /tmp/libkdb_mb_leg.so
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "kektor_hip.hpp"
+
+namespace {
+
+// what BasicMicroBatcher needs of an index, over a handle somebody else owns
+class BorrowedIndex {
+  public:
+    BorrowedIndex(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {}
+    uint32_t Dim() const { return dim_; }
+    uint32_t Count() const {
+        uint32_t count = 0, entry = 0;
+        int32_t maxLevel = -1;
+        if (kdb_index_graph_info(h_, &count, &entry, &maxLevel)) return 0;
+        return count;
+    }
+    std::vector<std::vector<kektor::SearchResult>> SearchBatch(const float *queries, uint32_t B, int k, const kektor::AllowList *allowList, int efSearch) const {
+        std::vector<std::vector<kektor::SearchResult>> out(B);
+        std::vector<uint32_t> ids((size_t)B * k), cnt(B);
+        std::vector<float> dist((size_t)B * k);
+        if (kdb_search_batch(h_, queries, B, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0), allowList ? allowList->words.data() : nullptr, 0u, ids.data(),
+                             dist.data(), cnt.data()))
+            return out;
+        const bool cos = metric_ == KDB_METRIC_COSINE && precision_ == KDB_PREC_F32;
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t i = 0; i < cnt[b]; i++)
+                out[b].push_back({ids[(size_t)b * k + i], cos ? 1.0 - (double)dist[(size_t)b * k + i] : (double)dist[(size_t)b * k + i]});
+        return out;
+    }
+    std::vector<std::vector<kektor::SearchResult>> FlatScanBatch(const float *queries, uint32_t B, int k, const kektor::AllowList *allowList) const {
+        std::vector<std::vector<kektor::SearchResult>> out(B);
+        std::vector<uint32_t> ids((size_t)B * k), cnt(B);
+        std::vector<float> dist((size_t)B * k);
+        if (kdb_flat_scan_batch(h_, queries, B, (uint32_t)k, allowList ? allowList->words.data() : nullptr, 0u, ids.data(), dist.data(), cnt.data())) return out;
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t i = 0; i < cnt[b]; i++) out[b].push_back({ids[(size_t)b * k + i], (double)dist[(size_t)b * k + i]});
+        return out;
+    }
+
+  private:
+    kdb_index *h_;
+    uint32_t dim_, metric_, precision_;
+};
+
+} // namespace
+
+// T threads, `per` calls each, queries taken round-robin from the nq given; lat_us: [T * per] per-call latencies (thread-major).
+// window_us < 0: no batcher -- every caller makes its own one-query kdb_search_batch call (what the unpatched seam would do).
+extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision, const float *queries, uint32_t nq, int k,
+                                           int ef, int T, int per, int window_us, double *lat_us, double *wall_s, uint64_t *batches, uint64_t *largest,
+                                           uint64_t *answers) {
+    BorrowedIndex idx(h, dim, metric, precision);
+    kektor::hnsw::BasicMicroBatcher<BorrowedIndex>::Options o;
+    o.window = std::chrono::microseconds(window_us > 0 ? window_us : 1);
+    kektor::hnsw::BasicMicroBatcher<BorrowedIndex> mb(idx, o);
+    std::atomic<uint64_t> got{0};
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            std::vector<float> q(dim);
+            ready++;
+            while (!go.load()) std::this_thread::yield();
+            for (int it = 0; it < per; it++) {
+                const uint32_t qi = (uint32_t)((size_t)t * per + it) % nq;
+                std::memcpy(q.data(), queries + (size_t)qi * dim, (size_t)dim * 4);
+                const auto t0 = std::chrono::steady_clock::now();
+                size_t n;
+                if (window_us < 0) n = idx.SearchBatch(q.data(), 1, k, nullptr, ef)[0].size();
+                else n = mb.SearchWithScores(q, k, nullptr, ef).size();
+                lat_us[(size_t)t * per + it] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                got += n;
+            }
+        });
+    while (ready.load() < T) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true);
+    for (auto &x : th) x.join();
+    *wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const auto st = mb.stats();
+    *batches = st.batches;
+    *largest = st.largest;
+    *answers = got.load();
+    return 0;
+}

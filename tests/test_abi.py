@@ -32,7 +32,7 @@ def test_header_symbols_exported(K):
     missing = [s for s in syms if s not in exported]
     assert not missing, missing
     lib = K.load()
-    assert lib.kdb_abi_version() == 1
+    assert lib.kdb_abi_version() == 2
     for s in syms:
         getattr(lib, s)
 
@@ -51,7 +51,7 @@ def test_legacy_compute_symbols_exported(K):
 
 
 def test_header_compiles_as_plain_c():
-    src = '#include "kektor_hip.h"\nint main(void){kdb_index_desc d; (void)d; return sizeof(kdb_counters) == 40 ? 0 : 1;}\n'
+    src = '#include "kektor_hip.h"\nint main(void){kdb_index_desc d; (void)d; return sizeof(kdb_counters) == 48 ? 0 : 1;}\n'
     p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o",
                         "/tmp/kdb_hdr_test"], input=src, text=True, capture_output=True)
     assert p.returncode == 0, p.stderr

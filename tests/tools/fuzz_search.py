@@ -1,6 +1,8 @@
 """Randomised parity sweep of the graph search against the oracle (checker-side tool: uses oracle/): random shapes,
 metrics, precisions, k, ef (register / LDS beams, LDS hash / HBM bitset), allow lists (one per batch, one per query),
-deletions; ids, distance bits and per-query n_dist / n_hops must match.
+deletions, and -- every third case -- blocks of DUPLICATE rows next to the queries (equal distances: the reference's order is
+its heaps' history).  The search runs with KDB_SEARCH_HEAP_ORDER | KDB_SEARCH_TIE_FLAG: ids, distance bits and per-query
+n_dist / n_hops must equal the oracle's for EVERY query, tied or not, and no count may carry the tie bit.
     python tests/tools/fuzz_search.py [n_cases] [seed] [only_case|-] [wide]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,6 +27,10 @@ for case in range(n_cases):
         n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 256, 384, 512, 768]))
         k = int(rng.choice([1, 10, 50])); ef = int(rng.choice([0, 5, 40, 120, 300, 500])); B = int(rng.choice([1, 7, 40]))
     X = rng.random((n, dim), dtype=np.float32) if rng.random() < 0.5 else rng.standard_normal((n, dim)).astype(np.float32)
+    if case % 3 == 2 and n >= 9:  # duplicates: 2..40 copies of a few rows, the queries next to them
+        for _ in range(int(rng.integers(1, 4))):
+            src = int(rng.integers(0, n))
+            X[rng.choice(n, size=min(n - 1, int(rng.integers(2, 41))), replace=False)] = X[src]
     m_, seed_ = int(rng.choice([4, 8, 16])), int(rng.integers(1, 99))
     n_del = int(rng.integers(0, min(30, n))) if not wide else int(n * float(rng.choice([0.0, 0.1, 0.5, 0.9])))
     dele = rng.choice(n, size=n_del, replace=False) + 1
@@ -49,35 +55,29 @@ for case in range(n_cases):
     ok = True; ties = 0
     if mode < 2:
         allow = lists[pick] if mode == 1 else None
-        ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, allow_bits=allow, trace=True, dist64=(prec == O.I8))
+        ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, ef, allow_bits=allow, trace=True, dist64=(prec == O.I8), tie_flag=True, heap_order=True)
         per_q = [allow] * B
     else:
         dev = torch.device("cuda:0")
         oi = torch.zeros((B, k), dtype=torch.int32, device=dev); od = torch.zeros((B, k), device=dev); oc = torch.zeros((B,), dtype=torch.int32, device=dev)
-        idx.search_batch_multi_dev(torch.from_numpy(Q).to(dev), k, ef, torch.from_numpy(np.stack(lists).view(np.int64)).to(dev), torch.from_numpy(of_q).to(dev), oi, od, oc); idx.sync()
+        idx.search_batch_multi_dev(torch.from_numpy(Q).to(dev), k, ef, torch.from_numpy(np.stack(lists).view(np.int64)).to(dev), torch.from_numpy(of_q).to(dev), oi, od, oc, tie_flag=True, heap_order=True); idx.sync()
         ids, dist, cnt = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy(); nd = nh = None
         per_q = [None if g < 0 else lists[g] for g in of_q]
     for b in range(B):
         wi, wd, (ond, onh) = orc.search(Q[b], k, allow=per_q[b], ef=ef, counters=True)
-        c = int(cnt[b]); got_d = np.array([idx.score(x) for x in dist[b, :c]], dtype=np.float64)
+        c = int(cnt[b]) & 0x7fffffff; got_d = np.array([idx.score(x) for x in dist[b, :c]], dtype=np.float64)
         if prec == O.I8 and mode == 2:  # (the multi-list entry point returns floats: the float rounding of the oracle's doubles)
             good = c == len(wi) and np.array_equal(got_d.astype(np.float32), wd.astype(np.float32))
             if good: got_d = wd.copy()
         else:  # int8 with KDB_SEARCH_DIST_F64: the reference's float64 distances, ordered as float64
             good = c == len(wi) and np.array_equal(got_d, wd)
-        if True:
-            # equal-distance candidates pop in container/heap order in the reference and in (distance, id) order
-            # on the GPU: with an exact tie near the beam the walk may take one more or one
-            # fewer hop and tied ids may swap; everything else must be identical
-            # (a walk on hard data evaluates nodes far from the true neighbours, so any two nodes at the same
-            # distance from the query count as a possible tie)
-            D = np.sort(orc.distances(Q[b], np.arange(1, n + 1, dtype=np.uint32)))
-            tie = bool((np.diff(D) == 0).any())
-            if tie: ties += 1
-            if good and not tie:
-                good = np.array_equal(ids[b, :c], wi) and (nd is None or (int(nd[b]), int(nh[b])) == (ond, onh))
-            elif good:
-                good = all(sorted(ids[b, :c][got_d == x]) == sorted(wi[wd == x]) for x in np.unique(wd)) or c == k
+        # equal distances included: the heap-order walk answers those queries with the reference's own heaps
+        if good:
+            good = np.array_equal(ids[b, :c], wi) and (nd is None or (int(nd[b]), int(nh[b])) == (ond, onh))
+        if int(cnt[b]) & 0x80000000:
+            good = False  # an unresolved tie
+        D = np.sort(orc.distances(Q[b], np.arange(1, n + 1, dtype=np.uint32)))
+        if bool((np.diff(D) == 0).any()): ties += 1
         ok &= bool(good)
         if only is not None and not good:
             print("  q", b, "got", ids[b, :c], got_d, None if nd is None else (int(nd[b]), int(nh[b])), "want", wi, wd, (ond, onh))
