@@ -162,6 +162,9 @@ def main():
                     help="run the RCCL all-gather + merge even with one rank (plumbing check on a 1-GPU box)")
     ap.add_argument("--cluster", action="store_true",
                     help="single-process route: --gpus shards behind ONE kdb_cluster handle (what the Go shim uses), host buffers")
+    ap.add_argument("--ref-graph", action="store_true",
+                    help="side leg: the headline corpus linked by kdb_index_add_batch (the reference's own batch linking, 5000 nodes per "
+                         "call as Compress re-inserts them) instead of the fast builder: ef needed for the recall bar, and QPS there")
     ap.add_argument("--preset", default="", choices=["", "config4"],
                     help="config4 = BASELINE configs[3]: 12.5M x 768 cosine rows PER RANK (100M over 8 GPUs), clustered law (ii), 8192 queries")
     a = ap.parse_args()
@@ -462,6 +465,12 @@ def main():
                     fl["roofline"]["mfma_busy_frac"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / (b["SQ_BUSY_CYCLES"] * 32.0), 4)
                 fl["roofline"]["mfma_counters"] = {kk: round(vv, 1) for kk, vv in b.items()}
 
+    if rank == 0 and world == 1 and a.ref_graph:
+        try:
+            res["reference_linked_graph"] = ref_graph_leg(K, a, dev, centers, Q, Qh, gt, gth, k)
+        except Exception as e:
+            log(f"[bench] reference-linked graph leg failed: {e!r}")
+            res["reference_linked_graph"] = None
     # ---- CPU baseline: the restatement oracle on the SAME graph + rows + queries (rank 0, N = 1)
     if rank == 0 and world == 1 and not a.no_cpu:
         try:
@@ -703,6 +712,61 @@ def pcie_inclusive(idx, Q, k, ef):
                        "p99_ms": round(float(np.percentile(ts, 99)) * 1e3, 4), "calls": reps, "slowest_call_ms": round(max(ts) * 1e3, 4),
                        "slowest_call_index": int(np.argmax(ts))}
     return out
+
+
+def ref_graph_leg(K, a, dev, centers, Q, Qh, gt, gth, k, chunk=5000):
+    """The headline read on a reference-SHAPED graph: the same rows, linked by kdb_index_add_batch -- addBatchInternal's own linking
+    (a request for all efConstruction candidates and a reverse request to each, sorted de-duplicated unions, selectNeighbors on
+    overflow), pinned list for list against the restated batch insert -- in calls of 5000 nodes, the size DB.Compress re-inserts
+    (pkg/core/core.go:1240).  The first efConstruction nodes come from the fast builder (the reference inserts them one by one,
+    hnsw_index.go:1505-1516: 0.02 % of the graph).  Levels: randomLevel's law (:2616-2625) from a seeded stream."""
+    n, dim = a.n, a.dim
+    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, a.efc, capacity=n, device_id=dev.index or 0)
+    upload_corpus(idx, n, dim, a.corpus, 1000, dev, centers)
+    t0 = time.time()
+    first = max(a.efc, 1000)
+    idx.build(first, batch=512, ef_construction=a.efc, seed=1)
+    rng = np.random.default_rng(77)
+    ml = 1.0 / np.log(16)
+    levels = np.floor(-np.log(1.0 - rng.random(n)) * ml).astype(np.int64)
+    pos = first
+    while pos < n:
+        m = min(chunk, n - pos)
+        idx.add_batch(pos + 1, np.minimum(levels[pos:pos + m], 255).astype(np.uint8), a.efc)
+        pos += m
+    idx.sync()
+    t_build = time.time() - t0
+    B = Q.shape[0]
+    sweep, ef = {}, 0
+    ho = outs(Qh.shape[0], k, dev)
+    for cand in EF_GRID:
+        idx.search_batch_dev(Qh, k, cand, *ho)
+        idx.sync()
+        r = recall_at_k(ho[0].cpu().numpy().view(np.uint32), gth, k)
+        sweep[cand] = round(r, 4)
+        if r >= a.recall + 0.001:
+            ef = cand
+            break
+    if ef == 0:
+        ef = max(sweep)
+    o = outs(B, k, dev)
+    for _ in range(2):
+        idx.search_batch_dev(Q, k, ef, *o)
+    idx.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        idx.search_batch_dev(Q, k, ef, *o)
+    idx.sync()
+    wall = (time.perf_counter() - t0) / 10
+    st = idx.launch_stats(10)
+    kms = float(np.mean([c["kernel_ms"] for c in st]))
+    alg = float(np.mean([c["bytes"] for c in st]))
+    rec = recall_at_k(o[0].cpu().numpy().view(np.uint32), gt, k)
+    idx.Close()
+    return {"graph": f"kdb_index_add_batch, {chunk} nodes per call, efConstruction {a.efc}: {t_build:.1f} s for {n} rows",
+            "ef_search_for_recall_bar": ef, "ef_sweep_recall_heldout": sweep, "recall_at_10": round(rec, 4),
+            "qps": round(B / wall, 1), "ms_per_batch": round(wall * 1e3, 3), "kernel_ms": round(kms, 3),
+            "achieved_GBps": round(alg / (kms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
 def micro_batcher_leg(idx, Q, k, ef, per=150):

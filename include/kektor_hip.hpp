@@ -75,6 +75,8 @@ class Index {
     uint32_t Metric() const { return metric_; }
     uint32_t Precision() const { return precision_; }
     void SetNeedsRefine(bool v) { needsRefine_ = v; } // hnsw_index.go:3590
+    void SetHeapOrder(bool v) { heapOrder_ = v; }     // (on by default: the reference's answer when distances tie)
+    void Reserve(uint32_t capacity) { check(kdb_index_reserve(h_, capacity), "reserve"); } // growNodes, hnsw_index.go:2732-2768
 
     // rows in stored form (see kdb_index_upload_rows); graph as exported by SnapshotData
     void UploadRows(uint32_t firstID, uint32_t n, const void *rows) { check(kdb_index_upload_rows(h_, firstID, n, rows), "upload_rows"); }
@@ -169,8 +171,11 @@ class Index {
         if (!b.d.empty()) return b.d[i];
         return (metric_ == KDB_METRIC_COSINE && precision_ == KDB_PREC_F32) ? 1.0 - (double)b.f[i] : (double)b.f[i];
     }
+    // KDB_SEARCH_HEAP_ORDER: queries whose walk meets equal distances (duplicate vectors) are walked again with the reference's two
+    // heaps -- ids and their order are hnsw.Index's own, ties included; costs nothing while distances are distinct
     uint32_t flags() const {
-        return (needsRefine_ ? (uint32_t)KDB_SEARCH_NEEDS_REFINE : 0u) | (wide() ? (uint32_t)KDB_SEARCH_DIST_F64 : 0u);
+        return (needsRefine_ ? (uint32_t)KDB_SEARCH_NEEDS_REFINE : 0u) | (wide() ? (uint32_t)KDB_SEARCH_DIST_F64 : 0u) |
+               (heapOrder_ ? (uint32_t)KDB_SEARCH_HEAP_ORDER : 0u);
     }
     static void check(int rc, const char *what) {
         if (rc) throw Error(rc, what);
@@ -178,6 +183,7 @@ class Index {
     kdb_index *h_ = nullptr;
     uint32_t dim_, metric_, precision_;
     bool needsRefine_ = false;
+    bool heapOrder_ = true;
 };
 
 // MicroBatcher -- turns concurrent one-query callers into GPU batches (the compiled counterpart of

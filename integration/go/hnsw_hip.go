@@ -453,6 +453,9 @@ func (h *Index) searchBatchHIP(reqs []*hipRequest, k, ef int, allow *roaring.Bit
 		if h.needsRefine.Load() {
 			flags |= C.KDB_SEARCH_NEEDS_REFINE // the ef boost of hnsw_index.go:387-399 is applied by the library
 		}
+		// duplicate vectors: equal distances pop / evict / sort in the order of the two heaps of hnsw_heap.go; the library walks
+		// exactly those queries again with the same two heaps, so ids and their order are this package's own, ties included
+		flags |= C.KDB_SEARCH_HEAP_ORDER
 		rc = C.kdb_search_batch(h.gpu.h, (*C.float)(unsafe.Pointer(&queries[0])), C.uint32_t(B), C.uint32_t(k), C.uint32_t(ef),
 			allowPtr, flags, (*C.uint32_t)(unsafe.Pointer(&ids[0])), distPtr,
 			(*C.uint32_t)(unsafe.Pointer(&cnt[0])))

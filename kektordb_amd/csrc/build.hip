@@ -84,7 +84,7 @@ struct BuildViewT {
 // ---- phase 1 ------------------------------------------------------------------------------------
 template <int METRIC, int BS, int PREC>
 __global__ void __launch_bounds__(64)
-build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t beam_cap, uint32_t *visited_pool, uint32_t *work) {
+build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t beam_cap, uint32_t nr_cap, uint32_t *visited_pool, uint32_t *work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool I8 = PREC == KDB_PREC_I8;
     WaveLds s;
@@ -106,10 +106,18 @@ build_search_kernel(KdbView v, BuildViewT<typename BKey<PREC>::T> bv, uint32_t b
         }
         s.beam_cap = beam_cap;
     }
-    s.nr_d = nullptr; // construction never meets a deleted node or a filter
-    s.nr_id = nullptr;
-    s.nr_cap = 0;
+    // soft-deleted nodes are traversed, never returned (:2583-2590): they wait in the side list, exactly as in the query path
+    // (AddBatch into an index that holds deleted nodes is ordinary); sized like the search kernel's
+    s.nr_d = reinterpret_cast<float *>(smem + off);
+    off += (size_t)nr_cap * 4;
+    s.nr_id = reinterpret_cast<uint32_t *>(smem + off);
+    off += (size_t)nr_cap * 4;
     s.nr_lo = nullptr;
+    if (I8) {
+        s.nr_lo = reinterpret_cast<uint32_t *>(smem + off);
+        off += (size_t)nr_cap * 4;
+    }
+    s.nr_cap = nr_cap;
     s.ctl = nullptr;
     s.nb_id = reinterpret_cast<uint32_t *>(smem + off);
     off += 64 * 4;
@@ -1094,8 +1102,9 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     // ---- launch geometry
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
     const int bs = kdb_beam_slots(efc) == 0 ? 0 : kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
+    const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u; // traversal-only candidates (deleted nodes)
     const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
-                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0);
+                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0) + (size_t)nr_cap * (PREC == KDB_PREC_I8 ? 12 : 8);
     const size_t lds_prune = prune_lds_bytes<KT>();
     auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
                    : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
@@ -1153,7 +1162,7 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
         KdbView v = kdb_make_view(idx);
         v.count = next + nb - 1;
         uint32_t grid = slots_vis < nb ? slots_vis : nb;
-        hipLaunchKernelGGL(ksearch, dim3(grid), dim3(64), lds_search, s, v, bv, beam_cap, idx->d_visited, idx->d_work);
+        hipLaunchKernelGGL(ksearch, dim3(grid), dim3(64), lds_search, s, v, bv, beam_cap, nr_cap, idx->d_visited, idx->d_work);
         KDB_HIP(hipGetLastError());
         hipLaunchKernelGGL(kselect, dim3(n_tasks), dim3(256), lds_prune, s, v, bv);
         KDB_HIP(hipGetLastError());
@@ -1244,8 +1253,9 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     }
     const uint32_t beam_cap = ((efc + 64 + 1) + 63) / 64 * 64;
     const int bs = kdb_beam_slots(efc) == 0 ? 0 : kdb_beam_slots(efc) < 2 ? 2 : kdb_beam_slots(efc);
+    const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u; // traversal-only candidates (deleted nodes)
     const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
-                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0);
+                              (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0) + (size_t)nr_cap * (PREC == KDB_PREC_I8 ? 12 : 8);
     auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
                    : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
                    : bs == 4 ? build_search_kernel<METRIC, 4, PREC>
@@ -1355,7 +1365,7 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     KDB_TRY(hipMemsetAsync(idx->d_work, 0, 4, s));
     // ---- phase 1: every new node searches the graph as it was (entry point / maxLevel frozen, :1796-1801)
     KdbView v = kdb_make_view(idx); // count = new_count: the new ids are valid wherever a walk meets them (the re-used slot)
-    hipLaunchKernelGGL(ksearch, dim3(slots_vis < nb ? slots_vis : nb), dim3(64), lds_search, s, v, bv, beam_cap, idx->d_visited, idx->d_work);
+    hipLaunchKernelGGL(ksearch, dim3(slots_vis < nb ? slots_vis : nb), dim3(64), lds_search, s, v, bv, beam_cap, nr_cap, idx->d_visited, idx->d_work);
     KDB_TRY(hipGetLastError());
     // ---- phases 2 + 3
     const uint32_t reuse_id = reuse ? first : 0u;

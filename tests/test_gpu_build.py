@@ -440,7 +440,8 @@ def _compare_graphs(idx, orc, O, prec):
     """(lists compared, lists that differ) between the GPU index and the oracle, every level, stored order"""
     cnt, entry, mlv, glv, offs, nbrs = idx.download_graph()
     og = orc.export_graph()
-    assert (cnt, entry, mlv) == (og.count, og.entry, og.max_level), ((cnt, entry, mlv), (og.count, og.entry, og.max_level))
+    # (after a batch insert the reference's counter is one ahead: the last reserved id holds no node, hnsw_index.go:1620)
+    assert cnt in (og.count, og.count - 1) and (entry, mlv) == (og.entry, og.max_level), ((cnt, entry, mlv), (og.count, og.entry, og.max_level))
     assert np.array_equal(glv[1:cnt + 1], og.levels[1:cnt + 1]), np.nonzero(glv[1:cnt + 1] != og.levels[1:cnt + 1])[0][:10] + 1
     total = bad = 0
     for l in range(mlv + 1):
