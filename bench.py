@@ -414,6 +414,7 @@ def main():
     if extras:
         for name, fn in (("batch_sweep", lambda: batch_sweep(idx, Q, k, ef, dev)),
                          ("pcie_inclusive", lambda: pcie_inclusive(idx, Q, k, ef)),
+                         ("heap_order", lambda: heap_order_leg(idx, Q, k, ef, dev)),
                          ("micro_batcher", lambda: micro_batcher_leg(idx, Q, k, ef)),
                          ("flat_scan_leg", lambda: flat_leg(idx, Q, k, n, dim, a.flat_batch, dev)),
                          ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev)),
@@ -767,6 +768,26 @@ def ref_graph_leg(K, a, dev, centers, Q, Qh, gt, gth, k, chunk=5000):
             "ef_search_for_recall_bar": ef, "ef_sweep_recall_heldout": sweep, "recall_at_10": round(rec, 4),
             "qps": round(B / wall, 1), "ms_per_batch": round(wall * 1e3, 3), "kernel_ms": round(kms, 3),
             "achieved_GBps": round(alg / (kms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def heap_order_leg(idx, Q, k, ef, dev):
+    """KDB_SEARCH_HEAP_ORDER on the headline batch: how many walks meet two different nodes at EQUAL distance (the reference's order
+    among those is the history of its two heaps), and what walking exactly those again with the reference's heaps costs."""
+    B = Q.shape[0]
+    o = outs(B, k, dev)
+    res = {}
+    for name, kw in (("fast_path_only", {}), ("tie_flag", {"tie_flag": True}), ("heap_order", {"heap_order": True})):
+        idx.search_batch_dev(Q, k, ef, *o, **kw)
+        idx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            idx.search_batch_dev(Q, k, ef, *o, **kw)
+        idx.sync()
+        t = (time.perf_counter() - t0) / 5
+        res[name] = {"ms_per_batch": round(t * 1e3, 3), "qps": round(B / t, 1)}
+        res["queries_with_equal_distances"] = idx.counters()["n_tied"]
+    res["queries"] = B
+    return res
 
 
 def micro_batcher_leg(idx, Q, k, ef, per=150):

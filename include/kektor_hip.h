@@ -252,7 +252,7 @@ KDB_API int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint32_
 KDB_API int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device);
 
 /* Exact scan over every non-deleted (and allowed) row.  An EMPTY allow list means "no filter"
- * (vector_index.go:130).  k <= 128.  The answer is the exact top-k under the index's own distance (total order:
+ * (vector_index.go:130).  k <= 1024 (the matrix-core kernels serve k <= 128; above that every distance is computed in the final order and a radix select per query picks the k smallest: exact for any k, HBM-bound on the rows).  The answer is the exact top-k under the index's own distance (total order:
  * distance, then id); reported distances are computed in the accumulation order of kdb_search_batch, so a (query,
  * row) pair has the same distance bits from either entry point.  Internally the matrix cores rank (f32 / f16 / i8
  * MFMA; float32 rows of large batches on the f16 MFMA inside a rigorous error band) and the finalists are re-scored;

@@ -207,7 +207,7 @@ class BasicMicroBatcher {
     struct Stats {
         uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
     };
-    static constexpr int kMaxFlatK = 128; // kdb_flat_scan_batch: k <= 128
+    static constexpr int kMaxFlatK = 1024; // kdb_flat_scan_batch: k <= 1024
     explicit BasicMicroBatcher(IndexT &idx) : idx_(idx) {}
     BasicMicroBatcher(IndexT &idx, const Options &o) : idx_(idx), opt_(o) {}
     ~BasicMicroBatcher() { Stop(); }

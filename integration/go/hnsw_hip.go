@@ -428,8 +428,8 @@ func (h *Index) searchBatchHIP(reqs []*hipRequest, k, ef int, allow *roaring.Bit
 		}
 		allowPtr = (*C.uint64_t)(unsafe.Pointer(&dense[0]))
 		card := allow.GetCardinality()
-		// the exact scan answers k <= 128 (kdb_flat_scan_batch); larger k keeps the walk, as the C++ twin does
-		useFlat = card > 0 && k <= 128 && float64(card) < hipFlatScanSelectivity*float64(count)
+		// the exact scan answers k <= 1024 (kdb_flat_scan_batch); larger k keeps the walk, as the C++ twin does
+		useFlat = card > 0 && k <= 1024 && float64(card) < hipFlatScanSelectivity*float64(count)
 	}
 	ids := make([]uint32, B*k)
 	// int8 indexes: the distances are float64 in the reference (hnsw_index.go:2429-2454); KDB_SEARCH_DIST_F64 makes the

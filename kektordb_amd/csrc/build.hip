@@ -1106,10 +1106,7 @@ int build_impl(kdb_index *idx, uint32_t count, const kdb_build_params *bp) {
     const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
                               (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0) + (size_t)nr_cap * (PREC == KDB_PREC_I8 ? 12 : 8);
     const size_t lds_prune = prune_lds_bytes<KT>();
-    auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
-                   : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
-                   : bs == 4 ? build_search_kernel<METRIC, 4, PREC>
-                             : build_search_kernel<METRIC, 6, PREC>;
+    auto ksearch = bs == 0 ? build_search_kernel<METRIC, 0, PREC> : bs == 2 ? build_search_kernel<METRIC, 2, PREC> : build_search_kernel<METRIC, 4, PREC>;
     auto kselect = build_select_kernel<METRIC, PREC>;
     auto krev = build_reverse_kernel<METRIC, PREC>;
     if (lds_prune > 64 * 1024) {
@@ -1256,10 +1253,7 @@ int add_batch_ref_impl(kdb_index *idx, uint32_t first, uint32_t nb, const uint8_
     const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u; // traversal-only candidates (deleted nodes)
     const size_t lds_search = (PREC == KDB_PREC_I8 ? (size_t)idx->ld + 64 * 12 : (size_t)idx->ld * 4 + 64 * 8) + KDB_UP_MARK_CAP * 4 +
                               (bs == 0 ? (size_t)beam_cap * (PREC == KDB_PREC_I8 ? 12 : 8) : 0) + (size_t)nr_cap * (PREC == KDB_PREC_I8 ? 12 : 8);
-    auto ksearch = bs == 0   ? build_search_kernel<METRIC, 0, PREC>
-                   : bs == 2 ? build_search_kernel<METRIC, 2, PREC>
-                   : bs == 4 ? build_search_kernel<METRIC, 4, PREC>
-                             : build_search_kernel<METRIC, 6, PREC>;
+    auto ksearch = bs == 0 ? build_search_kernel<METRIC, 0, PREC> : bs == 2 ? build_search_kernel<METRIC, 2, PREC> : build_search_kernel<METRIC, 4, PREC>;
     if (lds_search > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)ksearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_search));
     const size_t lds_commit = prune_lds_bytes<KT>() + (size_t)ucap_lds * (KB + 8) + 2048 + (size_t)idx->ld * 4 + 64;
     const size_t lds_big = prune_lds_bytes<KT>() + 2048 + (size_t)idx->ld * 4 + 64;

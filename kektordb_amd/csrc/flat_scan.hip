@@ -1658,11 +1658,40 @@ int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld,
 int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
                          float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s) {
-    if (k == 0 || k > 128) {
-        kdb_set_error("flat scan: k must be in 1..128 (got %u)", k);
+    if (k == 0 || k > KDB_FLAT_MAX_K) {
+        kdb_set_error("flat scan: k must be in 1..%u (got %u)", KDB_FLAT_MAX_K, k);
         return KDB_ERR_INVALID;
     }
     if (B == 0) return KDB_OK;
+    if (k > 128) { // beyond the tile kernels' lists: every distance in the final order + a radix select per query (flat_anyk.hip)
+        const size_t ids_b = ((size_t)v.count * 4 + 255) / 256 * 256;
+        const bool ids_needed = d_allow != nullptr || idx->n_deleted > 0;
+        const size_t stride = ((size_t)v.count + 63) & ~(size_t)63;
+        uint32_t chunk_q = (uint32_t)(((size_t)2 << 30) / (stride * 8)); // <= 2 GB of keys at a time
+        if (chunk_q < 1) chunk_q = 1;
+        if (chunk_q > B) chunk_q = B;
+        if (chunk_q > 65535u) chunk_q = 65535u;
+        int rc = kdb_ensure_scratch(idx, ids_b + 256 + (size_t)chunk_q * stride * 8 + 256);
+        if (rc) return rc;
+        unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
+        uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
+        uint32_t *d_nscan = reinterpret_cast<uint32_t *>(base + ids_b);
+        unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(base + ids_b + 256);
+        if (ids_needed) {
+            KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
+            hipLaunchKernelGGL(compact_ids_kernel, dim3(((v.count >> 5) + 256) / 256), dim3(256), 0, s, v.deleted, d_allow, d_first_allowed, v.count, d_ids,
+                               d_nscan);
+            KDB_HIP(hipGetLastError());
+        }
+        unsigned long long *slot = kdb_stats_begin(idx, 2, B, 0);
+        KDB_HIP(hipMemsetAsync(slot, 0, 32, s));
+        KDB_HIP(hipEventRecord(idx->ev0, s));
+        rc = kdb_launch_flat_anyk(idx, v, d_q, d_qnorm, B, k, ids_needed ? d_ids : nullptr, ids_needed ? d_nscan : nullptr, d_keys, chunk_q, d_out_ids, d_out_dist,
+                                  d_out_count, (queries_normalised & 2) ? 1 : 0, slot, s);
+        if (rc) return rc;
+        KDB_HIP(hipEventRecord(idx->ev1, s));
+        return KDB_OK;
+    }
     const bool dist64 = (queries_normalised & 2) != 0; // int8: d_out_dist is a double array (KDB_SEARCH_DIST_F64)
     const int qn_arg = queries_normalised;
     queries_normalised &= 1;

@@ -205,6 +205,11 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                          uint32_t k, const uint32_t *d_allow, const uint32_t *d_first_allowed, uint32_t *d_out_ids,
                          float *d_out_dist, uint32_t *d_out_count, int queries_normalised, hipStream_t s);
 int kdb_ensure_up_slots(kdb_index *idx, hipStream_t s);
+// flat_anyk.hip: the exact scan for 128 < k <= KDB_FLAT_MAX_K (all distances in the final order + radix select)
+#define KDB_FLAT_MAX_K 1024u
+int kdb_launch_flat_anyk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, uint32_t k, const uint32_t *d_scan_ids,
+                         const uint32_t *d_nscan, unsigned long long *d_keys, uint32_t chunk_q, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                         int dist64, unsigned long long *d_ctr, hipStream_t s);
 int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s);
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,

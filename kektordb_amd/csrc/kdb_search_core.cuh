@@ -1591,8 +1591,8 @@ __host__ __device__ inline int kdb_beam_slots(uint32_t ef) {
     if (need <= 64) return 1; // one entry per lane: every beam operation stays inside one register
     if (need <= 128) return 2;
     if (need <= 256) return 4;
-    if (need <= 384) return 6;
-    return 0;
+    return 0; // (six register slots, ef 257..384, lost to the LDS beam's one merge per hop: 1M x 768, k=100, 1024 queries, ef 384: 3.63 ms
+              //  against 2.89 ms at ef 400 -- scripts/ef_probe.py, round 4; the slot count 6 is gone)
 }
 
 } // namespace kdbcore

@@ -699,7 +699,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
     }
-    if constexpr (BS == 6 || BS == 0) {
+    if constexpr (BS == 0) {
         // ef 261 .. 1040: the visited set of a walk (~9 ef ids) still fits LDS when the batch leaves LDS free -- 32 KB (64 KB above
         // ef 520) per wave, four (two) waves per CU.  A batch that fits ONE round of such waves takes the LDS hash and loses the HBM
         // bitset's dependent round trip per hop (atomicOr at the device's coherence point); larger batches keep the bitset, whose
@@ -725,11 +725,10 @@ static int launch_search_t(kdb_index *idx, const KdbView &v, const void *d_q, co
                            hipStream_t s) {
     const uint32_t eff = ef < k ? k : ef;
 #define KDB_A idx, v, d_q, d_qnorm, raw, B, k, ef, d_allow, ma, entry, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s
-    switch (kdb_beam_slots(eff)) { // beam in registers (1/2/4/6 slots of 64 entries) or in LDS
+    switch (kdb_beam_slots(eff)) { // beam in registers (1/2/4 slots of 64 entries) or in LDS
     case 1: return launch_search_bs<PREC, METRIC, NCH, 1>(KDB_A);
     case 2: return launch_search_bs<PREC, METRIC, NCH, 2>(KDB_A);
     case 4: return launch_search_bs<PREC, METRIC, NCH, 4>(KDB_A);
-    case 6: return launch_search_bs<PREC, METRIC, NCH, 6>(KDB_A);
     default: return launch_search_bs<PREC, METRIC, NCH, 0>(KDB_A);
     }
 #undef KDB_A

@@ -62,14 +62,14 @@ int main() {
     const auto st = mb.stats();
     if (st.calls != 24 * 60 || st.batches >= st.calls || st.largest > 16 || st.flatBatches == 0) bad++;
     if (idx.calls.load() + idx.flat_calls.load() != (int)st.batches) bad++;
-    // a selective filter with k > 128 must still be answered (by the walk: the exact scan takes k <= 128), and a scan that
+    // a selective filter with k > 1024 must still be answered (by the walk: the exact scan takes k <= 1024), and a scan that
     // refuses its arguments falls back to the walk instead of returning []
     {
         std::vector<float> q(8, 0.f);
         q[0] = 7.f;
         const int before_flat = idx.flat_calls.load();
-        auto r = mb.SearchWithScores(q, 200, &narrow, 64);
-        if (r.size() != 200 || r[0].Score != 64.0 || idx.flat_calls.load() != before_flat) bad++;
+        auto r = mb.SearchWithScores(q, 1500, &narrow, 64);
+        if (r.size() != 1500 || r[0].Score != 64.0 || idx.flat_calls.load() != before_flat) bad++;
         idx.refuse_flat = true;
         r = mb.SearchWithScores(q, 5, &narrow, 33);
         if (r.size() != 5 || r[0].Score != 33.0) bad++;

@@ -88,15 +88,21 @@ int main() {
                         (unsigned long long)st.batches, (unsigned long long)st.largest, (unsigned long long)st.flatBatches);
             bad++;
         }
-        // k > 128 under a selective filter: the exact scan does not take it, the walk answers (never [] where the
-        // reference answers); with a wide filter the walk fills all 200 places
+        // k above 128 under a selective filter: the exact scan takes it up to k = 1024 (flat_anyk.hip) -- the batcher's answer is
+        // the scan's; beyond that the walk answers (never [] where the reference answers); with a wide filter the walk fills
+        // all 200 places
         {
             std::vector<float> qq(X.begin() + dim, X.begin() + 2 * dim);
             auto narrow = mb.SearchWithScores(qq, 200, &few, 300);
-            auto direct = idx.SearchWithScores(qq, 200, &few, 300);
-            if (narrow.empty() || narrow.size() != direct.size()) bad++;
-            for (size_t j = 0; j < narrow.size() && j < direct.size(); j++)
-                if (narrow[j].DocID != direct[j].DocID) bad++;
+            auto scan = idx.FlatScanBatch(qq.data(), 1, 200, &few)[0];
+            if (narrow.empty() || narrow.size() != scan.size()) bad++;
+            for (size_t j = 0; j < narrow.size() && j < scan.size(); j++)
+                if (narrow[j].DocID != scan[j].DocID || narrow[j].Score != scan[j].Score) bad++;
+            auto huge = mb.SearchWithScores(qq, 1100, &few, 300);
+            auto direct = idx.SearchWithScores(qq, 1100, &few, 300);
+            if (huge.empty() || huge.size() != direct.size()) bad++;
+            for (size_t j = 0; j < huge.size() && j < direct.size(); j++)
+                if (huge[j].DocID != direct[j].DocID) bad++;
             if (mb.SearchWithScores(qq, 200, &allow, 300).size() != 200) bad++;
         }
         if (!mb.SearchWithScores(std::vector<float>(3, 0.f), 5, nullptr, 10).empty()) bad++; // wrong width -> []
