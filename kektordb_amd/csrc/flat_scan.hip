@@ -593,6 +593,7 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
 constexpr int FSS_TQ = 16;     // queries per workgroup
 constexpr int FSS_CH = 8;      // 16-element K steps per register chunk (128 floats of every row)
 constexpr int FSS_SLACK = 64;  // buffer = kl + one tile of rows + slack entries
+constexpr uint32_t FSS_TAIL = FSS_TQ * 12; // thresholds, counts
 template <int PREC>
 __host__ __device__ inline size_t fss_q_bytes(uint32_t ld);
 __host__ __device__ inline uint32_t fss_qstride(uint32_t ld) { return ld + ((40u + 64u - (ld & 63u)) & 63u); }
@@ -600,20 +601,51 @@ __host__ __device__ inline uint32_t fss_qstride(uint32_t ld) { return ld + ((40u
 template <int PREC>
 __host__ __device__ inline size_t fss_q_bytes(uint32_t ld) {
     return PREC == KDB_PREC_I8   ? (((size_t)FSS_TQ * (ld + 16u) + 255u) & ~(size_t)255u)
-           : PREC == FS_PREC_F32R ? (((size_t)FSS_TQ * (ld * 2u + 16u) + 255u) & ~(size_t)255u)
+           : (PREC == FS_PREC_F32R || PREC == KDB_PREC_F16) ? (((size_t)FSS_TQ * (ld * 2u + 16u) + 255u) & ~(size_t)255u)
                                   : (size_t)FSS_TQ * fss_qstride(ld) * 4u;
 }
 
-template <int METRIC, int PREC>
-__global__ void __launch_bounds__(256)
+// Steps per register chunk.  When the rows cut into an even number of whole chunks of whole 64-byte (RAW) / 16-float steps the
+// kernel is instantiated with CS as a compile-time constant: no clamped addresses, immediate offsets, <= 244 registers (two
+// workgroups per CU).  8 is preferred (2 x 16 row loads per lane in flight), then 6, then 4.  0: the generic instantiation (any
+// row length; 289 registers, one workgroup per CU).  KDB_FSS_CS forces a feasible value (measurements).
+template <int PREC>
+__host__ inline uint32_t fss_exact_cs(uint32_t ld) {
+    constexpr bool RAW = PREC == KDB_PREC_I8 || PREC == FS_PREC_F32R || PREC == KDB_PREC_F16;
+    const uint32_t rowb = PREC == KDB_PREC_I8 ? ld : ld * 2u;
+    if (RAW ? (rowb & 63u) != 0u : (ld & 15u) != 0u) return 0u;
+    const uint32_t nsteps = RAW ? rowb >> 6 : ld >> 4;
+    if (nsteps == 0u) return 0u;
+    if (const char *e = getenv("KDB_FSS_CS")) {
+        const uint32_t c = (uint32_t)atoi(e);
+        if (c == 0u) return 0u;
+        if ((c == 8u || c == 6u || c == 4u) && nsteps % (2u * c) == 0u) return c;
+    }
+    for (uint32_t c : {8u, 6u, 4u})
+        if (nsteps % (2u * c) == 0u) return c;
+    return 0u;
+}
+
+// measurement switches of the small kernel (KDB_FSS_DBG, only in builds with -DKDB_FB_DEBUG: `make dbg`): 1 no selection (the
+// accumulators are dropped; barriers stay), 2 neither selection nor its barriers, 4 queries zero-filled instead of loaded,
+// 8 no side loads (ids of the rows to select from, norms)
+#ifdef KDB_FB_DEBUG
+#define FSS_DBG p.fb_dbg
+#else
+#define FSS_DBG 0u
+#endif
+template <int METRIC, int PREC, int CS>
+__global__ void __launch_bounds__(256, CS ? 2 : 1)
 flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uint32_t n_q16, uint32_t cap_s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // queries in LDS: [16][S] floats (f32, f16 widened), or [16][S8] bytes (int8, stride ld+16: conflict-free b128 reads)
     const uint32_t S = fss_qstride(v.ld);
     // raw-bytes mode (int8 rows; the half-precision ranking copy of float32 rows): a row is rowb bytes, one step = 64 of
     // them per row (64 int8 / 32 f16 components), queries sit in LDS in the same encoding with stride rowb + 16
-    constexpr bool RAW = PREC == KDB_PREC_I8 || PREC == FS_PREC_F32R;
-    const uint32_t rowb = PREC == FS_PREC_F32R ? v.ld * 2u : v.ld;
+    // (float16 rows: the prepared query holds exact halfs, f16 x f16 products are exact in f32 and only the summation order is
+    // the MFMA's -- the keys rank, the merge re-scores in the final order, like every other scan)
+    constexpr bool RAW = PREC == KDB_PREC_I8 || PREC == FS_PREC_F32R || PREC == KDB_PREC_F16;
+    const uint32_t rowb = PREC == KDB_PREC_I8 ? v.ld : v.ld * 2u;
     const uint32_t S8 = rowb + 16u;
     float *qs = reinterpret_cast<float *>(smem);
     unsigned char *qs8 = smem;
@@ -656,11 +688,11 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     uint32_t row_end = row_begin + geo.rows_per_stripe;
     if (row_end > geo.n_scan) row_end = geo.n_scan;
 
-    if (PREC == FS_PREC_F32R) { // prepared float32 queries -> halfs (RNE), 8 at a time
+    if (PREC == FS_PREC_F32R || PREC == KDB_PREC_F16) { // prepared float32 queries -> halfs (RNE; exact for a float16 index), 8 at a time
         for (uint32_t i = (uint32_t)tid; i < FSS_TQ * (v.ld >> 3); i += 256) {
             const uint32_t n = i / (v.ld >> 3), c = i % (v.ld >> 3);
             f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n < nq) {
+            if (n < nq && !(FSS_DBG & 4u)) {
                 const float4 *qp = reinterpret_cast<const float4 *>(queries + (size_t)(q0 + n) * v.ld + c * 8u);
                 const float4 y0 = qp[0], y1 = qp[1];
                 h = (f16x8){(_Float16)y0.x, (_Float16)y0.y, (_Float16)y0.z, (_Float16)y0.w,
@@ -692,48 +724,57 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     __syncthreads();
 
     const float *rows = reinterpret_cast<const float *>(v.rows);
-    const uint16_t *rows16 = reinterpret_cast<const uint16_t *>(v.rows);
     const unsigned char *rows8 = PREC == FS_PREC_F32R ? reinterpret_cast<const unsigned char *>(p.rows16)
                                                       : reinterpret_cast<const unsigned char *>(v.rows);
     // one step = one 16-byte load per lane: 16 k-values of a f32/f16 row, 64 of an int8 row
     const uint32_t nsteps = RAW ? (rowb + 63u) >> 6 : v.ld >> 4;
     // a tile is cut into an EVEN number of register chunks (<= FSS_CH steps each), so that every tile starts
     // in buffer A and the per-tile side loads below have a fixed place in the pipeline
-    const uint32_t nch = 2u * ((nsteps + 2u * FSS_CH - 1u) / (2u * FSS_CH));
-    const uint32_t cs = (nsteps + nch - 1u) / nch;
+    const uint32_t nch = CS ? nsteps / (uint32_t)CS : 2u * ((nsteps + 2u * FSS_CH - 1u) / (2u * FSS_CH));
+    const uint32_t cs = CS ? (uint32_t)CS : (nsteps + nch - 1u) / nch;
+    constexpr int NU = CS ? CS : FSS_CH; // loads per row and chunk
     const uint32_t wrow = (uint32_t)wave * 32u; // this wave's 32 rows of the 128-row tile
 
     // row ids of the two rows this lane LOADS (fi of each 16-row group); under a filter they come from scan_ids
     // and are fetched one tile ahead so that the row loads never wait for them
+    // EVERY global load of the pipelined loop is unconditional and straight-line (addresses are clamped into the row / the id
+    // list; what a clamped load fetched is discarded where it is consumed).  A load under a branch -- even a wave-uniform one --
+    // makes the compiler's s_waitcnt placement give up counting: it then waits for vmcnt(0) before the MFMAs, i.e. for the chunk
+    // it has JUST issued, and the two register buffers stop overlapping (round 4: that was 0.74 vs 0.89 of the HBM peak on the
+    // gathered scan; scripts/micro/gather_patterns.hip is the same loop without the branches).
+    const uint32_t *id_src = scan_ids ? scan_ids : reinterpret_cast<const uint32_t *>(v.rows); // no list: any readable word, unused
+    const uint32_t id_last = scan_ids && row_end > 0u ? row_end - 1u : 0u;
     uint32_t ld_id[2] = {0u, 0u}, ld_nx[2] = {0u, 0u};
-    auto load_ids = [&](uint32_t (&dst)[2], uint32_t tile) {
+    auto load_ids_raw = [&](uint32_t (&dst)[2], uint32_t tile) { // fixed up by ids_fix() where the ids are first needed
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const uint32_t rr = tile + wrow + (uint32_t)(a * 16 + fi);
-            dst[a] = rr < row_end ? (scan_ids ? scan_ids[rr] : rr + 1u) : 0u;
+            dst[a] = id_src[rr < id_last ? rr : id_last];
+        }
+    };
+    auto ids_fix = [&](uint32_t (&dst)[2], uint32_t tile) {
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const uint32_t rr = tile + wrow + (uint32_t)(a * 16 + fi);
+            dst[a] = rr < row_end ? (scan_ids ? dst[a] : rr + 1u) : 0u; // past the stripe: row 0 (the pad row), never selected
         }
     };
     auto issue = [&](float4 (&dst)[2][FSS_CH], uint32_t ch) {
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int u = 0; u < FSS_CH; u++) {
-                const uint32_t step = ch * cs + (uint32_t)u;
+            for (int u = 0; u < NU; u++) {
+                // generic instantiation: a step past the chunk / the row re-reads the row's FIRST step (cached; multiply() skips
+                // it), the tail of a partial last step re-reads the row's last 16 bytes (its query bytes are zero)
+                uint32_t step = ch * cs + (uint32_t)u;
+                if (!CS) step = ((uint32_t)u < cs && step < nsteps) ? step : 0u;
                 const uint32_t col = step * 16u + (uint32_t)fg * 4u;
-                if ((uint32_t)u < cs && step < nsteps) {
-                    if (RAW) { // bytes as they are; the last step of a row may be partial
-                        const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
-                        dst[a][u] = cb < rowb ? *reinterpret_cast<const float4 *>(rows8 + (size_t)ld_id[a] * rowb + cb)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                    } else if (PREC == KDB_PREC_F16) { // halfs, widened exactly onto the f32 MFMA
-                        const uint2 h = *reinterpret_cast<const uint2 *>(rows16 + (size_t)ld_id[a] * v.ld + col);
-                        dst[a][u] = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)),
-                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
-                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)),
-                                                (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
-                    } else {
-                        dst[a][u] = *reinterpret_cast<const float4 *>(rows + (size_t)ld_id[a] * v.ld + col);
-                    }
+                if (RAW) {
+                    uint32_t cb = step * 64u + (uint32_t)fg * 16u;
+                    if (!CS) cb = cb < rowb ? cb : rowb - 16u;
+                    dst[a][u] = *reinterpret_cast<const float4 *>(rows8 + (size_t)ld_id[a] * rowb + cb);
+                } else {
+                    dst[a][u] = *reinterpret_cast<const float4 *>(rows + (size_t)ld_id[a] * v.ld + col);
                 }
             }
     };
@@ -741,13 +782,13 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     auto multiply = [&](float4 (&src)[2][FSS_CH], uint32_t ch) {
 #pragma unroll
-        for (int u = 0; u < FSS_CH; u++) {
+        for (int u = 0; u < NU; u++) {
             const uint32_t step = ch * cs + (uint32_t)u;
-            if ((uint32_t)u >= cs || step >= nsteps) break;
+            if (!CS && ((uint32_t)u >= cs || step >= nsteps)) break;
             if (RAW) { // one MFMA per 16-row group and 64-byte step: exact i32 dots (int8), f16 products summed in f32
                 const uint32_t cb = step * 64u + (uint32_t)fg * 16u;
-                const float4 q16 = cb < rowb ? *reinterpret_cast<const float4 *>(qs8 + (uint32_t)fi * S8 + cb)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 q16 = (CS || cb < rowb) ? *reinterpret_cast<const float4 *>(qs8 + (uint32_t)fi * S8 + cb)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
                     if (PREC == KDB_PREC_I8)
@@ -761,12 +802,13 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
                 continue;
             }
             const float4 qf = *reinterpret_cast<const float4 *>(qs + (uint32_t)fi * S + step * 16u + (uint32_t)fg * 4u);
+            const float4 ra[2] = {src[0][u], src[1][u]};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float bv = j == 0 ? qf.x : j == 1 ? qf.y : j == 2 ? qf.z : qf.w;
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
-                    const float av = j == 0 ? src[a][u].x : j == 1 ? src[a][u].y : j == 2 ? src[a][u].z : src[a][u].w;
+                    const float av = j == 0 ? ra[a].x : j == 1 ? ra[a].y : j == 2 ? ra[a].z : ra[a].w;
                     acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
                 }
             }
@@ -776,11 +818,18 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     // squared norms (chunk 1) are fetched while the tile is being multiplied.
     uint32_t sel_id[8];
     float sel_nrm[8];
-    auto sel_load_ids = [&](uint32_t tile) {
+    auto sel_load_ids = [&](uint32_t tile) { // raw (see load_ids_raw); sel_fix_ids() one stage later
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const uint32_t rr = tile + wrow + (uint32_t)((e >> 2) * 16 + fg * 4 + (e & 3));
-            sel_id[e] = rr < row_end ? (scan_ids ? scan_ids[rr] : rr + 1u) : 0u;
+            sel_id[e] = id_src[rr < id_last ? rr : id_last];
+        }
+    };
+    auto sel_fix_ids = [&](uint32_t tile) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t rr = tile + wrow + (uint32_t)((e >> 2) * 16 + fg * 4 + (e & 3));
+            sel_id[e] = rr < row_end ? (scan_ids ? sel_id[e] : rr + 1u) : 0u;
         }
     };
     auto sel_load_norms = [&]() {
@@ -790,6 +839,15 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
         }
     };
     auto select = [&]() {
+        if (FSS_DBG & 3u) {
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (FSS_DBG & 1u) {
+                kdb_lds_barrier();
+                kdb_lds_barrier();
+            }
+            return;
+        }
         if ((uint32_t)fi < nq) {
             const float t_k = tau[fi];
             const uint32_t t_id = tau_id[fi];
@@ -825,35 +883,57 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     };
 
     float4 bufA[2][FSS_CH], bufB[2][FSS_CH];
-    uint32_t tile = row_begin, ch = 0;
-    if (tile < row_end) {
-        load_ids(ld_id, tile);
+    if (row_begin < row_end) {
+        load_ids_raw(ld_id, row_begin);
+        ids_fix(ld_id, row_begin);
         issue(bufA, 0);
     }
-    // one pipeline stage: start the loads of the next (tile, chunk), multiply the current one
-    auto stage = [&](float4 (&cur)[2][FSS_CH], float4 (&nxt)[2][FSS_CH]) {
-        uint32_t ntile = tile, nchk = ch + 1;
-        if (nchk == nch) { nchk = 0; ntile = tile + FS_TR; }
-        if (ch == 0) {
-            sel_load_ids(tile);
-            if (scan_ids && tile + FS_TR < row_end) load_ids(ld_nx, tile + FS_TR);
+    // The pipeline, written out per tile so that the compiler can count the loads between an issue and its use (its s_waitcnt
+    // placement merges control-flow paths conservatively: a side load that MAY have been issued just now costs a vmcnt(0)):
+    //   stage 0      side loads (ids of the rows this lane selects from, ids of the next tile's rows), issue chunk 1, multiply 0
+    //   stage 1      ids fixed up, norms loaded, issue chunk 2 (or the next tile's chunk 0), multiply 1
+    //   stages 2..   in pairs; the tile's last stage issues the next tile's chunk 0 (past the stripe: row 0, multiplied by nobody)
+    // Every stage issues exactly 2 x FSS_CH row loads after its side loads, so the wait in front of the MFMAs is "all but the
+    // newest 16" everywhere.
+    uint32_t tile = row_begin;
+    auto issue_next = [&](float4 (&nxt)[2][FSS_CH], uint32_t c) { // after chunk c - 1 of this tile: chunk c, or the next tile's first
+        if (c == nch) {
+            ld_id[0] = ld_nx[0];
+            ld_id[1] = ld_nx[1];
+            ids_fix(ld_id, tile + FS_TR);
+            issue(nxt, 0);
+        } else {
+            issue(nxt, c);
         }
-        if (ch == 1) sel_load_norms();
-        if (ntile < row_end) {
-            if (nchk == 0) {
-                if (scan_ids) { ld_id[0] = ld_nx[0]; ld_id[1] = ld_nx[1]; }
-                else load_ids(ld_id, ntile);
-            }
-            issue(nxt, nchk);
-        }
-        multiply(cur, ch);
-        if (ch == nch - 1) select();
-        tile = ntile;
-        ch = nchk;
     };
-    while (tile < row_end) { // nch is even: the pair (A,B) always ends on a tile boundary or in its middle
-        stage(bufA, bufB);
-        stage(bufB, bufA);
+    // (sched_barrier: the compiler must not sink a stage's loads below its MFMAs to save registers -- that is the whole pipeline)
+#define FSS_PIN() __builtin_amdgcn_sched_barrier(0)
+    while (tile < row_end) { // nch is even: a tile starts in buffer A and ends in B
+        if (!(FSS_DBG & 8u)) sel_load_ids(tile);
+        load_ids_raw(ld_nx, tile + FS_TR);
+        issue(bufB, 1);
+        FSS_PIN();
+        multiply(bufA, 0);
+        FSS_PIN();
+        sel_fix_ids(tile);
+        if (!(FSS_DBG & 8u)) sel_load_norms();
+        issue_next(bufA, 2);
+        FSS_PIN();
+        multiply(bufB, 1);
+        FSS_PIN();
+        for (uint32_t c = 2; c < nch; c += 2) {
+            issue(bufB, c + 1);
+            FSS_PIN();
+            multiply(bufA, c);
+            FSS_PIN();
+            issue_next(bufA, c + 2);
+            FSS_PIN();
+            multiply(bufB, c + 1);
+            FSS_PIN();
+        }
+#undef FSS_PIN
+        select();
+        tile += FS_TR;
     }
 
     __syncthreads();
@@ -870,6 +950,17 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
             p.part_id[lb + i] = b_id[q * cap_s + i];
         }
         if (lane == 0) p.part_cnt[(size_t)stripe * p.n_qtiles * FS_TQ + qg] = c;
+    }
+}
+
+using fss_kernel_t = void (*)(KdbView, const float *, FsParams, uint32_t, uint32_t);
+template <int METRIC, int PREC>
+static fss_kernel_t fss_kernel_for(uint32_t ld) {
+    switch (fss_exact_cs<PREC>(ld)) {
+    case 8: return flat_scan_small_kernel<METRIC, PREC, 8>;
+    case 6: return flat_scan_small_kernel<METRIC, PREC, 6>;
+    case 4: return flat_scan_small_kernel<METRIC, PREC, 4>;
+    default: return flat_scan_small_kernel<METRIC, PREC, 0>;
     }
 }
 
@@ -1717,8 +1808,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // small batches take the HBM-bound streaming kernel (16 queries per workgroup, whole queries in LDS)
     const uint32_t n_q16 = (B + FSS_TQ - 1) / FSS_TQ;
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
-    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
-                         (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : v.precision == KDB_PREC_F16 ? fss_q_bytes<KDB_PREC_F16>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
+                         (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
     // which kernel (measured at 1M x 768, scripts/flat_probe.py): the streaming kernel re-reads the rows once per 16 queries
     // and wins up to 32 queries (0.47 ms at 32); the big-tile kernel (flat_scan_big.cuh: 256 queries x 256 rows per
     // workgroup; rows must be whole 128-byte slabs, >= 3 of them, in a 1- or 2-byte encoding: int8 rows, float16 rows, or the
@@ -1894,14 +1985,14 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         else if (v.metric == KDB_METRIC_COSINE) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
         else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
     } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
-        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, d_q, lds_r);
-        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p, d_q, lds_r);
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(v.ld), p, d_q, lds_r);
+        else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(v.ld), p, d_q, lds_r);
     } else if (small) {
-        if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
-        else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
-        else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
-        else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+        if (v.precision == KDB_PREC_I8) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_I8>(v.ld));
+        else if (v.precision == KDB_PREC_F16) rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F16>(v.ld));
+        else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld));
+        else rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld));
     } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
     else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
     else if (rank16 && v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>);
@@ -1958,8 +2049,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p2.rows16 = nullptr;
         p2.q16 = nullptr;
         if (small) {
-            if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, p2, d_fbq, lds_s);
-            else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, d_fbq, lds_s);
+            if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld), p2, d_fbq, lds_s);
+            else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld), p2, d_fbq, lds_s);
             if (rc) return rc;
             KDB_HIP(hipGetLastError());
         } else if (v.metric == KDB_METRIC_COSINE) {
@@ -2022,8 +2113,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     if (B == 0 || G == 0) return KDB_OK;
     const uint32_t kl = k + 16 > 144 ? 144 : k + 16; // finalists are re-scored in the order of the graph search
     const uint32_t cap_s = kl + FS_TR + FSS_SLACK;
-    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
-                         (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
+    const size_t lds_s = (v.precision == KDB_PREC_I8 ? fss_q_bytes<KDB_PREC_I8>(v.ld) : v.precision == KDB_PREC_F16 ? fss_q_bytes<KDB_PREC_F16>(v.ld) : fss_q_bytes<KDB_PREC_F32>(v.ld)) +
+                         (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
     if (lds_s > 150u * 1024u) {
         kdb_set_error("grouped flat scan: %u-d rows need %zu bytes of LDS per workgroup", v.dim, lds_s);
         return KDB_ERR_UNSUPPORTED;
@@ -2156,6 +2247,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.rs_count = d_rsc;
     p.rs_list = d_rsl;
     p.rmax = idx->max_norm2 > 0.f ? sqrtf(idx->max_norm2) : 1.0f;
+    { const char *e = getenv("KDB_FSS_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     p.g_tile = d_tiles;
     p.g_nscan = d_gn;
     p.g_base = d_gbase;
@@ -2171,13 +2263,13 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, lds_s); };
     if (rank16) {
         p.rows16 = idx->d_rows16;
-        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TQ * 12;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p, lds_r);
-        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p, lds_r);
-    } else if (v.precision == KDB_PREC_I8) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>);
-    else if (v.precision == KDB_PREC_F16) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F16>);
-    else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
-    else rc = launch_small(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(v.ld), p, lds_r);
+        else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(v.ld), p, lds_r);
+    } else if (v.precision == KDB_PREC_I8) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_I8>(v.ld));
+    else if (v.precision == KDB_PREC_F16) rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F16>(v.ld));
+    else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld));
+    else rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld));
     if (rc) return rc;
     KDB_HIP(hipGetLastError());
     KDB_HIP(hipEventRecord(idx->ev1, s));
@@ -2215,8 +2307,8 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
         p2.tile_flag = nullptr;
         p2.q_sel = d_qflag;
         p2.tile_sel = d_tflag;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>, p2, lds_s);
-        else rc = launch_small_on(flat_scan_small_kernel<KDB_METRIC_L2, KDB_PREC_F32>, p2, lds_s);
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld), p2, lds_s);
+        else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld), p2, lds_s);
         if (rc) return rc;
         KDB_HIP(hipGetLastError());
         if (v.metric == KDB_METRIC_COSINE) rc = launch_merge_on(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>, p2);

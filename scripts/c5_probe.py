@@ -1,6 +1,8 @@
-"""Config 5 as SURVEY 8d defines it (10M x 1536 cosine, 100 categories, 1024 queries each with its own random category):
-ONE kdb_flat_scan_groups_dev call per batch.  Sweeps the stripe count (KDB_GROUP_STRIPES) and prints wall / kernel time,
-gathered GB/s, and a signature of the answers (must not change).  Measurement script, not a test."""
+"""Config 5 (10M x 1536 cosine, 100 one-percent filters, 1024 queries grouped by filter): the grouped exact scan timed under the
+measurement knobs of flat_scan_small_kernel (KDB_FSS_CS: steps per register chunk, 0 = the generic instantiation; KDB_GROUP_STRIPES).
+The answers of every setting must be identical (a signature is printed).  With the measurement build (make -C kektordb_amd/csrc dbg;
+KEKTOR_HIP_LIB=kektordb_amd/lib/libkektor_hip_dbg.so) the KDB_FSS_DBG switches are walked instead: what each part of the kernel costs.
+    python scripts/c5_probe.py [rows]"""
 import hashlib
 import os
 import sys
@@ -10,65 +12,40 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import kektordb_amd as K
-from kektordb_amd.index import dense_bitset
+import bench  # noqa: E402
+import kektordb_amd as K  # noqa: E402
 
 
 def main():
-    n = int(os.environ.get("C5_ROWS", 10_000_000))
-    dim, k, B, ncat = 1536, 10, 1024, 100
-    dev = torch.device("cuda:0")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
-    g.manual_seed(41)
-    cent = torch.randn((4096, dim), device=dev, generator=g)
-    cat = torch.randint(0, ncat, (n,), device=dev, generator=g)
-    lab = torch.randint(0, 4096, (B,), device=dev, generator=g)
-    Q = cent[lab] + 0.3 * torch.randn((B, dim), device=dev, generator=g)
-    qcat = torch.randint(0, ncat, (B,), device=dev, generator=g).cpu().numpy()
-    order = np.argsort(qcat, kind="stable")
-    Qs = Q[torch.from_numpy(order).to(dev)].contiguous()
-    cats = np.unique(qcat)
-    offs = np.concatenate([[0], np.cumsum([int((qcat == c).sum()) for c in cats])]).astype(np.uint32)
-    t0 = time.time()
-    idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 200, capacity=n)
-    CH = 1_000_000
-    for s in range(0, n, CH):
-        m = min(CH, n - s)
-        l2 = torch.randint(0, 4096, (m,), device=dev, generator=g)
-        x = cent[l2] + 0.3 * torch.randn((m, dim), device=dev, generator=g)
-        x /= x.norm(dim=1, keepdim=True)
-        idx.upload_rows(x, s + 1)
-        del x
-    idx.set_count(n)
-    print(f"corpus {n}x{dim} in {time.time() - t0:.1f}s", flush=True)
-    allowed = {int(c): (torch.nonzero(cat == int(c)).flatten() + 1).cpu().numpy().astype(np.uint32) for c in cats}
-    total = int(sum(a.size for a in allowed.values()))
-    lists = np.stack([dense_bitset(allowed[int(c)], n) for c in cats])
-    d_lists = torch.from_numpy(lists.view(np.int64)).to(dev)
-    out = (torch.zeros((B, k), dtype=torch.int32, device=dev), torch.zeros((B, k), dtype=torch.float32, device=dev),
-           torch.zeros((B,), dtype=torch.int32, device=dev))
-    gbytes = total * dim * 2 / 1e9   # the half-precision ranking copy is what the scan gathers
-    print(f"{len(cats)} groups, {total} allowed rows in total = {gbytes:.2f} GB of halfs per batch", flush=True)
-    for st in os.environ.get("C5_STRIPES", "auto,8,9,16,24,32,48").split(","):
-        if st == "auto":
-            os.environ.pop("KDB_GROUP_STRIPES", None)
-        else:
-            os.environ["KDB_GROUP_STRIPES"] = st
+    g.manual_seed(3)
+    idx, Q, Qs, cats, offs, allowed, total, d_lists = bench.c5_case(K, dev, g, n, 1024)
+    o = bench.outs(1024, 10, dev)
+    alg = total * 1536 * 2 + 1024 * 1536 * 2 + 1024 * 10 * 8
+    tiles = sum((int(offs[j + 1] - offs[j]) + 15) // 16 for j in range(len(cats)))
+    print(f"{len(cats)} filters, {tiles} sixteen-query tiles, {total} allowed rows, {alg / 1e9:.2f} GB algorithmic")
+    knobs = ("KDB_FSS_CS", "KDB_FSS_DBG", "KDB_GROUP_STRIPES")
+    cases = [{}, {"KDB_FSS_CS": "6"}, {"KDB_FSS_CS": "0"}, {"KDB_GROUP_STRIPES": "16"}, {"KDB_GROUP_STRIPES": "32"}, {"KDB_GROUP_STRIPES": "48"}, {}]
+    if "dbg" in os.environ.get("KEKTOR_HIP_LIB", ""):  # the measurement build: parts of the kernel switched off (answers are wrong)
+        cases = [{"KDB_FSS_DBG": d} for d in ("0", "1", "2", "4", "6", "10", "14")]  # (8 alone would select with unloaded ids)
+    for case in cases:
+        for kn in knobs:
+            os.environ.pop(kn, None)
+        os.environ.update(case)
         for _ in range(2):
-            idx.flat_scan_groups_dev(Qs, k, offs, d_lists, *out, max_total_allowed=total)
+            idx.flat_scan_groups_dev(Qs, 10, offs, d_lists, *o, max_total_allowed=total)
         idx.sync()
-        reps = 5
         t0 = time.perf_counter()
-        for _ in range(reps):
-            idx.flat_scan_groups_dev(Qs, k, offs, d_lists, *out, max_total_allowed=total)
+        for _ in range(5):
+            idx.flat_scan_groups_dev(Qs, 10, offs, d_lists, *o, max_total_allowed=total)
         idx.sync()
-        wall = (time.perf_counter() - t0) / reps
-        ls = idx.launch_stats(reps)
-        kms = float(np.mean([c["kernel_ms"] for c in ls]))
-        exact_q, rescue_q = ls[-1]["n_hops"] & 0xffffffff, ls[-1]["n_hops"] >> 32
-        sig = hashlib.sha1(out[0].cpu().numpy().tobytes() + out[1].cpu().numpy().tobytes()).hexdigest()[:12]
-        print(f"stripes {st:>4}: wall {wall * 1e3:7.3f} ms ({B / wall / 1e3:6.1f} k QPS)  ranking kernel {kms:7.3f} ms = "
-              f"{gbytes / kms:6.2f} TB/s   exact-pass queries {exact_q}, rescued {rescue_q}   answers {sig}", flush=True)
+        wall = (time.perf_counter() - t0) / 5
+        kms = float(np.mean([x["kernel_ms"] for x in idx.launch_stats(5)]))
+        sig = hashlib.sha1(o[0].cpu().numpy().tobytes() + o[1].cpu().numpy().tobytes()).hexdigest()[:12]
+        print(f"{' '.join(f'{a}={b}' for a, b in case.items()) or 'defaults':<50}: kernel {kms:.3f} ms = {alg / kms / 1e6:.0f} GB/s ({alg / kms / 1e6 / 8000:.3f} of peak), "
+              f"call {wall * 1e3:.3f} ms, answers {sig}")
 
 
 if __name__ == "__main__":

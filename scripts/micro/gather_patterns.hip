@@ -1,0 +1,231 @@
+// The grouped exact scan's row phase (config 5: 100 filters of 1 % over 10M x 1536 halfs, 16-query tiles) in two lane -> address maps,
+// with the scan's own pipeline (two register buffers of 16 x 16 B per lane, the next chunk in flight while this one is multiplied
+// on v_mfma_f32_16x16x32_f16 against 16 queries in LDS) and WITHOUT its selection:
+//   strided    today's kernel: lane (fi, fg) loads 16 B at step*64 + fg*16 of row fi -- the MFMA A-fragment layout straight from
+//              HBM; a quarter-wave (16 lanes) touches 16 rows = 16 cache lines for 256 B;
+//   coalesced  lane (g, t) loads 16 B at piece*256 + t*16 of row 4j+g: a quarter-wave reads 256 contiguous bytes of ONE row (2
+//              lines); the fragments are formed by a trip through a wave-private 4 KB LDS staging area (ds_write_b128 in the load
+//              layout, XOR-swizzled; ds_read_b128 in the fragment layout).
+// Question: is the 0.74 of peak of the grouped scan (uniform-gather ceiling 0.84) the texture-addresser's line rate?
+//   hipcc --offload-arch=gfx950 -O3 scripts/micro/gather_patterns.hip -o /tmp/gather_patterns && /tmp/gather_patterns
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#include <type_traits>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr uint32_t ROWB = 3072, QS = ROWB + 16, CH = 8; // bytes per row; query stride in LDS; 64-byte steps per register chunk
+constexpr uint32_t NCH = ROWB / (64 * CH);              // 6 chunks per row
+
+__global__ void fill_kernel(uint4 *p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u;
+        p[i] = make_uint4(x & 0x3bff3bffu, (x >> 3) & 0x3bff3bffu, (x >> 5) & 0x3bff3bffu, (x >> 7) & 0x3bff3bffu); // finite halfs
+    }
+}
+
+// MODE 0 strided, 1 coalesced + LDS staging.  WAVES waves per workgroup, 32 rows of a tile each.
+template <int MODE, int WAVES, int SEL>
+__global__ void __launch_bounds__(WAVES * 64)
+scan_kernel(const unsigned char *__restrict__ rows, const uint32_t *__restrict__ ids, uint32_t rows_per_group, uint32_t n_stripes, float *out,
+            const uint32_t *__restrict__ bounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *qs8 = smem;                              // [16][QS]
+    unsigned char *stage = smem + 16 * QS;                  // [WAVES][4096]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t fi = lane & 15u, fg = lane >> 4;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, local = bid >> 3;
+    const uint32_t n_groups = gridDim.x / n_stripes;
+    const uint32_t stripe = (local / n_groups) * 8u + xcd, grp = local % n_groups;
+    if (stripe >= n_stripes) return;
+    const uint32_t per = (rows_per_group + n_stripes - 1) / n_stripes;
+    // bounds: stripes cut by ROW ID range (stripe s of every group = its rows inside the s-th part of the table) instead of by list position
+    const uint32_t row_begin = bounds ? bounds[grp * (n_stripes + 1) + stripe] : stripe * per;
+    const uint32_t row_end = bounds ? bounds[grp * (n_stripes + 1) + stripe + 1] : min(row_begin + per, rows_per_group);
+    const uint32_t *scan_ids = ids + (size_t)grp * rows_per_group;
+    for (uint32_t i = tid; i < 16 * QS / 16; i += WAVES * 64) reinterpret_cast<uint4 *>(qs8)[i] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    __syncthreads();
+    constexpr uint32_t TR = WAVES * 32;
+    const uint32_t wrow = wave * 32u;
+    unsigned char *st = stage + wave * 4096u;
+
+    uint32_t ld_id[8], ld_nx[8]; // MODE 0 uses [0..1] (rows a*16 + fi), MODE 1 all 8 (rows 4j + g)
+    auto load_ids = [&](uint32_t (&dst)[8], uint32_t tile) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const uint32_t rr = tile + wrow + (uint32_t)a * 16u + fi;
+                dst[a] = rr < row_end ? scan_ids[rr] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t rr = tile + wrow + (uint32_t)j * 4u + fg; // g = lane >> 4
+                dst[j] = rr < row_end ? scan_ids[rr] : 0u;
+            }
+        }
+    };
+    // chunk ch = bytes [ch*512, +512) of every row: 16 loads per lane either way
+    auto issue = [&](f32x4 (&dst)[16], uint32_t ch) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    dst[a * 8 + u] = *reinterpret_cast<const f32x4 *>(rows + (size_t)ld_id[a] * ROWB + ch * 512u + (uint32_t)u * 64u + fg * 16u);
+        } else {
+            // lane (g, t = fi) of load (j, h): row 4j+g, 16-byte piece t of the 256-byte half h -- stored swizzled below
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    dst[j * 2 + h] = *reinterpret_cast<const f32x4 *>(rows + (size_t)ld_id[j] * ROWB + ch * 512u + (uint32_t)h * 256u + fi * 16u);
+        }
+    };
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // one 16-row group a, one 256-byte half h: 4 KB through the staging area ([16 rows][16 slots of 16 B]; piece p of row r in slot p ^ r)
+    auto phase = [&](auto AH, f32x4 (&src)[16], uint32_t ch) {
+        constexpr int a = decltype(AH)::value >> 1, h = decltype(AH)::value & 1;
+        {
+            const uint32_t r0 = fg, r1 = 4u + fg, r2 = 8u + fg, r3 = 12u + fg; // this lane holds rows 4jj + g of the group, piece t
+            *reinterpret_cast<f32x4 *>(st + r0 * 256u + ((fi ^ r0) & 15u) * 16u) = src[(a * 4 + 0) * 2 + h];
+            *reinterpret_cast<f32x4 *>(st + r1 * 256u + ((fi ^ r1) & 15u) * 16u) = src[(a * 4 + 1) * 2 + h];
+            *reinterpret_cast<f32x4 *>(st + r2 * 256u + ((fi ^ r2) & 15u) * 16u) = src[(a * 4 + 2) * 2 + h];
+            *reinterpret_cast<f32x4 *>(st + r3 * 256u + ((fi ^ r3) & 15u) * 16u) = src[(a * 4 + 3) * 2 + h];
+        }
+        f32x4 fr[4], fq[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            fr[s] = *reinterpret_cast<const f32x4 *>(st + fi * 256u + ((((uint32_t)s * 4u + fg) ^ fi) & 15u) * 16u);
+            fq[s] = *reinterpret_cast<const f32x4 *>(qs8 + fi * QS + ch * 512u + (uint32_t)h * 256u + (uint32_t)s * 64u + fg * 16u);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[s]), __builtin_bit_cast(f16x8, fq[s]), acc[a], 0, 0, 0);
+    };
+    auto multiply = [&](f32x4 (&src)[16], uint32_t ch) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const f32x4 q16 = *reinterpret_cast<const f32x4 *>(qs8 + fi * QS + ch * 512u + (uint32_t)u * 64u + fg * 16u);
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[a * 8 + u]), __builtin_bit_cast(f16x8, q16), acc[a], 0, 0, 0);
+            }
+        } else {
+            phase(std::integral_constant<int, 0>{}, src, ch);
+            phase(std::integral_constant<int, 1>{}, src, ch);
+            phase(std::integral_constant<int, 2>{}, src, ch);
+            phase(std::integral_constant<int, 3>{}, src, ch);
+        }
+    };
+    float sink = 0.f;
+    f32x4 bufA[16], bufB[16];
+    uint32_t tile = row_begin, ch = 0;
+    if (tile < row_end) {
+        load_ids(ld_id, tile);
+        issue(bufA, 0);
+    }
+    auto stage_fn = [&](f32x4 (&cur)[16], f32x4 (&nxt)[16]) {
+        uint32_t ntile = tile, nchk = ch + 1;
+        if (nchk == NCH) { nchk = 0; ntile = tile + TR; }
+        if (ch == 0 && tile + TR < row_end) load_ids(ld_nx, tile + TR);
+        if (ntile < row_end) {
+            if (nchk == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) ld_id[j] = ld_nx[j];
+            }
+            issue(nxt, nchk);
+        }
+        multiply(cur, ch);
+        if (ch == NCH - 1) { // what the selection would consume
+            sink += acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[1][0] + acc[1][1] + acc[1][2] + acc[1][3];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (SEL) { // the selection's two workgroup barriers per tile (survivors appended | buffers compacted)
+                __syncthreads();
+                if (sink == 77.f) qs8[tid] = 1;
+                __syncthreads();
+            }
+        }
+        tile = ntile;
+        ch = nchk;
+    };
+    while (tile < row_end) {
+        stage_fn(bufA, bufB);
+        stage_fn(bufB, bufA);
+    }
+    if (sink == 123.456f) out[bid] = sink;
+}
+
+template <int MODE, int WAVES, int SEL>
+static void run(const char *name, const unsigned char *d_rows, const uint32_t *d_ids, float *d_out, uint32_t n_groups, uint32_t rows_per_group, uint32_t n_stripes, bool lists,
+                const uint32_t *d_bounds = nullptr) {
+    // lists: reserve what the scan's per-query survivor buffers take (16 x (kl 26 + a tile of rows + 64) x 8 bytes), so that the
+    // occupancy is the real kernel's
+    const size_t lds = 16 * QS + (MODE ? WAVES * 4096 : 0) + (lists ? 16 * (26 + WAVES * 32 + 64) * 8 : 0);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_kernel<MODE, WAVES, SEL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<MODE, WAVES, SEL>, WAVES * 64, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    const uint32_t grid = n_groups * ((n_stripes + 7u) / 8u) * 8u;
+    for (int it = 0; it < 4; it++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((scan_kernel<MODE, WAVES, SEL>), dim3(grid), dim3(WAVES * 64), lds, 0, d_rows, d_ids, rows_per_group, n_stripes, d_out, d_bounds);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    printf("%-28s %s %s %d waves/wg, %6zu B LDS, %d wg/CU, %2u stripes: %.3f ms  %.0f GB/s\n", name, d_bounds ? "stripes by id range" : "stripes by position", SEL ? "2 barriers/tile" : "no barriers    ", WAVES, lds, occ, n_stripes, best, (double)n_groups * rows_per_group * ROWB / best / 1e6);
+}
+
+int main(int argc, char **argv) {
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 10000000u, n_groups = 105, rows_per_group = n / 100;
+    unsigned char *d_rows; float *d_out; uint32_t *d_ids;
+    CK(hipMalloc(&d_rows, (size_t)n * ROWB));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint4 *>(d_rows), (size_t)n * ROWB / 16);
+    std::vector<uint32_t> ids((size_t)n_groups * rows_per_group);
+    uint64_t s = 88172645463325252ull;
+    const int law = argc > 2 ? atoi(argv[2]) : 1;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        uint32_t *gi = ids.data() + (size_t)g * rows_per_group;
+        for (uint32_t i = 0; i < rows_per_group; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            // law 0: ascending, one row of every 100 (the i-th row of EVERY group inside the same 100-row window: workgroups that
+            // advance together share DRAM pages and TLB entries); law 1: a sorted uniform sample (a real 1 % category: the i-th rows
+            // of two groups are ~ sqrt(i) * 100 rows apart)
+            gi[i] = law == 0 ? i * 100u + (uint32_t)(s % 100u) : (uint32_t)(s % n);
+        }
+        if (law) std::sort(gi, gi + rows_per_group);
+    }
+    printf("id law %d (%s)\n", law, law ? "sorted uniform sample" : "jittered lattice");
+    CK(hipMalloc(&d_ids, ids.size() * 4)); CK(hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_out, 1 << 20));
+    CK(hipDeviceSynchronize());
+    for (uint32_t st : {24u, 48u}) {
+        std::vector<uint32_t> bounds((size_t)n_groups * (st + 1));
+        for (uint32_t g = 0; g < n_groups; g++) {
+            const uint32_t *gi = ids.data() + (size_t)g * rows_per_group;
+            for (uint32_t q = 0; q <= st; q++)
+                bounds[(size_t)g * (st + 1) + q] = (uint32_t)(std::lower_bound(gi, gi + rows_per_group, (uint32_t)((uint64_t)n * q / st)) - gi);
+        }
+        uint32_t *d_bounds;
+        CK(hipMalloc(&d_bounds, bounds.size() * 4)); CK(hipMemcpy(d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
+        run<0, 4, 0>("strided (today)", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true);
+        run<0, 4, 1>("strided (today)", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true);
+        run<0, 4, 0>("strided (today)", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true, d_bounds);
+        run<0, 4, 1>("strided (today)", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true, d_bounds);
+        run<1, 8, 1>("coalesced + LDS staging", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true);
+        run<1, 8, 1>("coalesced + LDS staging", d_rows, d_ids, d_out, n_groups, rows_per_group, st, true, d_bounds);
+    }
+    return 0;
+}
