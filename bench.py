@@ -996,6 +996,13 @@ def big_configs_leg(K, dev, rows=10_000_000, nq=1024):
     inside = all(bool(np.isin(got[offs[j]:offs[j + 1]], allowed[int(c)]).all()) for j, c in enumerate(cats))
     alg = total * dim * 2 + nq * dim * 2 + nq * k * 8   # the scan ranks on the half-precision row copy: 2 bytes per element
     gbs = alg / (kms * 1e-3) / 1e9
+    # what THIS device delivers on THIS table for the same access pattern with nothing else running (kdb_probe_gather on the
+    # half-precision copy: 10M random whole rows; the filters partition the table, so no row is read twice and the 256 MB
+    # memory-side cache has nothing to give), and what the kernel actually pulls: a filter with more than 16 queries is scanned once
+    # per 16-query tile
+    ceil5 = idx.probe_gather(10_000_000, shadow=True)
+    tiles = [(int(offs[j + 1] - offs[j]) + 15) // 16 for j in range(len(cats))]
+    issued = sum(t * allowed[int(c)].size for t, c in zip(tiles, cats)) * dim * 2
     out["configs[4]"] = {
         "workload": f"{n}x{dim} cosine k={k}, 1 % category filter, {nq} queries each with its OWN random category ({len(cats)} "
                     f"filters, {total} allowed rows in total): one grouped exact scan (kdb_flat_scan_groups_dev)",
@@ -1003,7 +1010,10 @@ def big_configs_leg(K, dev, rows=10_000_000, nq=1024):
         "roofline": {"kernel": "flat_scan_small_kernel<cosine,f16-ranked> (gathered rows)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kms, 3), "algorithmic_bytes_per_launch": int(alg),
-                     "bytes_definition": "sum over the filters of allowed rows x dim x 2 (half-precision ranking copy) + B x dim x 2 + B x k x 8"},
+                     "bytes_definition": "sum over the filters of allowed rows x dim x 2 (half-precision ranking copy) + B x dim x 2 + B x k x 8",
+                     "measured_gather_ceiling_gbps": round(ceil5, 1), "frac_of_measured": round(gbs / ceil5, 4),
+                     "sixteen_query_tiles": int(sum(tiles)), "row_bytes_issued_per_launch": int(issued),
+                     "issued_rate_frac_of_measured": round(issued / (kms * 1e-3) / 1e9 / ceil5, 4)},
     }
     # (b) one filter shared by the whole batch: the big-tile kernel over gathered rows
     ab = torch.from_numpy(dense_bitset(allowed[int(cats[0])], n).view(np.int64)).to(dev)

@@ -607,8 +607,9 @@ __host__ __device__ inline size_t fss_q_bytes(uint32_t ld) {
 
 // Steps per register chunk.  When the rows cut into an even number of whole chunks of whole 64-byte (RAW) / 16-float steps the
 // kernel is instantiated with CS as a compile-time constant: no clamped addresses, immediate offsets, <= 244 registers (two
-// workgroups per CU).  8 is preferred (2 x 16 row loads per lane in flight), then 6, then 4.  0: the generic instantiation (any
-// row length; 289 registers, one workgroup per CU).  KDB_FSS_CS forces a feasible value (measurements).
+// workgroups per CU).  6 is preferred (2 x 12 row loads per lane in flight; 1 % ahead of 8 on the gathered scan of config 5, equal
+// on streamed rows), then 8, then 4.  0: the generic instantiation (any row length; 289 registers, one workgroup per CU).
+// KDB_FSS_CS forces a feasible value (measurements).
 template <int PREC>
 __host__ inline uint32_t fss_exact_cs(uint32_t ld) {
     constexpr bool RAW = PREC == KDB_PREC_I8 || PREC == FS_PREC_F32R || PREC == KDB_PREC_F16;
@@ -621,7 +622,7 @@ __host__ inline uint32_t fss_exact_cs(uint32_t ld) {
         if (c == 0u) return 0u;
         if ((c == 8u || c == 6u || c == 4u) && nsteps % (2u * c) == 0u) return c;
     }
-    for (uint32_t c : {8u, 6u, 4u})
+    for (uint32_t c : {6u, 8u, 4u})
         if (nsteps % (2u * c) == 0u) return c;
     return 0u;
 }

@@ -26,6 +26,11 @@ def main():
     alg = total * 1536 * 2 + 1024 * 1536 * 2 + 1024 * 10 * 8
     tiles = sum((int(offs[j + 1] - offs[j]) + 15) // 16 for j in range(len(cats)))
     print(f"{len(cats)} filters, {tiles} sixteen-query tiles, {total} allowed rows, {alg / 1e9:.2f} GB algorithmic")
+    idx.flat_scan_groups_dev(Qs, 10, offs, d_lists, *o, max_total_allowed=total)  # (makes the half-precision ranking copy)
+    idx.sync()
+    print(f"ceilings on THIS table (10M x 3072-byte half-precision rows, every row read about once -- nothing for the 256 MB memory-side "
+          f"cache to reuse): uniform random whole-row gather {idx.probe_gather(10_000_000, shadow=True):.0f} GB/s, "
+          f"one coalesced pass {idx.probe_stream(shadow=True):.0f} GB/s")
     knobs = ("KDB_FSS_CS", "KDB_FSS_DBG", "KDB_GROUP_STRIPES")
     cases = [{}, {"KDB_FSS_CS": "6"}, {"KDB_FSS_CS": "0"}, {"KDB_GROUP_STRIPES": "16"}, {"KDB_GROUP_STRIPES": "32"}, {"KDB_GROUP_STRIPES": "48"}, {}]
     if "dbg" in os.environ.get("KEKTOR_HIP_LIB", ""):  # the measurement build: parts of the kernel switched off (answers are wrong)

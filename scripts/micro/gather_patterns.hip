@@ -189,25 +189,51 @@ static void run(const char *name, const unsigned char *d_rows, const uint32_t *d
 }
 
 int main(int argc, char **argv) {
-    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 10000000u, n_groups = 105, rows_per_group = n / 100;
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 10000000u, n_groups = argc > 3 ? (uint32_t)atoi(argv[3]) : 105, rows_per_group = n / 100;
     unsigned char *d_rows; float *d_out; uint32_t *d_ids;
+    // ballast (GB) allocated and touched BEFORE the table, in 61 GB pieces like the float32 rows + the caller's copy of them in
+    // the real process: does the table's placement (page fragments) change with what was allocated before it?
+    const int ballast_gb = argc > 4 ? atoi(argv[4]) : 0;
+    for (int left = ballast_gb; left > 0; left -= 61) {
+        void *b;
+        const size_t bytes = (size_t)(left < 61 ? left : 61) << 30;
+        CK(hipMalloc(&b, bytes));
+        CK(hipMemset(b, 1, bytes));
+    }
+    if (ballast_gb) printf("%d GB of ballast allocated first\n", ballast_gb);
     CK(hipMalloc(&d_rows, (size_t)n * ROWB));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint4 *>(d_rows), (size_t)n * ROWB / 16);
     std::vector<uint32_t> ids((size_t)n_groups * rows_per_group);
     uint64_t s = 88172645463325252ull;
-    const int law = argc > 2 ? atoi(argv[2]) : 1;
+    const int law = argc > 2 ? atoi(argv[2]) : 2;
+    // law 0: ascending, one row of every 100 (the i-th row of EVERY group inside the same 100-row window: workgroups that advance
+    //        together share DRAM pages, TLB entries and lines of the memory-side cache);
+    // law 1: every group an independent sorted uniform sample -- groups OVERLAP (a third of the rows is read by two or more groups
+    //        within a few microseconds of each other: hits in the 256 MB memory-side cache that a real filter set does not have);
+    // law 2: a random category per row, group g = the rows of category g -- disjoint lists that cover the table exactly once: what
+    //        "every query its own 1 % category" means (config 5).  Groups beyond 100 repeat a category (a second 16-query tile).
+    if (law == 2) {
+        std::vector<uint32_t> fill(100, 0);
+        std::vector<std::vector<uint32_t>> cat(100);
+        for (uint32_t r = 0; r < n; r++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            cat[s % 100u].push_back(r);
+        }
+        for (uint32_t g = 0; g < n_groups; g++) {
+            const std::vector<uint32_t> &c = cat[g % 100u];
+            uint32_t *gi = ids.data() + (size_t)g * rows_per_group;
+            for (uint32_t i = 0; i < rows_per_group; i++) gi[i] = c[i < c.size() ? i : c.size() - 1];
+        }
+    } else
     for (uint32_t g = 0; g < n_groups; g++) {
         uint32_t *gi = ids.data() + (size_t)g * rows_per_group;
         for (uint32_t i = 0; i < rows_per_group; i++) {
             s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-            // law 0: ascending, one row of every 100 (the i-th row of EVERY group inside the same 100-row window: workgroups that
-            // advance together share DRAM pages and TLB entries); law 1: a sorted uniform sample (a real 1 % category: the i-th rows
-            // of two groups are ~ sqrt(i) * 100 rows apart)
             gi[i] = law == 0 ? i * 100u + (uint32_t)(s % 100u) : (uint32_t)(s % n);
         }
         if (law) std::sort(gi, gi + rows_per_group);
     }
-    printf("id law %d (%s)\n", law, law ? "sorted uniform sample" : "jittered lattice");
+    printf("id law %d (%s)\n", law, law == 2 ? "a random category per row: disjoint lists" : law ? "independent sorted uniform samples (overlapping)" : "jittered lattice");
     CK(hipMalloc(&d_ids, ids.size() * 4)); CK(hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_out, 1 << 20));
     CK(hipDeviceSynchronize());
