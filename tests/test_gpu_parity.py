@@ -286,11 +286,53 @@ def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
     assert np.array_equal(ids2, ids3) and np.array_equal(cnt2, cnt3)
 
 
+@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 100])
+@pytest.mark.parametrize("prec,metric", [(0, 1), (0, 0), (1, 0), (2, 1)])
+def test_small_scan_chunk_instantiations(oracle, hip, prec, metric, dim):
+    """B <= 32 takes flat_scan_small_kernel<METRIC, PREC, CS>: the steps per register chunk are a template constant chosen from
+    the row length (flat_scan.hip fss_exact_cs: 6, 8 or 4 whole 64-byte / 16-float steps; 0 = the generic instantiation with
+    clamped addresses).  Every instantiation, every precision (float16 rows rank on the f16 MFMA like the half-precision copy of
+    float32 rows), with deleted rows and under a filter: ids and distance bits of the oracle's scan."""
+    O = oracle
+    n, k = 2500, 10
+    X = make_corpus(n, dim, "normal", seed=300 + dim)
+    deleted = list(range(7, n, 60))
+    if prec == O.I8:
+        orc = O.OracleIndex(dim, 1, O.I8, 16, 20, seed=7)
+        orc.set_absmax(float(np.quantile(np.abs(X), 0.999)))
+        orc.add_many(X)
+        for d in deleted:
+            orc.mark_deleted(int(d))
+        idx = hip.HipIndex(dim, 1, O.I8, 16, 20, capacity=n + 8)
+        idx.upload_rows(orc.rows()[1:], 1)
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+        idx.upload_graph_obj(orc.export_graph())
+    else:
+        orc, idx = build_pair(O, hip, X, metric, precision=prec, efc=20, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    from kektordb_amd.index import dense_bitset
+    rng = np.random.default_rng(dim)
+    allowed = np.nonzero(rng.random(n + 1) < 0.2)[0]
+    ab = dense_bitset(allowed[allowed >= 1], n)
+    for B, allow in ((3, None), (20, None), (5, ab)):
+        Q = make_corpus(B, dim, "normal", seed=500 + B)
+        kw = {"dist64": True} if prec == O.I8 else {}
+        ids, dist, cnt = idx.flat_scan_batch(Q, k, allow_bits=allow, **kw)
+        for b in range(B):
+            oi, od = orc.flat_scan(Q[b], k, allow=allow)
+            c = int(cnt[b])
+            assert c == len(oi)
+            assert np.array_equal(ids[b, :c], oi), (B, b)
+            got = dist[b, :c] if prec == O.I8 else raw_to_score(idx, dist[b, :c])
+            assert np.array_equal(np.asarray(got, dtype=np.float64), od), (B, b)
+            assert not (set(ids[b, :c].tolist()) & set(deleted))
+
+
 @pytest.mark.parametrize("B", [40, 150])
 def test_flat_scan_f16(oracle, hip, B):
-    """float16 rows (euclidean only, hnsw_index.go:210-213): MFMA ranking (small batches: rows widened onto the f32
-    MFMA; large batches: the f16 MFMA on the raw halfs), exact re-score in the f16 wave order -> bit-exact against
-    the oracle"""
+    """float16 rows (euclidean only, hnsw_index.go:210-213): ranking on the f16 MFMA over the raw halfs (products exact in
+    f32, the MFMA's summation order), exact re-score in the f16 wave order -> bit-exact against the oracle"""
     O = oracle
     n, dim, k = 4000, 96, 10
     X = make_corpus(n, dim, "normal", seed=71)
