@@ -1813,14 +1813,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
                          (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
     // which kernel (measured at 1M x 768, scripts/flat_probe.py): the streaming kernel re-reads the rows once per 16 queries
     // and wins up to 32 queries (0.47 ms at 32); the big-tile kernel (flat_scan_big.cuh: 256 queries x 256 rows per
-    // workgroup; rows must be whole 128-byte slabs, >= 3 of them, in a 1- or 2-byte encoding: int8 rows, float16 rows, or the
+    // workgroup; rows must be whole 128-byte slabs -- any number: 64-d halfs are ONE slab, 8192 queries 11.4 -> 2.9 ms against the
+    // 128 x 128 tile kernel -- in a 1- or 2-byte encoding: int8 rows, float16 rows, or the
     // half-precision ranking copy of float32 rows) wins from 65 queries on (128 queries 0.92 vs 1.20 ms for the 128 x 128
     // tile kernel, 256 queries 1.10 vs 1.81 ms; k=100: 1.30 vs 3.66 ms) and between 33 and 64 queries when the lists are
     // short (k=10, 48 queries: 0.69 vs 1.04 ms; k=100, 64 queries: 1.12 vs 0.94 ms)
     const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : v.ld * 2u;
     const bool rank16_ok = v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) && idx->max_norm2 > 0.f &&
                            idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
-    const bool big_ok = B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u && rowb >= 3u * FB_SLAB &&
+    const bool big_ok = B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u &&
                         (v.precision == KDB_PREC_I8 || v.precision == KDB_PREC_F16 || (rank16_ok && idx->d_rows16 != nullptr));
     const bool small = B <= (uint32_t)kdb_flat_small_max() && lds_s <= 150u * 1024u && !(big_ok && B > 32u && kl <= 48u);
     // float32 cosine, large batches: rank on the f16 MFMA inside a rigorous error band, settle the rest exactly

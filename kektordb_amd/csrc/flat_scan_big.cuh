@@ -215,6 +215,13 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             n_id = r < row_end ? (p.scan_ids ? p.scan_ids[r] : r + 1u) : 0u;
             if (NEED_NORM) n_nrm = v.norms[n_id];
         }
+        if (nslab == 1u && has_next) { // one-slab rows: this tile's only slab step is the one that requests the next tile's rows
+            if (tid < FB_T) {          // (the other parity's ids were last read before the barrier that closed the previous selection)
+                sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
+                if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int ab = 0; ab < 4; ab++)
 #pragma unroll

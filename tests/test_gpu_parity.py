@@ -329,6 +329,38 @@ def test_small_scan_chunk_instantiations(oracle, hip, prec, metric, dim):
             assert not (set(ids[b, :c].tolist()) & set(deleted))
 
 
+@pytest.mark.parametrize("dim,prec,metric", [(64, 0, 1), (64, 0, 0), (64, 1, 0), (128, 2, 1), (128, 0, 0), (128, 1, 0), (256, 2, 1)])
+def test_big_tile_kernel_on_one_and_two_slab_rows(oracle, hip, dim, prec, metric):
+    """rows of ONE or TWO 128-byte slabs (64 / 128 halfs, 128 / 256 int8 components) take the 256 x 256 tile kernel like longer
+    rows do (round 4; before, three slabs were asked for and these shapes ran on the 128 x 128 tile kernel, 4 x slower): the
+    one-slab case stores the next tile's row ids before its only slab step requests those rows"""
+    O = oracle
+    n, k, B = 6000, 10, 300
+    X = make_corpus(n, dim, "normal", seed=41)
+    orc = O.OracleIndex(dim, metric, prec, 16, 20, seed=7)
+    if prec == O.I8:
+        orc.set_absmax(float(np.quantile(np.abs(X), 0.999)))
+    orc.add_many(X)
+    for d in range(11, n, 70):
+        orc.mark_deleted(d)
+    idx = hip.HipIndex(dim, metric, prec, 16, 20, capacity=n + 8)
+    idx.upload_rows(orc.rows()[1:], 1)
+    if prec == O.I8:
+        idx.upload_norms(orc.norms()[1:], 1)
+        idx.set_quantizer(orc.absmax)
+    idx.upload_graph_obj(orc.export_graph())
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(B, dim, "normal", seed=42)
+    kw = {"dist64": True} if prec == O.I8 else {}
+    ids, dist, cnt = idx.flat_scan_batch(Q, k, **kw)
+    for b in range(B):
+        oi, od = orc.flat_scan(Q[b], k)
+        assert int(cnt[b]) == len(oi)
+        assert np.array_equal(ids[b], oi), b
+        got = dist[b] if prec == O.I8 else raw_to_score(idx, dist[b])
+        assert np.array_equal(np.asarray(got, dtype=np.float64), od), b
+
+
 @pytest.mark.parametrize("B", [40, 150])
 def test_flat_scan_f16(oracle, hip, B):
     """float16 rows (euclidean only, hnsw_index.go:210-213): ranking on the f16 MFMA over the raw halfs (products exact in
