@@ -165,9 +165,15 @@ def main():
     ap.add_argument("--ref-graph", action="store_true",
                     help="side leg: the headline corpus linked by kdb_index_add_batch (the reference's own batch linking, 5000 nodes per "
                          "call as Compress re-inserts them) instead of the fast builder: ef needed for the recall bar, and QPS there")
+    ap.add_argument("--shapes", action="store_true",
+                    help="side leg only: the reference's published benchmark shapes (GloVe-100/200/300, SIFT-1M) on synthetic rows")
     ap.add_argument("--preset", default="", choices=["", "config4"],
                     help="config4 = BASELINE configs[3]: 12.5M x 768 cosine rows PER RANK (100M over 8 GPUs), clustered law (ii), 8192 queries")
     a = ap.parse_args()
+    if a.shapes:  # side leg on its own: the reference's published benchmark shapes
+        import kektordb_amd as K
+        print(json.dumps(reference_shapes_leg(K, torch.device("cuda", 0))), flush=True)
+        return
     if a.inner_c5:  # under rocprofv3 --pmc: the grouped exact scan of BASELINE configs[4] at full size, three launches
         import kektordb_amd as K
         dev = torch.device("cuda", 0)
@@ -418,6 +424,7 @@ def main():
                          ("micro_batcher", lambda: micro_batcher_leg(idx, Q, k, ef)),
                          ("flat_scan_leg", lambda: flat_leg(idx, Q, k, n, dim, a.flat_batch, dev)),
                          ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev)),
+                         ("reference_benchmark_shapes", lambda: reference_shapes_leg(K, dev)),
                          ("baseline_configs_2_and_4", lambda: big_configs_leg(K, dev))):
             try:
                 res[name] = fn()
@@ -902,6 +909,72 @@ def iid_leg(K, n, dim, k, a, dev):
                                 "qps": round(B / t, 1)}
     idx.Close()
     return res
+
+
+def reference_shapes_leg(K, dev, k=10, nq=8192):
+    """The reference's OWN published benchmarks (GloVe-100 / -200 / -300 cosine, SIFT-1M L2; M / efConstruction /
+    efSearch as published) on synthetic rows of the same shape -- there is no network for the datasets: clustered rows (law ii;
+    SIFT-like rows are left unnormalised, L2).  Per shape: build time on the GPU, recall@10 against the exact scan of the same
+    index, QPS of `nq` resident queries per call, kernel time.  Side leg; the published figures (real data, an i5-12500) ride
+    along for orientation, never as `vs_baseline`."""
+    shapes = [("GloVe-100d 400k cosine", 400_000, 100, K.COSINE, 16, 200, 100, "0.9664 / 1073 QPS / build 102.9 s"),
+              ("GloVe-100d 400k cosine", 400_000, 100, K.COSINE, 16, 200, 20, "0.8753 / 1563 QPS"),
+              ("GloVe-100d 400k cosine", 400_000, 100, K.COSINE, 32, 400, 200, "0.9977 / 603 QPS"),
+              ("GloVe-200d 200k cosine", 200_000, 200, K.COSINE, 16, 200, 100, "0.9780 / 701 QPS / build 96.2 s"),
+              ("GloVe-300d 200k cosine", 200_000, 300, K.COSINE, 16, 200, 100, "0.9569 / 586 QPS / build 130.2 s"),
+              ("SIFT-1M 128d L2", 1_000_000, 128, K.L2, 16, 200, 100, "0.9906 / 881 QPS / build 481.4 s")]
+    out = []
+    built = {}
+    for name, n, dim, metric, m, efc, efs, pub in shapes:
+        key = (n, dim, metric, m, efc)
+        if key not in built:
+            for old in list(built.values()):  # one index at a time
+                old[0].Close()
+            built.clear()
+            g = torch.Generator(device=dev)
+            g.manual_seed(77 + dim)
+            cent = torch.randn((4096, dim), device=dev, generator=g)
+            lab = torch.randint(0, 4096, (n,), device=dev, generator=g)
+            X = cent[lab] + 0.3 * torch.randn((n, dim), device=dev, generator=g)
+            labq = torch.randint(0, 4096, (nq,), device=dev, generator=g)
+            Q = cent[labq] + 0.3 * torch.randn((nq, dim), device=dev, generator=g)
+            if metric == K.COSINE:
+                X /= X.norm(dim=1, keepdim=True)
+                Q /= Q.norm(dim=1, keepdim=True)
+            idx = K.HipIndex(dim, metric, K.F32, m, efc, capacity=n, device_id=dev.index or 0)
+            idx.upload_rows(X.contiguous(), 1)
+            del X
+            t0 = time.time()
+            idx.build(n, batch=16384, ef_construction=efc, seed=5)
+            tb = time.time() - t0
+            gt_o = outs(nq, k, dev)
+            idx.flat_scan_batch_dev(Q.contiguous(), k, *gt_o)
+            idx.sync()
+            built[key] = (idx, Q.contiguous(), gt_o[0].cpu().numpy().view(np.uint32), tb)
+        idx, Q, gt, tb = built[key]
+        o = outs(nq, k, dev)
+        idx.search_batch_dev(Q, k, efs, *o)
+        idx.sync()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx.search_batch_dev(Q, k, efs, *o)
+        idx.sync()
+        wall = (time.perf_counter() - t0) / reps
+        st = idx.launch_stats(reps)
+        kms = float(np.mean([c["kernel_ms"] for c in st]))
+        nd = float(np.mean([c["n_dist"] for c in st])) / nq
+        nh = float(np.mean([c["n_hops"] for c in st])) / nq
+        algb = nq * (nd * dim * 4 + nh * 2 * m * 4 + nd * 4)
+        out.append({"shape": f"{name}, M={m} efC={efc} efS={efs}", "build_s": round(tb, 2),
+                    "recall_at_10": round(recall_at_k(o[0].cpu().numpy().view(np.uint32), gt, k), 4),
+                    "qps": round(nq / wall, 1), "kernel_ms": round(kms, 3), "queries_per_call": nq,
+                    "algorithmic_gbps": round(algb / (kms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(algb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "reference_published_recall_qps": pub})
+    for old in built.values():
+        old[0].Close()
+    return {"note": "synthetic rows of the published shapes (no datasets offline); reference figures: BASELINE.md, real data, Intel i5-12500, "
+                    "one query at a time", "shapes": out}
 
 
 def c5_case(K, dev, g, n, nq, rows_of=None, dim=1536, ncat=100):

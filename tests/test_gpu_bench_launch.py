@@ -54,6 +54,19 @@ def test_bench_cluster_two_shards_one_process():
     assert line["config"]["total_rows"] == 40000
 
 
+def test_bench_reference_benchmark_shapes():
+    """`bench.py --shapes`: the reference's published benchmarks (GloVe-100/200/300 cosine, SIFT-1M L2 at the published M /
+    efConstruction / efSearch) on synthetic rows of those shapes -- built on the GPU, searched, recall measured against the exact
+    scan of the same index.  Every shape must reach the recall the reference publishes for it."""
+    p, line = _run(["--shapes"], timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None and len(line["shapes"]) == 6
+    for sh in line["shapes"]:
+        published = float(sh["reference_published_recall_qps"].split("/")[0])
+        assert sh["recall_at_10"] >= published, sh
+        assert sh["qps"] > 1000 * float(sh["reference_published_recall_qps"].split("/")[1].split()[0]) / 10, sh
+
+
 def test_bench_refuses_a_world_smaller_than_asked():
     """a launcher that started ONE rank for --gpus 2 (what round 3's bench silently accepted): exit code 2, no JSON line"""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
