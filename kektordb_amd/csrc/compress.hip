@@ -119,7 +119,7 @@ extern "C" int kdb_index_compress(kdb_index *src, uint32_t precision, uint32_t f
     const uint32_t n = src->count, dim = src->desc.dim;
     const float *rows = reinterpret_cast<const float *>(src->d_rows);
     if (precision == KDB_PREC_F16) {
-        rc = kdb_launch_rows_to_f16(rows, reinterpret_cast<uint16_t *>(dst->d_rows), src->ld, 1, n, s);
+        rc = kdb_launch_rows_to_f16(rows, reinterpret_cast<uint16_t *>(dst->d_rows), src->ld, src->ld, 1, n, s);
         if (rc) return fail(rc);
         KdbView v = kdb_make_view(dst);
         v.count = n;

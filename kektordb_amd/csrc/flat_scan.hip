@@ -1450,16 +1450,34 @@ flat_rescue_kernel(KdbView v, const float *__restrict__ queries, FsParams p, uin
     }
 }
 
-// ranking copy of float32 rows: ld halfs per row (pad columns included), RNE
-__global__ void rows_to_f16_kernel(const float *__restrict__ rows, uint16_t *__restrict__ rows16, size_t first_elem, size_t n_elems) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n_elems) return;
-    const float4 y = *reinterpret_cast<const float4 *>(rows + first_elem + i);
-    const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
-    uint2 o;
-    o.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
-    o.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
-    *reinterpret_cast<uint2 *>(rows16 + first_elem + i) = o;
+// ranking copy of float32 rows: ld16 halfs per row (ld rounded up to whole 128-byte slabs; pad columns zero), RNE
+__global__ void rows_to_f16_kernel(const float *__restrict__ rows, uint16_t *__restrict__ rows16, uint32_t ld, uint32_t ld16, size_t first_row,
+                                   size_t n_quads) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // four halfs of the copy per thread
+    if (i >= n_quads) return;
+    const uint32_t per_row = ld16 >> 2;
+    const size_t row = first_row + i / per_row;
+    const uint32_t col = (uint32_t)(i % per_row) * 4u;
+    uint2 o = make_uint2(0u, 0u);
+    if (col < ld) { // ld is a multiple of 16: a quad is inside the row or wholly in the pad
+        const float4 y = *reinterpret_cast<const float4 *>(rows + row * ld + col);
+        const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+        o.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+        o.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+    }
+    *reinterpret_cast<uint2 *>(rows16 + row * ld16 + col) = o;
+}
+
+// prepared float32 queries re-laid with the ranking copy's row stride (zero pad columns): what the ranking kernels read beside it
+__global__ void pad_queries_kernel(const float *__restrict__ src, uint32_t ld, float *__restrict__ dst, uint32_t ld16, size_t n_quads) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_quads) return;
+    const uint32_t per_row = ld16 >> 2;
+    const size_t row = i / per_row;
+    const uint32_t col = (uint32_t)(i % per_row) * 4u;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < ld) y = *reinterpret_cast<const float4 *>(src + row * ld + col);
+    *reinterpret_cast<float4 *>(dst + row * ld16 + col) = y;
 }
 
 // f16-ranked scan: the prepared queries as halfs, once per call (every workgroup used to convert them per row tile)
@@ -1738,11 +1756,10 @@ int kdb_launch_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t
     return KDB_OK;
 }
 
-int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s) {
+int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t ld16, uint32_t first, uint32_t n, hipStream_t s) {
     if (n == 0) return KDB_OK;
-    const size_t n_elems = (size_t)n * ld, first_elem = (size_t)first * ld;
-    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, s, d_rows, d_rows16, first_elem,
-                       n_elems);
+    const size_t n_quads = (size_t)n * (ld16 >> 2);
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, d_rows, d_rows16, ld, ld16, (size_t)first, n_quads);
     KDB_HIP(hipGetLastError());
     return KDB_OK;
 }
@@ -1818,7 +1835,12 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     // half-precision ranking copy of float32 rows) wins from 65 queries on (128 queries 0.92 vs 1.20 ms for the 128 x 128
     // tile kernel, 256 queries 1.10 vs 1.81 ms; k=100: 1.30 vs 3.66 ms) and between 33 and 64 queries when the lists are
     // short (k=10, 48 queries: 0.69 vs 1.04 ms; k=100, 64 queries: 1.12 vs 0.94 ms)
-    const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : v.ld * 2u;
+    // float32 indexes: the ranking copy has its own row stride (idx->ld16: whole 128-byte slabs, zero pad).  The kernels that
+    // read it take a view with that stride (vr) and queries re-laid with it (q_rank); everything exact keeps v and d_q.
+    const bool copy_padded = v.precision == KDB_PREC_F32 && idx->d_rows16 != nullptr && idx->ld16 != v.ld;
+    KdbView vr = v;
+    if (copy_padded) vr.ld = idx->ld16;
+    const uint32_t rowb = v.precision == KDB_PREC_I8 ? v.ld : vr.ld * 2u;
     const bool rank16_ok = v.precision == KDB_PREC_F32 && (v.metric == KDB_METRIC_L2 || queries_normalised) && idx->max_norm2 > 0.f &&
                            idx->max_norm2 <= 1.0e4f && !getenv("KDB_FLAT_EXACT_ONLY");
     const bool big_ok = B >= (uint32_t)kdb_flat_big_min() && rowb % (uint32_t)FB_SLAB == 0u &&
@@ -1881,9 +1903,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     if (big && n_part_big * cap_big * 8 + n_part_big * 12 + 1024 > part_bytes) part_bytes = n_part_big * cap_big * 8 + n_part_big * 12 + 1024;
     size_t fbq_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * v.ld * 4 + 255) & ~(size_t)255) : 0; // vectors of the unsettled queries
     if (big && v.precision == KDB_PREC_F16) fbq_bytes = ((size_t)fb_nqt * FB_T * v.ld * 2 + 255) & ~(size_t)255; // the queries as halfs
+    if (rank16 && copy_padded) { // ... the ranking scan's query halfs live there first, with the copy's stride
+        const size_t h = (((size_t)(big ? fb_nqt * FB_T : n_qtiles * FS_TQ) * vr.ld * 2 + 255) & ~(size_t)255);
+        if (h > fbq_bytes) fbq_bytes = h;
+    }
+    const size_t n_qpad = (size_t)(big ? fb_nqt * FB_T : n_qtiles * FS_TQ); // query rows the ranking kernels may touch (d_q holds >= as many)
+    const size_t qp_bytes = (rank16 && copy_padded) ? ((n_qpad * vr.ld * 4 + 255) & ~(size_t)255) : 0;
     const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
     const size_t rsl_bytes = ((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255; // queries handed to the rescue pass
-    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes + part_bytes + 4096);
+    int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes + part_bytes + qp_bytes + 4096);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(base);
@@ -1894,6 +1922,15 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     uint32_t *d_rscount = d_nscan + 8;
     uint32_t *d_rslist = reinterpret_cast<uint32_t *>(base + ids_bytes + 256 + fbq_bytes + fbl_bytes);
     unsigned char *part = base + ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes;
+    const void *q_rank = d_q; // what the ranking kernels read as queries
+    if (qp_bytes) {
+        float *d_qp = reinterpret_cast<float *>(part + part_bytes);
+        const size_t quads = n_qpad * (vr.ld >> 2);
+        hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float *>(d_q), v.ld, d_qp,
+                           vr.ld, quads);
+        KDB_HIP(hipGetLastError());
+        q_rank = d_qp;
+    }
     if (need_ids) {
         KDB_HIP(hipMemsetAsync(d_nscan, 0, 8, s));
         hipLaunchKernelGGL(compact_ids_kernel, dim3(((v.count >> 5) + 256) / 256), dim3(256), 0, s, v.deleted, d_allow, d_first_allowed,
@@ -1927,9 +1964,10 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     const uint32_t grid = stripes8 * n_qtiles;
     if (rank16 && small) p.rows16 = idx->d_rows16;
     if ((rank16 && !small) || (big && v.precision == KDB_PREC_F16)) { // the query halfs live in the buffer the exact pass fills later (it is idle during the ranking scan)
-        const size_t nq_elems = big ? (size_t)fb_nqt * FB_T * v.ld : (size_t)n_qtiles * FS_TQ * v.ld;
+        const bool rk = rank16 && copy_padded; // (float16 indexes: their own rows, their own stride)
+        const size_t nq_elems = (big ? (size_t)fb_nqt * FB_T : (size_t)n_qtiles * FS_TQ) * (rk ? vr.ld : v.ld);
         hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq_elems / 4 + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const float *>(d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
+                           reinterpret_cast<const float *>(rk ? q_rank : d_q), nq_elems, reinterpret_cast<uint16_t *>(d_fbq));
         KDB_HIP(hipGetLastError());
         p.q16 = reinterpret_cast<const uint16_t *>(d_fbq);
         p.rows16 = idx->d_rows16;
@@ -1939,16 +1977,18 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     unsigned long long *stat_slot = p.ctr;
     KDB_HIP(hipMemsetAsync(stat_slot, 0, 32, s));
     KDB_HIP(hipEventRecord(idx->ev0, s));
-    auto launch_scan = [&](auto kern) -> int {
+    auto launch_scan_on = [&](auto kern, const KdbView &vv, const void *qv) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, v, reinterpret_cast<const float *>(d_q), p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, vv, reinterpret_cast<const float *>(qv), p);
         return KDB_OK;
     };
-    auto launch_small_on = [&](auto kern, const FsParams &pp, const void *qv, size_t lds_k) -> int {
+    auto launch_scan = [&](auto kern) -> int { return launch_scan_on(kern, v, d_q); };
+    auto launch_small_view = [&](auto kern, const KdbView &vv, const FsParams &pp, const void *qv, size_t lds_k) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
-        hipLaunchKernelGGL(kern, dim3(stripes8 * n_q16), dim3(256), lds_k, s, v, reinterpret_cast<const float *>(qv), pp, n_q16, cap_s);
+        hipLaunchKernelGGL(kern, dim3(stripes8 * n_q16), dim3(256), lds_k, s, vv, reinterpret_cast<const float *>(qv), pp, n_q16, cap_s);
         return KDB_OK;
     };
+    auto launch_small_on = [&](auto kern, const FsParams &pp, const void *qv, size_t lds_k) -> int { return launch_small_view(kern, v, pp, qv, lds_k); };
     auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, d_q, lds_s); };
     FsParams p_old = p; // geometry of the 128 x 128 tile kernel (the exact pass of a big-tile ranked scan keeps it)
     if (big) {
@@ -1977,8 +2017,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     }
     auto launch_big = [&](auto kern, const void *rows_b, const void *q_b) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), FB_LDS, s, v, reinterpret_cast<const unsigned char *>(rows_b),
-                           reinterpret_cast<const unsigned char *>(q_b), p);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), FB_LDS, s, rows_b == (const void *)idx->d_rows16 ? vr : v,
+                           reinterpret_cast<const unsigned char *>(rows_b), reinterpret_cast<const unsigned char *>(q_b), p);
         return KDB_OK;
     };
     if (big) {
@@ -1987,9 +2027,9 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         else if (v.metric == KDB_METRIC_COSINE) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
         else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
     } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
-        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(v.ld), p, d_q, lds_r);
-        else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(v.ld), p, d_q, lds_r);
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(vr.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_view(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(vr.ld), vr, p, q_rank, lds_r);
+        else rc = launch_small_view(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(vr.ld), vr, p, q_rank, lds_r);
     } else if (small) {
         if (v.precision == KDB_PREC_I8) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_I8>(v.ld));
         else if (v.precision == KDB_PREC_F16) rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F16>(v.ld));
@@ -1997,8 +2037,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         else rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld));
     } else if (v.precision == KDB_PREC_I8) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>); // int8 is cosine only
     else if (v.precision == KDB_PREC_F16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F16>); // f16 is L2 only
-    else if (rank16 && v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>);
-    else if (rank16) rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, FS_PREC_F32R>);
+    else if (rank16 && v.metric == KDB_METRIC_COSINE) rc = launch_scan_on(flat_scan_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, p.rows16 ? vr : v, p.rows16 ? q_rank : d_q);
+    else if (rank16) rc = launch_scan_on(flat_scan_kernel<KDB_METRIC_L2, FS_PREC_F32R>, p.rows16 ? vr : v, p.rows16 ? q_rank : d_q);
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_scan(flat_scan_kernel<KDB_METRIC_COSINE, KDB_PREC_F32>);
     else rc = launch_scan(flat_scan_kernel<KDB_METRIC_L2, KDB_PREC_F32>);
     if (rc) return rc;
@@ -2196,7 +2236,12 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
 
     const size_t ids_bytes = al((size_t)total * 4 + 1024);
     const size_t part_bytes = n_part * kl * 8 + n_part * 4 + 1024;
-    const size_t need = ids_bytes + al((size_t)G * 4) * 2 + al(chunk_words * 4) * 2 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + part_bytes + 4096;
+    // (the ranking copy's own row stride: see kdb_launch_flat_scan)
+    const bool copy_padded = v.precision == KDB_PREC_F32 && idx->d_rows16 != nullptr && idx->ld16 != v.ld;
+    KdbView vr = v;
+    if (copy_padded) vr.ld = idx->ld16;
+    const size_t qp_bytes = copy_padded ? al((size_t)B * vr.ld * 4) : 0;
+    const size_t need = ids_bytes + al((size_t)G * 4) * 2 + al(chunk_words * 4) * 2 + al(tiles.size() * 4) * 2 + al((size_t)B * 4) * 4 + 256 + al(part_bytes) + qp_bytes + 4096;
     rc = kdb_ensure_scratch(idx, need);
     if (rc) return rc;
     unsigned char *base = reinterpret_cast<unsigned char *>(idx->d_scratch);
@@ -2257,17 +2302,27 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.ctr = nullptr; // written by group_prefix_kernel
     const uint32_t stripes8 = (want + 7) / 8 * 8;
     KDB_HIP(hipEventRecord(idx->ev0, s));
-    auto launch_small_on = [&](auto kern, const FsParams &pp, size_t lds_k) -> int {
+    auto launch_small_view = [&](auto kern, const KdbView &vv, const void *qv, const FsParams &pp, size_t lds_k) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
-        hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_k, s, v, reinterpret_cast<const float *>(d_q), pp, T, cap_s);
+        hipLaunchKernelGGL(kern, dim3(stripes8 * T), dim3(256), lds_k, s, vv, reinterpret_cast<const float *>(qv), pp, T, cap_s);
         return KDB_OK;
     };
+    auto launch_small_on = [&](auto kern, const FsParams &pp, size_t lds_k) -> int { return launch_small_view(kern, v, d_q, pp, lds_k); };
     auto launch_small = [&](auto kern) -> int { return launch_small_on(kern, p, lds_s); };
     if (rank16) {
         p.rows16 = idx->d_rows16;
-        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(v.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
-        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(v.ld), p, lds_r);
-        else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(v.ld), p, lds_r);
+        const void *q_rank = d_q;
+        if (qp_bytes) {
+            float *d_qp = reinterpret_cast<float *>(part + al(part_bytes));
+            const size_t quads = (size_t)B * (vr.ld >> 2);
+            hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float *>(d_q), v.ld, d_qp,
+                               vr.ld, quads);
+            KDB_HIP(hipGetLastError());
+            q_rank = d_qp;
+        }
+        const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(vr.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
+        if (v.metric == KDB_METRIC_COSINE) rc = launch_small_view(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(vr.ld), vr, q_rank, p, lds_r);
+        else rc = launch_small_view(fss_kernel_for<KDB_METRIC_L2, FS_PREC_F32R>(vr.ld), vr, q_rank, p, lds_r);
     } else if (v.precision == KDB_PREC_I8) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_I8>(v.ld));
     else if (v.precision == KDB_PREC_F16) rc = launch_small(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F16>(v.ld));
     else if (v.metric == KDB_METRIC_COSINE) rc = launch_small(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld));

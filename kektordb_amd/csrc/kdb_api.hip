@@ -277,6 +277,7 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     idx->deg_up = m;
     idx->elem = desc->precision == KDB_PREC_F32 ? 4 : desc->precision == KDB_PREC_F16 ? 2 : 1;
     idx->ld = (desc->dim + 15u) & ~15u;
+    idx->ld16 = (idx->ld + 63u) & ~63u;
     auto fail = [&](int code) {
         kdb_index_destroy(idx);
         return code;
@@ -377,7 +378,7 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
     // ||x||^2 per row: ranking key of the L2 flat scan; for float32 rows also the largest one (error band of the
     // f16-ranked cosine scan: the reference normalises cosine rows at insert, the mirror does not assume it)
     if (idx->d_rows16) { // ranking copy of the new rows
-        int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, first_id, n, idx->stream);
+        int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), idx->d_rows16, idx->ld, idx->ld16, first_id, n, idx->stream);
         if (rc) return rc;
     }
     const bool want_norms = idx->desc.precision != KDB_PREC_I8 &&
@@ -489,7 +490,7 @@ extern "C" int kdb_index_reserve(kdb_index *idx, uint32_t new_capacity) {
     };
     void *rows16 = idx->d_rows16;
     Arr arrs[] = {{&idx->d_rows, o1 * row_b, n1 * row_b},
-                  {&rows16, idx->d_rows16 ? o1 * idx->ld * 2 : 0, idx->d_rows16 ? n1 * idx->ld * 2 : 0},
+                  {&rows16, idx->d_rows16 ? o1 * idx->ld16 * 2 : 0, idx->d_rows16 ? n1 * idx->ld16 * 2 : 0},
                   {reinterpret_cast<void **>(&idx->d_norms), o1 * 4, n1 * 4},
                   {reinterpret_cast<void **>(&idx->d_adj0), o1 * idx->deg0 * 4, n1 * idx->deg0 * 4},
                   {reinterpret_cast<void **>(&idx->d_up_idx), o1 * 4, n1 * 4},
@@ -1210,14 +1211,14 @@ static int ensure_rows16(kdb_index *idx, hipStream_t s) {
         return KDB_OK;
     const size_t n1 = (size_t)idx->cap + 1;
     uint16_t *copy = nullptr;
-    if (hipMalloc(&copy, n1 * idx->ld * 2) != hipSuccess) {
+    if (hipMalloc(&copy, n1 * idx->ld16 * 2) != hipSuccess) {
         (void)hipGetLastError();
         idx->rows16_refused = true; // no room: the scan ranks on the float32 rows (same answers) and does not ask again
         return KDB_OK;
     }
     // The copy is published only once it is COMPLETE: scans of other streams (the cluster's second lane, a second caller)
     // and later uploads on idx->stream order against nothing but this wait -- a one-time cost of the first exact scan.
-    int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), copy, idx->ld, 0, idx->count + 1, s);
+    int rc = kdb_launch_rows_to_f16(reinterpret_cast<const float *>(idx->d_rows), copy, idx->ld, idx->ld16, 0, idx->count + 1, s);
     if (rc == KDB_OK && hipStreamSynchronize(s) != hipSuccess) {
         kdb_set_error("half-precision ranking copy: conversion failed");
         rc = KDB_ERR_HIP;

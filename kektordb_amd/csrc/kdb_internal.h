@@ -92,6 +92,8 @@ struct kdb_index {
     uint64_t graph_epoch = 1, up_slot_epoch = 0; // every writer of levels / up_idx / adj_up bumps graph_epoch
     uint16_t *d_rows16 = nullptr; // float32 indexes: the rows once more as halfs (ranking copy of the exact scan: half the bytes)
     bool rows16_refused = false;  // its allocation failed once (no room): not retried
+    uint32_t ld16 = 0;            // halfs per row of that copy: ld rounded up to whole 128-byte slabs (zero-filled), so that every
+                                  // float32 index -- GloVe's 100 / 200 / 300 columns too -- is ranked by the 256 x 256 tile kernel
     float max_norm2 = 0.f; // largest ||x||^2 among the float32 rows uploaded so far (error band of the f16-ranked scan)
     // host copies of the per-node level and first upper slot (incremental refresh validates and places lists with them)
     std::vector<uint8_t> h_levels;
@@ -210,7 +212,7 @@ int kdb_ensure_up_slots(kdb_index *idx, hipStream_t s);
 int kdb_launch_flat_anyk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B, uint32_t k, const uint32_t *d_scan_ids,
                          const uint32_t *d_nscan, unsigned long long *d_keys, uint32_t chunk_q, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
                          int dist64, unsigned long long *d_ctr, hipStream_t s);
-int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t first, uint32_t n, hipStream_t s);
+int kdb_launch_rows_to_f16(const float *d_rows, uint16_t *d_rows16, uint32_t ld, uint32_t ld16, uint32_t first, uint32_t n, hipStream_t s);
 int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                                 uint32_t k, uint32_t G, const uint32_t *group_offsets, const uint32_t *d_lists,
                                 uint32_t words32, uint64_t max_total_allowed, uint32_t *d_out_ids, float *d_out_dist,

@@ -116,7 +116,7 @@ extern "C" int kdb_probe_gather(kdb_index *idx, int which, uint64_t n_reads, flo
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     const unsigned char *rows = reinterpret_cast<const unsigned char *>(which ? (const void *)idx->d_rows16 : (const void *)idx->d_rows);
-    const uint32_t row_bytes = idx->ld * (which ? 2u : (uint32_t)idx->elem);
+    const uint32_t row_bytes = which ? idx->ld16 * 2u : idx->ld * (uint32_t)idx->elem;
     if (!rows || idx->count == 0 || (row_bytes & 255u)) {
         kdb_set_error("probe_gather: no such row array, no rows, or rows that are not whole 256-byte pieces");
         return KDB_ERR_UNSUPPORTED;
@@ -142,7 +142,7 @@ extern "C" int kdb_probe_stream(kdb_index *idx, int which, float *ms, uint64_t *
     std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     const void *rows = which ? (const void *)idx->d_rows16 : (const void *)idx->d_rows;
-    const size_t total = ((size_t)idx->count + 1) * idx->ld * (which ? 2u : idx->elem);
+    const size_t total = ((size_t)idx->count + 1) * (which ? idx->ld16 * 2u : idx->ld * idx->elem);
     if (!rows || idx->count == 0) {
         kdb_set_error("probe_stream: no such row array or no rows");
         return KDB_ERR_UNSUPPORTED;

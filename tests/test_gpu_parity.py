@@ -249,7 +249,8 @@ def test_search_f16_and_int8(oracle, hip):
 
 @pytest.mark.parametrize("metric", [1, 0])
 @pytest.mark.parametrize("n,dim,k,B", [(5000, 128, 10, 70), (3000, 100, 100, 5), (700, 768, 10, 130),
-                                        (20000, 64, 128, 140), (5000, 128, 10, 16), (4000, 768, 10, 33), (9000, 1536, 20, 7)])
+                                        (20000, 64, 128, 140), (5000, 128, 10, 16), (4000, 768, 10, 33), (9000, 1536, 20, 7),
+                                        (4000, 100, 10, 300), (3000, 200, 20, 40), (2500, 300, 10, 20)])
 def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
     O = oracle
     X = make_corpus(n, dim, "normal", seed=41)
