@@ -287,7 +287,7 @@ def test_flat_scan_vs_oracle(oracle, hip, metric, n, dim, k, B):
     assert np.array_equal(ids2, ids3) and np.array_equal(cnt2, cnt3)
 
 
-@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 100])
+@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 100, 64, 192, 300, 448])
 @pytest.mark.parametrize("prec,metric", [(0, 1), (0, 0), (1, 0), (2, 1)])
 def test_small_scan_chunk_instantiations(oracle, hip, prec, metric, dim):
     """B <= 32 takes flat_scan_small_kernel<METRIC, PREC, CS>: the steps per register chunk are a template constant chosen from
