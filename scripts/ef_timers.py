@@ -1,6 +1,6 @@
 """Per-phase cycle counters of the graph search at large ef (the measurement build: make -C kektordb_amd/csrc dbgs;
 KEKTOR_HIP_LIB=kektordb_amd/lib/libkektor_hip_dbgs.so): 1M x 768 clustered, k=100, B queries, one call per ef; the kernel prints the
-counters of its first 64 queries, this script averages them.
+counters of its first 64 queries, this script averages them.  EF_ROWS / EF_DIM / EF_METRIC=l2 / EF_K / EF_B select another shape.
     python scripts/ef_timers.py [ef ...]"""
 import os
 import re
@@ -43,13 +43,13 @@ import kektordb_amd as K  # noqa: E402
 import bench as Bm  # noqa: E402
 
 dev = torch.device("cuda:0")
-n, dim, k, B = 1_000_000, 768, 100, int(os.environ.get("EF_B", 1024))
+n, dim, k, B = int(os.environ.get("EF_ROWS", 1_000_000)), int(os.environ.get("EF_DIM", 768)), int(os.environ.get("EF_K", 100)), int(os.environ.get("EF_B", 1024))
 gc = torch.Generator(device=dev)
 gc.manual_seed(2)
 cent = torch.randn((4096, dim), device=dev, generator=gc)
 X = Bm.gen_corpus(n, dim, "clustered", 1000, dev, cent)
 Q = Bm.gen_corpus(8192, dim, "clustered", 11, dev, cent)
-idx = K.HipIndex(dim, K.COSINE, K.F32, 16, 200, capacity=n)
+idx = K.HipIndex(dim, K.L2 if os.environ.get("EF_METRIC") == "l2" else K.COSINE, K.F32, 16, 200, capacity=n)
 idx.upload_rows(X, 1)
 del X
 idx.build(n, batch=16384, ef_construction=200, seed=1)
