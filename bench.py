@@ -947,9 +947,11 @@ def reference_shapes_leg(K, dev, k=10, nq=8192):
             t0 = time.time()
             idx.build(n, batch=16384, ef_construction=efc, seed=5)
             tb = time.time() - t0
+            log(f"[shapes] {name} M={m} efC={efc}: built in {tb:.2f} s")
             gt_o = outs(nq, k, dev)
             idx.flat_scan_batch_dev(Q.contiguous(), k, *gt_o)
             idx.sync()
+            log("[shapes]   exact scan done")
             built[key] = (idx, Q.contiguous(), gt_o[0].cpu().numpy().view(np.uint32), tb)
         idx, Q, gt, tb = built[key]
         o = outs(nq, k, dev)
@@ -963,6 +965,7 @@ def reference_shapes_leg(K, dev, k=10, nq=8192):
         wall = (time.perf_counter() - t0) / reps
         st = idx.launch_stats(reps)
         kms = float(np.mean([c["kernel_ms"] for c in st]))
+        log(f"[shapes]   efS={efs}: {reps} searches done, kernel {kms:.3f} ms")
         nd = float(np.mean([c["n_dist"] for c in st])) / nq
         nh = float(np.mean([c["n_hops"] for c in st])) / nq
         algb = nq * (nd * dim * 4 + nh * 2 * m * 4 + nd * 4)

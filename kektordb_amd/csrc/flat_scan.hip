@@ -79,6 +79,7 @@ struct FsParams {
     float *g_pub;             // [n_stripes][qstride] shared thresholds: stripe s publishes the r-th smallest key of its list, r = ceil(kl / n_stripes)
     float *part_thr;          // [n_stripes][qstride] the threshold a stripe ended with: its list is complete for keys <= that
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
+    uint32_t fb_fullsync;     // 1 (KDB_FB_FULLSYNC, A/B switch): a full __syncthreads() behind every tile's selection
     uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
     uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
@@ -2021,6 +2022,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_spx = fb_spx;
         p.fb_slack = fb_slack;
         p.fb_alt = getenv("KDB_FB_NOALT") ? 0u : 1u;
+        p.fb_fullsync = getenv("KDB_FB_FULLSYNC") ? 1u : 0u;
         p.fb_period = fb_period;
         { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     }

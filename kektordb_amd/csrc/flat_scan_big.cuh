@@ -267,12 +267,16 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             mfma_step(0);
             FB_SB();
             fb_dma_wait();
-            __syncthreads(); // slab s+1 has landed (every wave drained its own DMA), nobody reads slab s any more
-            if (dma_same) read_frags(0, buf ^ 1u, 0); // (the next tile reads its first fragments after the selection: kept across it, they spill)
-            if (s == 0 && has_next && tid < FB_T) {
+            // ids / norms of the next tile: stored BEFORE the first slab's barrier.  The last slab step reads them (aptr, above)
+            // and with two-slab rows that step is the next one: stored behind this barrier they raced with it (waves 4-7 read
+            // what waves 0-3 had not written yet: stale or never-written ids -> wrong rows ranked, or a fault).  The other
+            // parity's entries were last read by the selection of the previous tile, closed by its barrier.
+            if (s == 0 && nslab > 1u && has_next && tid < FB_T) {
                 sel_id[(tp ^ 1u) * FB_T + tid] = n_id;
                 if (NEED_NORM) sel_nrm[(tp ^ 1u) * FB_T + tid] = n_nrm;
             }
+            __syncthreads(); // slab s+1 has landed (every wave drained its own DMA), nobody reads slab s any more
+            if (dma_same) read_frags(0, buf ^ 1u, 0); // (the next tile reads its first fragments after the selection: kept across it, they spill)
             FB_SB();
             mfma_step(1);
             FB_SB();
@@ -385,8 +389,14 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         // ---- compaction round, every fb_period tiles: the lists that outgrew kl + fb_slack are cut back to their kl best
         //      and the thresholds follow.  All eight waves share the work (a compaction is a dependent round trip to the
         //      list in HBM scratch plus a 32-step search: the whole workgroup waits for the slowest wave at the next barrier).
-        __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete; the dump scratch is free again
-        if ((t == 0u || (t + 1u) % p.fb_period == 0u) && has_next) { // (the first tile keeps everything: thresholds start open)
+        // Between selection and the next tile only LDS has to be settled (list lengths, the dump scratch): the appends to the
+        // lists in HBM scratch are read again by a compaction round at the earliest, and that round -- like the hand-over at
+        // the end -- starts with a full __syncthreads().  A plain s_waitcnt lgkmcnt(0) + s_barrier lets the store acknowledgements
+        // (vmcnt counts stores on gfx9) return behind the first MFMA steps of the next tile instead of in front of them.
+        const bool compact_now = (t == 0u || (t + 1u) % p.fb_period == 0u) && has_next;
+        if (compact_now || !has_next || p.fb_fullsync) __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete; the dump scratch is free again
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (compact_now) { // (the first tile keeps everything: thresholds start open)
             if (flags[0] && !(FB_DBG & 8u)) {
                 if (tid < FB_T && l_cnt[tid] > p.kl + p.fb_slack) need_list[atomicAdd(&flags[1], 1u)] = (uint32_t)tid;
                 __syncthreads();

@@ -131,3 +131,55 @@ def test_flat_scan_big_tile_identical_rows(oracle, hip):
     ids, dist, cnt = idx.flat_scan_batch(Q, k)
     _check(O, orc, idx, Q, k, ids, dist, cnt, range(0, B, 5), O.F32)
     assert np.array_equal(ids[0], np.arange(3001, 3011, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("dim", [100, 128])
+def test_flat_scan_big_tile_two_slab_rows_between_builds(hip, dim):
+    """Rows of exactly TWO 128-byte slabs (GloVe-100's ranking copy, SIFT's 128 columns): the tile's second slab step is the one
+    that addresses the next tile's rows, so their ids must be in LDS before the FIRST slab's barrier.  They used to be stored
+    behind it: waves 4-7 could read ids of two tiles ago -- or, in a workgroup's first tile, whatever the previous kernel had
+    left in LDS (a memory fault in `bench.py --shapes` after the builder's kernels; wrong rows ranked otherwise).  Rounds of
+    build -> scan on fresh indexes; every round's answers equal the exact-only scan (no ranking copy, no big-tile kernel)."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    n, B, k = 120_000, 4096, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + dim)
+    X = torch.randn((n, dim), device=dev, generator=g)
+    X /= X.norm(dim=1, keepdim=True)
+    Q = torch.randn((B, dim), device=dev, generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q = Q.contiguous()
+
+    def outs():
+        return (torch.zeros((B, k), dtype=torch.int32, device=dev), torch.zeros((B, k), dtype=torch.float32, device=dev),
+                torch.zeros((B,), dtype=torch.int32, device=dev))
+
+    want = None
+    for rnd in range(5):
+        junk = torch.empty(1 << 28, dtype=torch.int32, device=dev)  # 1 GiB of garbage for the next allocations to start from
+        junk.random_(-2**31, 2**31 - 1) if rnd % 2 == 0 else junk.fill_(0x01010101)
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
+        idx = hip.HipIndex(dim, hip.COSINE, hip.F32, 16, 100, capacity=n)
+        idx.upload_rows(X, 1)
+        idx.build(n, batch=16384, ef_construction=100, seed=5)
+        if want is None:
+            os.environ["KDB_FLAT_EXACT_ONLY"] = "1"
+            try:
+                o = outs()
+                idx.flat_scan_batch_dev(Q, k, *o)
+                idx.sync()
+            finally:
+                del os.environ["KDB_FLAT_EXACT_ONLY"]
+            want = [t.cpu().numpy() for t in o]
+        o = outs()
+        idx.flat_scan_batch_dev(Q, k, *o)
+        idx.sync()
+        got = [t.cpu().numpy() for t in o]
+        assert np.array_equal(got[2], want[2]), rnd
+        assert np.array_equal(got[0], want[0]), rnd
+        assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), rnd
+        idx.Close()
