@@ -22,6 +22,7 @@
 #include "kdb_device.cuh"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -79,7 +80,8 @@ struct FsParams {
     float *g_pub;             // [n_stripes][qstride] shared thresholds: stripe s publishes the r-th smallest key of its list, r = ceil(kl / n_stripes)
     float *part_thr;          // [n_stripes][qstride] the threshold a stripe ended with: its list is complete for keys <= that
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
-    uint32_t fb_fullsync;     // 1 (KDB_FB_FULLSYNC, A/B switch): a full __syncthreads() behind every tile's selection
+    uint32_t fb_grow;         // 1: compaction rounds thin out once the thresholds have settled (KDB_FB_NOGROW: A/B switch)
+    uint32_t fb_seeded;       // 1: a seed launch published first thresholds into g_pub (KDB_FB_NOSEED: A/B switch)
     uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
     uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
@@ -138,23 +140,29 @@ __device__ __forceinline__ unsigned long long fs_compact_core(float *key, uint32
         }
     }
     uint32_t Tk = 0; // smallest Tk with count(key <= Tk) >= kl
-    for (int bit = 31; bit >= 0; bit--) {
-        const uint32_t test = Tk | ((1u << bit) - 1u);
-        uint32_t c = 0;
-#pragma unroll
-        for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
-        if (c < kl) Tk |= 1u << bit;
-    }
-    if (r2) { // the same search for rank r2
+    if (r2) { // ... and the same search for rank r2, in the same 32 steps: two independent chains of compare -> ballot -> count
         uint32_t T2 = 0;
         for (int bit = 31; bit >= 0; bit--) {
-            const uint32_t test = T2 | ((1u << bit) - 1u);
+            const uint32_t low = (1u << bit) - 1u;
+            const uint32_t test = Tk | low, test2 = T2 | low;
+            uint32_t c = 0, c2 = 0;
+#pragma unroll
+            for (int u = 0; u < SLOTS; u++) {
+                c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
+                c2 += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test2));
+            }
+            if (c < kl) Tk |= 1u << bit;
+            if (c2 < r2) T2 |= 1u << bit;
+        }
+        *key_r2 = fs_unpack_key((unsigned long long)T2 << 32);
+    } else {
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t test = Tk | ((1u << bit) - 1u);
             uint32_t c = 0;
 #pragma unroll
             for (int u = 0; u < SLOTS; u++) c += (uint32_t)__builtin_popcountll(__ballot(ek[u] <= test));
-            if (c < r2) T2 |= 1u << bit;
+            if (c < kl) Tk |= 1u << bit;
         }
-        *key_r2 = fs_unpack_key((unsigned long long)T2 << 32);
     }
     uint32_t c_lt = 0, c_eq = 0;
 #pragma unroll
@@ -2022,21 +2030,48 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_spx = fb_spx;
         p.fb_slack = fb_slack;
         p.fb_alt = getenv("KDB_FB_NOALT") ? 0u : 1u;
-        p.fb_fullsync = getenv("KDB_FB_FULLSYNC") ? 1u : 0u;
+        p.fb_grow = getenv("KDB_FB_NOGROW") ? 0u : 1u;
+        // Seed launch: only when the stripe geometry is known here (no filter, no deleted rows: the row count never leaves the
+        // device otherwise), every stripe holds a whole first tile, and a stripe's share of the kl best is at most the 16 rows
+        // a tile's block maxima vouch for.  Same integer arithmetic as fs_resolve_n.
+        if (p.g_pub && !need_ids && !getenv("KDB_FB_NOSEED")) {
+            const uint32_t n_tiles = (v.count + FB_T - 1) / FB_T;
+            uint32_t ns = want_big;
+            const uint32_t lim4 = (n_tiles + 3u) / 4u;
+            if (ns > lim4) ns = lim4;
+            if (ns < 1u) ns = 1u;
+            const uint32_t tiles_per = (n_tiles + ns - 1u) / ns;
+            const uint32_t n_str = (n_tiles + tiles_per - 1u) / tiles_per;
+            const uint64_t last_rows = (uint64_t)v.count - (uint64_t)(n_str - 1u) * tiles_per * FB_T;
+            const uint32_t share = (kl + n_str - 1u) / n_str;
+            if (n_str >= 2u && last_rows >= (uint64_t)FB_T && share <= 16u) p.fb_seeded = 1u;
+        }
         p.fb_period = fb_period;
         { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     }
-    auto launch_big = [&](auto kern, const void *rows_b, const void *q_b) -> int {
+    auto launch_big_one = [&](auto kern, const void *rows_b, const void *q_b) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
         hipLaunchKernelGGL(kern, dim3(256), dim3(512), FB_LDS, s, rows_b == (const void *)idx->d_rows16 ? vr : v,
                            reinterpret_cast<const unsigned char *>(rows_b), reinterpret_cast<const unsigned char *>(q_b), p);
+        KDB_HIP(hipGetLastError());
         return KDB_OK;
     };
+    // the seed launch (first tile of every stripe -> first thresholds, flat_scan_big.cuh) and the scan proper
+    auto launch_big = [&](auto seed_kern, auto kern, const void *rows_b, const void *q_b) -> int {
+        if (p.fb_seeded) {
+            int r1 = launch_big_one(seed_kern, rows_b, q_b);
+            if (r1) return r1;
+        }
+        return launch_big_one(kern, rows_b, q_b);
+    };
     if (big) {
-        if (v.precision == KDB_PREC_I8) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, v.rows, d_q);
-        else if (v.precision == KDB_PREC_F16) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16>, v.rows, d_fbq);
-        else if (v.metric == KDB_METRIC_COSINE) rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
-        else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+        if (v.precision == KDB_PREC_I8)
+            rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, true>, flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, v.rows, d_q);
+        else if (v.precision == KDB_PREC_F16)
+            rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16, true>, flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16>, v.rows, d_fbq);
+        else if (v.metric == KDB_METRIC_COSINE)
+            rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R, true>, flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+        else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R, true>, flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
     } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
         const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(vr.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
         if (v.metric == KDB_METRIC_COSINE) rc = launch_small_view(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(vr.ld), vr, p, q_rank, lds_r);

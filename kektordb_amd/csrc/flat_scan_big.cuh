@@ -21,12 +21,20 @@
 //     query's threshold; survivors are APPENDED (LDS atomic on the list length) to the query's list in HBM scratch,
 //     which has room for kl + slack + period * 256 entries: `period` tiles cannot overflow it, and every `period` tiles
 //     whole waves compact the lists that grew past kl + slack down to their kl best (fs_compact_wave), tightening the
-//     threshold;
+//     threshold.  Once the thresholds have settled the rounds thin out (every 8 / 16 / 32 tiles from tile 64 / 128 / 256 on:
+//     a round costs the whole workgroup ~17 k cycles for the handful of lists that need it); an append that leaves a list
+//     less than one tile's worth of room forces a round at once (flags[2]), so no list can overflow;
 //   * thresholds are shared between the stripes of a query: after a compaction a stripe publishes the r-th smallest key
 //     of its list, r = ceil(kl / n_stripes); the largest of the published keys bounds the kl-th best key of the whole
 //     corpus (every stripe holds r rows at or below its own), so every workgroup lowers its thresholds to it.  A list may
 //     then hold fewer than its stripe's kl best; the stripe hands over the threshold it ended with (part_thr) and the
 //     merge treats its list as complete only below that.
+//   * thresholds do not start open: a SEED launch of the same kernel (template flag) computes the first tile of every stripe
+//     and publishes, per (stripe, query), a key that at least pub_rank of those 256 rows reach -- the smallest of the four
+//     per-lane maxima of the query's column (four disjoint row sets), or of its sixteen block maxima when pub_rank > 4.
+//     The scan proper then starts from the largest published key per query, as after any compaction round.  Without it a
+//     stripe appended its whole first tile (256 entries per list), compacted all 256 lists, and did so again three tiles
+//     later: 32 tiles at 54 k cycles each against 7.5 k once the thresholds had settled (timers build, 8192 x 1M x 768);
 // The keys are ranking keys only (f16 products summed in the MFMA's order, ||x||^2 - 2 q.x, -dot/||x||): the merge
 // kernel re-scores the finalists in the order of the graph search, exactly as for the other scan kernels.
 
@@ -81,7 +89,11 @@ __device__ __forceinline__ void fb_glds4(const unsigned char *g0, const unsigned
 __device__ __forceinline__ float fb_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ void fb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int METRIC, int PREC>
+// monotone map float -> uint32 (larger float, larger word) and back: minima of scores through LDS atomics
+__device__ __forceinline__ uint32_t fb_ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float fb_unord(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+template <int METRIC, int PREC, bool SEED = false>
 __global__ void __launch_bounds__(512, 2)
 flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb bytes per row */,
                      const unsigned char *__restrict__ q8 /* [n_qt*256][rowb] prepared queries, same encoding */, FsParams p) {
@@ -93,7 +105,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     uint32_t *sel_id = l_cnt + FB_T;                                            // [2][256] row ids of a tile (by tile parity)
     float *sel_nrm = reinterpret_cast<float *>(sel_id + 2 * FB_T);              // [2][256] their norms
     uint32_t *need_list = reinterpret_cast<uint32_t *>(sel_nrm + 2 * FB_T);     // [256] queries whose list is due for compaction
-    uint32_t *flags = need_list + FB_T;                                         // [0] somebody appended since the last compaction round, [1] length of need_list
+    uint32_t *flags = need_list + FB_T;                                         // [0] somebody appended since the last compaction round, [1] length of need_list, [2] a list is within one tile of its capacity
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -115,6 +127,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     uint32_t row_begin = stripe * geo.rows_per_stripe;
     uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
     uint32_t q0 = qtile * FB_T;
+    if (SEED) row_end = row_begin + FB_T; // (the host launches it only when every stripe holds a whole tile)
     if (FB_DBG & 64u) { row_begin = 0; row_end = geo.rows_per_stripe; }   // measurement: every workgroup walks stripe 0
     if (FB_DBG & 128u) q0 = 0;                                             // measurement: every workgroup uses query tile 0
     const uint32_t qstride = p.n_qtiles * FS_TQ;
@@ -128,13 +141,13 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         const bool real = q0 + (uint32_t)tid < p.B;
         tau[tid] = real ? INFINITY : -INFINITY; // padding queries of the last tile never keep anything
         tau_id[tid] = real ? 0xffffffffu : 0u;
-        l_cnt[tid] = 0u;
+        l_cnt[tid] = SEED ? 0xffffffffu : 0u; // (seed launch: the minimum of the query's group maxima, fb_ord-encoded)
         const uint32_t r = row_begin + (uint32_t)tid;
         const uint32_t id = r < row_end ? (p.scan_ids ? p.scan_ids[r] : r + 1u) : 0u;
         sel_id[tid] = id;
         if (NEED_NORM) sel_nrm[tid] = v.norms[id];
     }
-    if (tid < 2) flags[tid] = 0u;
+    if (tid < 3) flags[tid] = 0u;
     __syncthreads();
 
     // ---- staging map: thread t moves piece (t & 7) ^ swizzle of rows j*64 + t/8 (j < 4) of both operands
@@ -193,6 +206,55 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                                                                          __builtin_bit_cast(f16x8, fb[set][bb]), acc[ab][bb], 0, 0, 0);
             }
     };
+    // the first K step of a tile: C = 0 as the instruction's constant operand (zeroing 128 accumulator registers per wave
+    // and tile by v_mov cost ~1 k cycles with nothing to overlap them: the pipeline is empty behind the selection)
+    auto mfma_step_first = [&](int set) {
+        if (FB_DBG & 4u) return;
+        const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const i32x16 zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ab = 0; ab < 4; ab++)
+#pragma unroll
+            for (int bb = 0; bb < 2; bb++) {
+                if (PREC == KDB_PREC_I8)
+                    acc[ab][bb] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                                                 __builtin_bit_cast(i32x4, fa[set][ab]), __builtin_bit_cast(i32x4, fb[set][bb]), zi, 0, 0, 0));
+                else
+                    acc[ab][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][ab]),
+                                                                         __builtin_bit_cast(f16x8, fb[set][bb]), zf, 0, 0, 0);
+            }
+    };
+
+    // shared threshold: the largest of the stripes' published keys bounds the GLOBAL kl-th best key (whole workgroup; one barrier)
+    auto read_published = [&]() {
+        const uint32_t qq = (uint32_t)tid & (FB_T - 1u), half = (uint32_t)tid >> 8; // two threads per query, every other stripe each
+        float th = -INFINITY;
+        const float *src = p.g_pub + q0 + qq;
+        for (uint32_t s0 = half; s0 < geo.n_stripes; s0 += 16u) { // eight loads in flight, then their maximum
+            float x[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t s2 = s0 + 2u * u < geo.n_stripes ? s0 + 2u * u : s0;
+                x[u] = __hip_atomic_load(src + (size_t)s2 * qstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) th = fmaxf(th, x[u]);
+        }
+        float *tmp = reinterpret_cast<float *>(need_list);
+        if (half) tmp[qq] = th;
+        __syncthreads();
+        if (!half) {
+            th = fmaxf(th, tmp[qq]);
+            if (th < tau[qq]) { // rows with key > th cannot be among the kl best of the corpus; key == th stays in
+                tau[qq] = th;
+                tau_id[qq] = 0xffffffffu;
+            }
+        }
+    };
+    if (!SEED && p.fb_seeded && p.g_pub) { // thresholds of the seed launch
+        read_published();
+        __syncthreads();
+    }
 
     uint32_t g = 0; // slabs computed so far: buffer parity
     if (row_begin < row_end) {
@@ -222,12 +284,14 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             }
             __syncthreads();
         }
+        if (FB_DBG & 4u) { // (measurement build without MFMAs: the accumulators still need a value)
 #pragma unroll
-        for (int ab = 0; ab < 4; ab++)
+            for (int ab = 0; ab < 4; ab++)
 #pragma unroll
-            for (int bb = 0; bb < 2; bb++)
+                for (int bb = 0; bb < 2; bb++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
+                    for (int r = 0; r < 16; r++) acc[ab][bb][r] = 0.f;
+        }
         read_frags(0, g & 1u, 0); // the tile's first slab landed behind the last barrier
 
         // One slab: the fragments of its first K step are already in set 0 (read behind the previous slab's barrier).
@@ -236,7 +300,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         //   step 2: read step 3 -> set 1 |                                 | MFMAs of set 0
         //   drain the DMA, barrier (every LDS read of this slab has returned: the buffer may be refilled)
         //   step 3: read step 0 of the NEXT slab -> set 0                  | MFMAs of set 1
-        for (uint32_t s = 0; s < nslab; s++, g++) {
+        auto slab_step = [&](const uint32_t s, auto first_tag) { // first_tag: the tile's first slab (compile-time: its first K step starts the accumulators)
             const uint32_t buf = g & 1u;
             const bool dma_same = s + 1 < nslab, dma_next = !dma_same && has_next;
             const bool dma = (dma_same || dma_next) && !(FB_DBG & 2u);
@@ -255,7 +319,8 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             read_frags(1, buf, 1);
             if (dma) issue_rows(buf ^ 1u, nslab_i);
             FB_SB();
-            mfma_step(0);
+            if constexpr (decltype(first_tag)::value) mfma_step_first(0); // (accumulators start here: no zeroing pass)
+            else mfma_step(0);
             FB_SB();
             read_frags(0, buf, 2);
             if (dma) issue_queries(buf ^ 1u, nslab_i);
@@ -280,7 +345,10 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             FB_SB();
             mfma_step(1);
             FB_SB();
-        }
+            g++;
+        };
+        slab_step(0u, std::true_type{});
+        for (uint32_t s = 1; s < nslab; s++) slab_step(s, std::false_type{});
 
         // ---- selection.  acc[ab][bb][r]: query wn*64 + bb*32 + l31, row wm*128 + ab*32 + (r&3) + 8*(r>>2) + 4*hi.
         // Scores s = -key (larger is better): the raw dot (cosine), 2 q.x - ||x||^2 (L2), dot/||x|| (int8).
@@ -290,6 +358,49 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         // Phase B, all 64 lanes on 4 dumped blocks at a time (16 lanes per block): exact test against the threshold
         // (total order key, id), one LDS atomic per survivor for its place in the query's list, two scattered stores.
         // The cost of a tile follows the number of survivors, not the number of lanes that hold one.
+        if (SEED) { // seed launch: publish a key that >= pub_rank rows of this tile reach, per query (see the header comment)
+            float gmax[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int ab = 0; ab < 4; ab++) {
+                float nr[16];
+                if (NEED_NORM) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const float4 x = *reinterpret_cast<const float4 *>(sel_nrm + tp * FB_T + wm * 128 + ab * 32 + gq * 8 + hi * 4);
+                        nr[gq * 4 + 0] = x.x;
+                        nr[gq * 4 + 1] = x.y;
+                        nr[gq * 4 + 2] = x.z;
+                        nr[gq * 4 + 3] = x.w;
+                    }
+                }
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { // the very scores the selection forms (fmaxf drops NaNs)
+                        float sc = acc[ab][bb][r];
+                        if (NEED_NORM) {
+                            if (PREC == KDB_PREC_I8) sc = (float)__float_as_int(sc) * (nr[r] == 0.f ? 0.f : 1.0f / nr[r]);
+                            else sc = __builtin_fmaf(2.0f, sc, -nr[r]);
+                        }
+                        m = fmaxf(m, sc);
+                    }
+                    if (pub_rank > 4u) atomicMin(&l_cnt[wn * 64 + bb * 32 + l31], fb_ord(m)); // sixteen disjoint blocks per query
+                    gmax[bb] = fmaxf(gmax[bb], m);
+                }
+            }
+            if (pub_rank <= 4u) {
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) atomicMin(&l_cnt[wn * 64 + bb * 32 + l31], fb_ord(gmax[bb])); // four disjoint lanes per query
+            }
+            __syncthreads();
+            if (tid < FB_T && q0 + (uint32_t)tid < p.B) {
+                const float sc = fb_unord(l_cnt[tid]);
+                if (sc > -INFINITY) // (every group saw a finite score)
+                    __hip_atomic_store(p.g_pub + (size_t)stripe * qstride + q0 + (uint32_t)tid, -sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         if (FB_DBG & 1u) continue;
         bool appended = false;
         const unsigned long long tm0 = (FB_DBG & 32u) ? __builtin_readcyclecounter() : 0ull;
@@ -315,6 +426,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                             const uint32_t rid = p.scan_ids ? sel_id[tp * FB_T + rloc] : rpos + 1u;
                             if (fs_better(key, rid, tk, ds.y) && !(FB_DBG & 16u)) {
                                 const uint32_t pos = atomicAdd(&l_cnt[qq], 1u); // < cap: see the header comment
+                                if (pos + 1u + (uint32_t)FB_T > cap) flags[2] = 1u; // the next tile could overflow this list: compaction round now
                                 const size_t lb = list0 + (size_t)qq * cap;
                                 p.part_key[lb + pos] = key;
                                 p.part_id[lb + pos] = rid;
@@ -384,18 +496,19 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             if (n_dump) phase_b();
         }
         if (appended) flags[0] = 1u;
-        if (FB_DBG & 32u) tm_sel += __builtin_readcyclecounter() - tm0;
+        const bool tm_on = (FB_DBG & 32u) && (!(FB_DBG & 1024u) || t >= 32u); // 1024: tiles 32.. only (thresholds settled)
+        if (tm_on) tm_sel += __builtin_readcyclecounter() - tm0;
         const unsigned long long tm1 = (FB_DBG & 32u) ? __builtin_readcyclecounter() : 0ull;
         // ---- compaction round, every fb_period tiles: the lists that outgrew kl + fb_slack are cut back to their kl best
         //      and the thresholds follow.  All eight waves share the work (a compaction is a dependent round trip to the
         //      list in HBM scratch plus a 32-step search: the whole workgroup waits for the slowest wave at the next barrier).
-        // Between selection and the next tile only LDS has to be settled (list lengths, the dump scratch): the appends to the
-        // lists in HBM scratch are read again by a compaction round at the earliest, and that round -- like the hand-over at
-        // the end -- starts with a full __syncthreads().  A plain s_waitcnt lgkmcnt(0) + s_barrier lets the store acknowledgements
-        // (vmcnt counts stores on gfx9) return behind the first MFMA steps of the next tile instead of in front of them.
-        const bool compact_now = (t == 0u || (t + 1u) % p.fb_period == 0u) && has_next;
-        if (compact_now || !has_next || p.fb_fullsync) __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete; the dump scratch is free again
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __syncthreads(); // appends (LDS counts, list entries in HBM scratch) are complete; the dump scratch is free again
+        // (a lighter barrier here -- s_waitcnt lgkmcnt(0) + s_barrier, the store acknowledgements returning behind the next
+        //  tile's first MFMA steps -- measured no different: 12.25 vs 12.26 ms)
+        uint32_t per = p.fb_period;
+        if (p.fb_grow) per = t < 64u ? per : t < 128u ? 2u * per : t < 256u ? 4u * per : 8u * per; // (powers of two: rounds stay aligned)
+        const bool compact_now = ((t == 0u && !p.fb_seeded) || (t + 1u) % per == 0u || flags[2] != 0u) && has_next;
+        if (tm_on && (FB_DBG & 2048u)) tm_cmp += __builtin_readcyclecounter() - tm1; // 2048: the wait at this barrier alone
         if (compact_now) { // (the first tile keeps everything: thresholds start open)
             if (flags[0] && !(FB_DBG & 8u)) {
                 if (tid < FB_T && l_cnt[tid] > p.kl + p.fb_slack) need_list[atomicAdd(&flags[1], 1u)] = (uint32_t)tid;
@@ -419,35 +532,11 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
                     }
                 }
                 __syncthreads(); // need_list and its length may be reused
-                if (tid == 0) { flags[0] = 0u; flags[1] = 0u; }
+                if (tid == 0) { flags[0] = 0u; flags[1] = 0u; flags[2] = 0u; }
             }
-            if (p.g_pub) { // shared threshold: the largest of the stripes' published keys bounds the GLOBAL kl-th best key
-                const uint32_t qq = (uint32_t)tid & (FB_T - 1u), half = (uint32_t)tid >> 8; // two threads per query, every other stripe each
-                float th = -INFINITY;
-                const float *src = p.g_pub + q0 + qq;
-                for (uint32_t s0 = half; s0 < geo.n_stripes; s0 += 16u) { // eight loads in flight, then their maximum
-                    float x[8];
-#pragma unroll
-                    for (uint32_t u = 0; u < 8u; u++) {
-                        const uint32_t s2 = s0 + 2u * u < geo.n_stripes ? s0 + 2u * u : s0;
-                        x[u] = __hip_atomic_load(src + (size_t)s2 * qstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 8u; u++) th = fmaxf(th, x[u]);
-                }
-                float *tmp = reinterpret_cast<float *>(need_list);
-                if (half) tmp[qq] = th;
-                __syncthreads();
-                if (!half) {
-                    th = fmaxf(th, tmp[qq]);
-                    if (th < tau[qq]) { // rows with key > th cannot be among the kl best of the corpus; key == th stays in
-                        tau[qq] = th;
-                        tau_id[qq] = 0xffffffffu;
-                    }
-                }
-            }
+            if (p.g_pub) read_published();
         }
-        if (FB_DBG & 32u) tm_cmp += __builtin_readcyclecounter() - tm1;
+        if (tm_on && !(FB_DBG & 2048u)) tm_cmp += __builtin_readcyclecounter() - tm1;
     }
     if ((FB_DBG & 32u) && p.ctr && lane == 0) { // per-wave cycle totals: selection phases, compaction rounds (with their barriers)
         atomicAdd(p.ctr + 2, tm_sel);
