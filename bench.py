@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline leg (no batch sweep, flat leg, iid corpus, PMC passes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--legs", default="", help="comma-separated names of the side legs to run (default: all), e.g. flat_scan_leg,corpus_iid")
     ap.add_argument("--flat-batch", type=int, default=8192, help="queries of the flat-scan leg")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) or gloo (test rigs: several ranks on one GPU)")
     ap.add_argument("--direct", action="store_true", help=argparse.SUPPRESS)
@@ -426,6 +427,8 @@ def main():
                          ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev)),
                          ("reference_benchmark_shapes", lambda: reference_shapes_leg(K, dev)),
                          ("baseline_configs_2_and_4", lambda: big_configs_leg(K, dev))):
+            if a.legs and name not in a.legs.split(","):
+                continue
             try:
                 res[name] = fn()
             except Exception as e:  # never lose the headline
@@ -846,7 +849,19 @@ def flat_leg(idx, Q, k, n, dim, FB, dev):
         idx.flat_scan_batch_dev(q, k, *o)
     idx.sync()
     wall = (time.perf_counter() - t0) / reps
-    ms = float(np.mean([c["kernel_ms"] for c in idx.launch_stats(reps)]))
+    st = idx.launch_stats(reps)
+    ms = float(np.mean([c["kernel_ms"] for c in st]))
+    exact_pass = [int(c["n_hops"]) & 0xffffffff for c in st]   # queries the f16 band could not settle (exact f32 pass)
+    rescue_pass = [int(c["n_hops"]) >> 32 for c in st]          # ... and the rounding band could not either (rescue pass)
+    per_call = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        idx.flat_scan_batch_dev(q, k, *o)
+        t2 = time.perf_counter()
+        idx.sync()
+        per_call.append((round((t2 - t1) * 1e3, 3), round((time.perf_counter() - t1) * 1e3, 3)))
+    log(f"[bench] flat leg: kernel {ms:.2f} ms, call {wall * 1e3:.2f} ms, exact-pass queries {exact_pass}, rescue {rescue_pass}, "
+        f"(host ms in the call, ms to completion) x3 {per_call}")
     flops = 2.0 * FB * n * dim
     tf = flops / (ms * 1e-3) / 1e12
     # small batches (<= 32 queries: the streaming kernel, 16 queries per pass over the half-precision row copy): HBM-bound
@@ -869,6 +884,7 @@ def flat_leg(idx, Q, k, n, dim, FB, dev):
         "workload": f"exact flat scan, {FB} queries x {n}x{dim} cosine k={k} (f16-ranked on the matrix cores inside a rigorous error "
                     f"band, finalists re-scored in f32: answers identical to the f32 scan)",
         "qps": round(FB / wall, 1), "ms_per_batch": round(wall * 1e3, 3),
+        "queries_settled_by_the_exact_f32_pass": exact_pass[-1], "queries_settled_by_the_rescue_pass": rescue_pass[-1],
         "roofline": {"kernel": "flat_scan_big_kernel<cosine,f16-ranked>", "bound": "mfma", "achieved": round(tf, 1),
                      "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / F16_MFMA_PEAK_TF, 4), "traffic": None,
                      "kernel_ms": round(ms, 3), "algorithmic_flop_per_launch": flops,

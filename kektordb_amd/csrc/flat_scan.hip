@@ -62,6 +62,9 @@ struct FsParams {
     // exact pass over those queries: how many there are (device), where their results go
     const uint32_t *b_dev;
     const uint32_t *q_map;
+    // ... in two tiers: a launch with b_le != 0 works only when *b_dev <= b_le (a handful of unsettled queries: the streaming
+    // kernel, HBM-bound, every CU), one with b_gt != 0 only when *b_dev > b_gt (many: the tile kernel).  0 = no condition.
+    uint32_t b_le, b_gt;
     // grouped scan, ranked: unsettled queries are marked in place (their group's id list is needed again)
     uint32_t *q_flag, *tile_flag;   // band merge writes: query / its 16-query tile needs the exact pass
     const uint32_t *q_tile;         // [B] tile of every query
@@ -271,7 +274,10 @@ flat_scan_kernel(KdbView v, const float *__restrict__ queries /*[>=n_qtiles*128]
     const FsGeom geo = fs_resolve(p);
     if (bid == 0 && threadIdx.x == 0 && p.ctr) p.ctr[0] = geo.n_scan;
     if (stripe >= geo.n_stripes) return;
-    if (p.b_dev && qtile * FS_TQ >= *p.b_dev) return; // exact pass: only the query tiles that hold unsettled queries
+    if (p.b_dev) { // exact pass: only the query tiles that hold unsettled queries (and only this tier's share of the cases)
+        const uint32_t nb = *p.b_dev;
+        if (qtile * FS_TQ >= nb || (p.b_gt && nb <= p.b_gt) || (p.b_le && nb > p.b_le)) return;
+    }
 
     const uint32_t row_begin = stripe * geo.rows_per_stripe;
     uint32_t row_end = row_begin + geo.rows_per_stripe;
@@ -683,6 +689,7 @@ flat_scan_small_kernel(KdbView v, const float *__restrict__ queries, FsParams p,
     if (!p.g_tile) {
         const uint32_t Beff = p.b_dev ? *p.b_dev : p.B; // exact pass of the ranked scan: only the unsettled queries
         if (q0 >= Beff) return;
+        if (p.b_dev && ((p.b_gt && Beff <= p.b_gt) || (p.b_le && Beff > p.b_le))) return; // (the other tier's case)
         nq = Beff - q0 < (uint32_t)FSS_TQ ? Beff - q0 : (uint32_t)FSS_TQ;
     }
     FsGeom geo;
@@ -1036,7 +1043,10 @@ flat_merge_kernel(KdbView v, const float *__restrict__ queries, const float *__r
         if (q >= *p.rs_count) return;
         q = p.rs_list[q];
     } else {
-        if (p.b_dev && q >= *p.b_dev) return;           // exact pass over the unsettled queries only
+        if (p.b_dev) {                                   // exact pass over the unsettled queries only
+            const uint32_t nb = *p.b_dev;
+            if (q >= nb || (p.b_gt && nb <= p.b_gt) || (p.b_le && nb > p.b_le)) return;
+        }
         if (p.q_sel && !p.q_sel[q]) return;             // (grouped scan: marked in place)
     }
     const uint32_t qo = p.q_map ? p.q_map[q] : q;       // where this query's answer goes
@@ -1927,6 +1937,21 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     }
     const size_t n_qpad = (size_t)(big ? fb_nqt * FB_T : n_qtiles * FS_TQ); // query rows the ranking kernels may touch (d_q holds >= as many)
     const size_t qp_bytes = (rank16 && copy_padded) ? ((n_qpad * vr.ld * 4 + 255) & ~(size_t)255) : 0;
+    // exact pass, first tier: up to FS_FEW unsettled queries go through the streaming kernel (16 queries per workgroup, the
+    // rows read at HBM speed by every CU) -- the tile kernel gives ONE query tile a handful of stripes: a single unsettled
+    // query of an 8192-query batch cost 78 ms behind a 12 ms ranking scan (seen once in five calls on the clustered corpus)
+    constexpr uint32_t FS_FEW = 64;
+    const bool few_tier = rank16 && !small && lds_s <= 150u * 1024u;
+    uint32_t want_few = 512u / (FS_FEW / (uint32_t)FSS_TQ);
+    if (want_few > stripes_max) want_few = stripes_max;
+    {
+        const uint32_t max_tiles = (v.count + FS_TR - 1) / FS_TR;
+        const uint32_t lim = (max_tiles + 3u) / 4u;
+        if (want_few > lim) want_few = lim;
+        if (want_few < 1u) want_few = 1u;
+    }
+    const size_t n_part_few = (size_t)want_few * FS_TQ; // one 128-query block of lists per stripe
+    if (few_tier && n_part_few * kl * 8 + n_part_few * 4 + 1024 > part_bytes) part_bytes = n_part_few * kl * 8 + n_part_few * 4 + 1024;
     const size_t fbl_bytes = rank16 ? (((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255) : 0;        // their indices
     const size_t rsl_bytes = ((size_t)n_qtiles * FS_TQ * 4 + 255) & ~(size_t)255; // queries handed to the rescue pass
     int rc = kdb_ensure_scratch(idx, ids_bytes + 256 + fbq_bytes + fbl_bytes + rsl_bytes + part_bytes + qp_bytes + 4096);
@@ -2136,6 +2161,31 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p2.fb_list = nullptr;
         p2.rows16 = nullptr;
         p2.q16 = nullptr;
+        if (few_tier) { // first tier: *d_fbcount <= FS_FEW (both launches return at once otherwise, and when nothing is unsettled)
+            FsParams ps = p2;
+            ps.want = want_few;
+            ps.min_tiles = 4u;
+            ps.tile_rows = 0u;
+            ps.n_qtiles = 1u;
+            ps.cap = kl;
+            ps.part_key = reinterpret_cast<float *>(part);
+            ps.part_id = reinterpret_cast<uint32_t *>(part + n_part_few * kl * 4);
+            ps.part_cnt = reinterpret_cast<uint32_t *>(part + n_part_few * kl * 8);
+            ps.lists_query_major = 1u;
+            ps.g_pub = nullptr;
+            ps.part_thr = nullptr;
+            ps.b_le = FS_FEW;
+            p2.b_gt = FS_FEW; // the tile kernel and its merge take the rest
+            auto kf = v.metric == KDB_METRIC_COSINE ? fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld) : fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld);
+            const uint32_t nq16_few = FS_FEW / (uint32_t)FSS_TQ;
+            KDB_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            hipLaunchKernelGGL(kf, dim3((want_few + 7u) / 8u * 8u * nq16_few), dim3(256), lds_s, s, v, reinterpret_cast<const float *>(d_fbq), ps, nq16_few, cap_s);
+            KDB_HIP(hipGetLastError());
+            if (v.metric == KDB_METRIC_COSINE) rc = launch_merge(flat_merge_kernel<KDB_METRIC_COSINE, KDB_PREC_F32, FM_ROUND>, ps, d_fbq);
+            else rc = launch_merge(flat_merge_kernel<KDB_METRIC_L2, KDB_PREC_F32, FM_ROUND>, ps, d_fbq);
+            if (rc) return rc;
+            KDB_HIP(hipGetLastError());
+        }
         if (small) {
             if (v.metric == KDB_METRIC_COSINE) rc = launch_small_on(fss_kernel_for<KDB_METRIC_COSINE, KDB_PREC_F32>(v.ld), p2, d_fbq, lds_s);
             else rc = launch_small_on(fss_kernel_for<KDB_METRIC_L2, KDB_PREC_F32>(v.ld), p2, d_fbq, lds_s);
