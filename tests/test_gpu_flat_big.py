@@ -91,6 +91,23 @@ def test_flat_scan_big_tile_vs_oracle(oracle, hip, metric, prec, n, dim, k, B):
     _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, B, 29)) + [B - 1], prec, allow=ab)
 
 
+@pytest.mark.parametrize("metric,prec,n,dim,k,B", [CASES[0], CASES[2], CASES[3], CASES[5], CASES[7], (1, 0, 30000, 100, 10, 700)])
+def test_flat_scan_big_tile_seed_launch_on_small_cases(oracle, hip, metric, prec, n, dim, k, B, monkeypatch):
+    """the seed launch (first tile of every stripe publishes first thresholds; by default only stripes of 32 tiles and more
+    get one) forced onto the small cases: per-lane maxima (a stripe's share of the kl best <= 4) and block maxima (k = 100 /
+    128 over few stripes: share up to 16), float32 ranking copy, float16 and int8 rows, two-slab rows -- same answers as the
+    oracle, bit for bit"""
+    monkeypatch.setenv("KDB_FB_SEED_MIN_TILES", "1")
+    O = oracle
+    X = make_corpus(n, dim, "normal", seed=151)
+    if prec == O.F16:
+        X = X * 0.5
+    orc, idx = _pair(O, hip, X, metric, prec)  # (no deleted rows: they switch the seed launch off -- the row count stays on the device)
+    Q = make_corpus(B, dim, "normal", seed=152)
+    ids, dist, cnt = idx.flat_scan_batch(Q, k)
+    _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, B, 5)) + [255, 256, B - 1], prec)
+
+
 @pytest.mark.parametrize("metric", [1, 0])
 @pytest.mark.parametrize("case", ["near_duplicates", "dense_block"])
 def test_flat_scan_big_tile_band(oracle, hip, metric, case):
