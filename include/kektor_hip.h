@@ -389,6 +389,10 @@ KDB_API int kdb_cluster_debug_fail_next(kdb_cluster *c, uint32_t stage);
  * bench.py reports its roofline fractions against these beside the nominal HBM peak.  Blocking.              */
 KDB_API int kdb_probe_gather(kdb_index *idx, int which, uint64_t n_reads, float *ms, uint64_t *bytes);
 KDB_API int kdb_probe_stream(kdb_index *idx, int which, float *ms, uint64_t *bytes);
+/* TEST HOOK (probe.hip): fills the LDS of every CU with `pattern` (0 = a pseudo-random word per address) on the index's stream and
+ * waits.  LDS keeps what the previous kernel left; called between launches it makes a kernel that reads LDS it never wrote show
+ * (the parity tests of the exact scan use it: a race of that kind survived the suite until HBM and LDS were poisoned).  Blocking. */
+KDB_API int kdb_probe_poison_lds(kdb_index *idx, uint32_t pattern);
 
 KDB_API int kdb_get_counters(kdb_index *idx, kdb_counters *out);
 /* Statistics of the last `last_n` (<= 64) search / flat-scan / distance launches, oldest first: each

@@ -170,3 +170,27 @@ extern "C" int kdb_probe_stream(kdb_index *idx, int which, float *ms, uint64_t *
     *bytes = total / 16 * 16;
     return KDB_OK;
 }
+
+// TEST HOOK: fills the LDS of every CU with a pattern (one workgroup of 160 KB per CU at a time, several rounds), on the index's
+// stream.  LDS is not cleared between kernels: a kernel that reads a word of LDS before writing it sees whatever the previous
+// kernel left -- usually its own previous launch, i.e. plausible values.  Called between launches, this makes such a read show.
+__global__ void __launch_bounds__(256) lds_poison_kernel(uint32_t pattern, uint32_t words, uint32_t *sink) {
+    extern __shared__ uint32_t lds_words[];
+    for (uint32_t i = threadIdx.x; i < words; i += 256u) lds_words[i] = pattern ? pattern : (i * 2654435761u) ^ (blockIdx.x * 40503u);
+    __syncthreads();
+    if (threadIdx.x == 0 && lds_words[(blockIdx.x * 97u) % words] == 0x5eed5eedu) sink[0] = 1u; // (keeps the stores alive)
+    // a little dwell time, so that the workgroups of one round spread over all CUs instead of queueing on a few
+    for (int i = 0; i < 64; i++) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int kdb_probe_poison_lds(kdb_index *idx, uint32_t pattern) {
+    if (!idx) return KDB_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    KDB_HIP(hipSetDevice(idx->device));
+    constexpr uint32_t LDS_BYTES = 160u * 1024u;
+    KDB_HIP(hipFuncSetAttribute((const void *)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    hipLaunchKernelGGL(lds_poison_kernel, dim3((uint32_t)idx->n_cu * 4u), dim3(256), LDS_BYTES, idx->stream, pattern, LDS_BYTES / 4u, idx->d_work + 13);
+    KDB_HIP(hipGetLastError());
+    KDB_HIP(hipStreamSynchronize(idx->stream));
+    return KDB_OK;
+}

@@ -355,6 +355,10 @@ class HipIndex:
         check(self.L.kdb_probe_gather(self.h, 1 if shadow else 0, n_reads, C.byref(ms), C.byref(nbytes)), "kdb_probe_gather")
         return nbytes.value / (ms.value * 1e-3) / 1e9
 
+    def poison_lds(self, pattern: int = 0):
+        """test hook: every CU's LDS filled with `pattern` (0 = pseudo-random words) -- a kernel that reads LDS it never wrote shows"""
+        check(self.L.kdb_probe_poison_lds(self.h, int(pattern) & 0xffffffff), "kdb_probe_poison_lds")
+
     def probe_stream(self, shadow: bool = False):
         """measurement hook: GB/s of one coalesced pass over this index's rows (or its half-precision copy)"""
         ms, nbytes = C.c_float(), C.c_uint64()

@@ -200,3 +200,30 @@ def test_flat_scan_big_tile_two_slab_rows_between_builds(hip, dim):
         assert np.array_equal(got[0], want[0]), rnd
         assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), rnd
         idx.Close()
+
+
+@pytest.mark.parametrize("metric,prec,n,dim,k,B", [(1, 0, 9000, 100, 10, 520), (0, 0, 9000, 128, 10, 300), (1, 0, 9000, 64, 10, 300),
+                                                   (1, 0, 9000, 768, 10, 300), (0, 1, 9000, 128, 10, 300), (1, 2, 9000, 256, 10, 300)])
+def test_scans_and_walks_after_poisoned_lds(oracle, hip, metric, prec, n, dim, k, B, monkeypatch):
+    """LDS keeps what the previous kernel left; `kdb_probe_poison_lds` fills every CU's LDS with garbage right before each
+    launch, so a kernel that reads a word of LDS it never wrote (the two-slab race read row ids that way) cannot pass by luck:
+    one-, two- and many-slab rows through the big-tile kernel (seed launch forced on), the 128 x 128 tile kernel, the streaming
+    kernel, and the graph walk -- all against the oracle"""
+    monkeypatch.setenv("KDB_FB_SEED_MIN_TILES", "1")
+    O = oracle
+    X = make_corpus(n, dim, "normal", seed=161)
+    if prec == O.F16:
+        X = X * 0.5
+    orc, idx = _pair(O, hip, X, metric, prec)
+    Q = make_corpus(B, dim, "normal", seed=162)
+    for pattern, nb in ((0, B), (0xffffffff, B), (0x01010101, 48), (0, 16), (0x7fc00000, 1)):
+        idx.poison_lds(pattern)
+        ids, dist, cnt = idx.flat_scan_batch(Q[:nb], k)
+        _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, nb, 7)) + [nb - 1], prec)
+    if prec == O.F32:
+        idx.poison_lds(0)
+        ids, dist, cnt = idx.search_batch(Q[:64], k, 40)
+        for b in range(0, 64, 5):
+            oi, od = orc.search(Q[b], k, ef=40)
+            c = int(cnt[b])
+            assert np.array_equal(ids[b, :c], oi), b
