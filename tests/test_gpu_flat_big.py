@@ -206,7 +206,9 @@ def test_flat_scan_big_tile_two_slab_rows_between_builds(hip, dim):
                                                    (1, 0, 9000, 768, 10, 300), (0, 1, 9000, 128, 10, 300), (1, 2, 9000, 256, 10, 300)])
 def test_scans_and_walks_after_poisoned_lds(oracle, hip, metric, prec, n, dim, k, B, monkeypatch):
     """LDS keeps what the previous kernel left; `kdb_probe_poison_lds` fills every CU's LDS with garbage right before each
-    launch, so a kernel that reads a word of LDS it never wrote (the two-slab race read row ids that way) cannot pass by luck:
+    launch, so a kernel that reads a word of LDS it never wrote sees garbage instead of its own previous launch's plausible values
+    (a race must still be LOST to show: the two-slab race was lost about once in 10^5 tile steps -- these small cases pass on a
+    build that has it; see test_two_slab_rows_full_size_rounds):
     one-, two- and many-slab rows through the big-tile kernel (seed launch forced on), the 128 x 128 tile kernel, the streaming
     kernel, and the graph walk -- all against the oracle"""
     monkeypatch.setenv("KDB_FB_SEED_MIN_TILES", "1")
@@ -227,3 +229,40 @@ def test_scans_and_walks_after_poisoned_lds(oracle, hip, metric, prec, n, dim, k
             oi, od = orc.search(Q[b], k, ef=40)
             c = int(cnt[b])
             assert np.array_equal(ids[b, :c], oi), b
+
+
+def test_two_slab_rows_full_size_rounds(hip):
+    """bench.py --shapes' first shape (400k x 100 float32 cosine rows = two-slab ranking copy, 8192 queries) for 16 rounds of
+    build -> poisoned LDS -> exact scan on a fresh index each: the answers of every round equal round 0's.  A statistical net, not a detector: a build with
+    the two-slab race (row ids of the next tile stored behind the first slab's barrier) faulted in round 5 and in round 11 of two
+    40-round runs of scripts/shapes_fault_loop.py, and passed these 16 rounds once -- the race has to be lost to show."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, dim, B, k = 400_000, 100, 8192, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + dim)
+    cent = torch.randn((4096, dim), device=dev, generator=g)
+    X = cent[torch.randint(0, 4096, (n,), device=dev, generator=g)] + 0.3 * torch.randn((n, dim), device=dev, generator=g)
+    Q = cent[torch.randint(0, 4096, (B,), device=dev, generator=g)] + 0.3 * torch.randn((B, dim), device=dev, generator=g)
+    X = (X / X.norm(dim=1, keepdim=True)).contiguous()
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    o = (torch.zeros((B, k), dtype=torch.int32, device=dev), torch.zeros((B, k), dtype=torch.float32, device=dev),
+         torch.zeros((B,), dtype=torch.int32, device=dev))
+    want = None
+    for rnd in range(16):
+        junk = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+        junk.random_(-2**31, 2**31 - 1)
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
+        idx = hip.HipIndex(dim, hip.COSINE, hip.F32, 16, 200, capacity=n)
+        idx.upload_rows(X, 1)
+        idx.build(n, batch=16384, ef_construction=200, seed=5)
+        idx.poison_lds(0 if rnd % 2 else 0x01010101)
+        idx.flat_scan_batch_dev(Q, k, *o)
+        idx.sync()
+        got = o[0].cpu().numpy().copy()
+        if want is None:
+            want = got
+        assert np.array_equal(got, want), rnd
+        idx.Close()
