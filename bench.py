@@ -816,7 +816,7 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
     idx.set_launch_timing(False)   # what a serving mirror runs (the host mirrors switch the per-launch events off)
     out = {}
     try:
-        for T, win in ((1, -1), (32, -1), (64, -1), (32, 50), (64, 50), (64, 150), (256, 150)):
+        for T, win in ((1, -1), (16, -1), (32, -1), (64, -1), (256, -1), (32, 0), (64, 0), (256, 0), (64, 150)):
             lat = np.zeros(T * per, dtype=np.float64)
             wall, nb, lg, ans = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
             rc = L.kdb_bench_one_query_callers(C.c_void_p(idx.h.value), idx.dim, idx.metric, idx.precision, q.ctypes.data_as(C.c_void_p), q.shape[0], k, ef,
@@ -825,8 +825,8 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
             lat = lat.reshape(T, per)[:, per // 10:]   # (the first tenth of every caller's calls: start-up)
             name = f"{T}_callers_" + ("direct_one_query_calls" if win < 0 else f"batcher_window_{win}us")
             out[name] = {"qps": round(T * per / wall.value, 1), "per_caller_p50_ms": round(float(np.percentile(lat, 50)) / 1e3, 4),
-                         "per_caller_p99_ms": round(float(np.percentile(lat, 99)) / 1e3, 4), "gpu_calls": int(nb.value) if win >= 0 else T * per,
-                         "largest_batch": int(lg.value) if win >= 0 else 1, "answers_per_call": round(ans.value / (T * per), 2)}
+                         "per_caller_p99_ms": round(float(np.percentile(lat, 99)) / 1e3, 4), "gpu_calls": int(nb.value),
+                         "largest_batch": int(lg.value), "answers_per_call": round(ans.value / (T * per), 2)}
     finally:
         idx.set_launch_timing(True)
         try:

@@ -32,11 +32,18 @@
  *     calling thread is available from kdb_last_error(); nothing throws or unwinds across the ABI;
  *   - the caller owns every buffer it passes; host inputs are consumed before the call returns
  *     (cgo rule: Go memory need not stay pinned after the call);
- *   - handles are opaque, usable from any thread; calls on one handle are serialised internally (the enqueue: the *_dev
- *     entry points are asynchronous on the stream they are given).  An index keeps two sets of per-call scratch: a *_dev
- *     call on a stream other than the one that last used its set first waits -- on the device -- for that use, so two
- *     streams run concurrently without sharing scratch and any number of streams is SAFE.  Uploads, kdb_index_mark_deleted
- *     and kdb_index_set_entry are snapshots for kernels that were already launched;
+ *   - handles are opaque, usable from any thread, and CONCURRENT callers are served concurrently, as the reference's
+ *     read lock allows (hnsw_index.go:343-352; pkg/engine/ops.go:1003-1007 calls SearchWithScores from a goroutine per
+ *     request).  The host-pointer entry points (kdb_search_batch, kdb_flat_scan_batch, kdb_distance_batch) hold the handle's
+ *     lock only to pick one of KDB_SLOTS (8, at most 16) slots -- a stream and a pair of staging buffers -- and to enqueue;
+ *     they wait for their answers outside it.  One-query callers that find every slot busy are combined: calls of up to
+ *     KDB_COMBINE_MAX_B (16) queries with the same (k, ef, flags) and no allow list leave as ONE launch as soon as a slot is
+ *     free (no window, no timer: a lone caller never waits); kdb_index_caller_stats counts launches and the calls they carried.
+ *     Writers -- uploads, kdb_index_mark_deleted, kdb_index_set_entry, build / add_batch, reserve, destroy -- wait until no
+ *     host-pointer call is in flight and hold new ones back meanwhile (the reference's write lock).  The *_dev entry points
+ *     are asynchronous on the stream they are given; the index keeps a set of per-call scratch per stream in use (up to 18):
+ *     a *_dev call on a stream other than the one that last used its set first waits -- on the device -- for that use, so
+ *     any number of streams is SAFE; for kernels already launched on a caller's stream a writer's change is a snapshot;
  *   - ids are the reference's internal ids: uint32, 1-based, id 0 never names a vector
  *     (hnsw_index.go:590); at most 2^30-1 ids per index;
  *   - distances are returned as the RAW f32 accumulate: sum (q-x)^2 for KDB_METRIC_L2, the dot
@@ -402,6 +409,10 @@ KDB_API int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counters *
 /* The graph-search launches are bracketed by two HIP events (kdb_counters.last_kernel_ms).  on = 0 drops them: two packets
  * less in the queue per call (9 us of a small-batch call); the counters stay, last_kernel_ms reads 0.  Default: on. */
 KDB_API int kdb_index_set_launch_timing(kdb_index *idx, int on);
+/* Statistics of the concurrent host-pointer calls (see "Conventions"): out[0] launches that left through a slot, out[1] the calls
+ * they carried (out[1] / out[0] = callers per launch), out[2] the largest number of queries one launch carried, out[3] the
+ * number of slots of this index. */
+KDB_API int kdb_index_caller_stats(kdb_index *idx, uint64_t *out);
 /* Block until all work queued on the index's internal stream has finished. */
 KDB_API int kdb_index_sync(kdb_index *idx);
 

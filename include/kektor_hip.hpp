@@ -9,7 +9,9 @@
 // to an empty result exactly like the reference (":356-359 slog.Error + empty slice"); everything else
 // throws kektor::Error carrying kdb_last_error().
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <climits>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -20,6 +22,10 @@
 #include <string>
 #include <tuple>
 #include <vector>
+
+#include <linux/futex.h> // (the batcher's followers sleep on a futex word: Linux, like the library itself)
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "kektor_hip.h"
 
@@ -190,26 +196,34 @@ class Index {
 // the Go shim's hipBatcher, integration/go/hnsw_hip.go).  SearchWithScores keeps the contract of
 // hnsw.Index.SearchWithScores (hnsw_index.go:343-366): it blocks until the caller's answer is ready and returns an
 // empty slice on any error, on a stopped batcher and for a non-nil empty allow list.
-//   * callers that share (k, efSearch, allow-list object) share a group; the first caller of a group is its leader:
-//     it waits `window` for company (or until `maxBatch` callers joined), then for its turn on the device -- the group
-//     stays open while the previous group's call runs, so batches grow with the load -- runs ONE kdb_search_batch for
-//     the group and hands every caller its slice; no service thread, no timer thread;
+//   * callers that share (k, efSearch, allow-list object) share a group; the first caller of a group is its leader;
+//   * PIPELINED: up to `maxInFlight` (2) groups are on the device at once (the library serves concurrent calls from separate
+//     slots: include/kektor_hip.h, "Conventions").  A leader that finds a turn free goes AT ONCE -- a lone caller never sleeps;
+//     while every turn is taken its group stays open and grows for free, so batch size follows the load: everything that
+//     arrived during the calls in flight leaves with the next one.  `window` > 0 additionally makes a leader that finds the
+//     device idle wait that long for company (off by default);
+//   * followers sleep on their group's futex word and are woken by one FUTEX_WAKE -- no condition variable, no mutex to
+//     queue on when sixty answers arrive at once; no service thread, no timer thread;
 //   * a filter that allows less than `flatScanSelectivity` of the ids takes the exact scan: the reference's filtered
-//     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there.
+//     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there (the crossover is
+//     measured: bench.py's filter_routing leg).
 template <class IndexT>
 class BasicMicroBatcher {
   public:
     struct Options {
         uint32_t maxBatch = 8192;                     // queries per GPU call
-        std::chrono::microseconds window{150};        // how long a group's first caller waits for company
+        std::chrono::microseconds window{0};          // > 0: a leader that finds the device idle waits this long for company
         double flatScanSelectivity = 0.05;
+        uint32_t maxInFlight = 2;                     // GPU calls of this batcher on the device at once
     };
     struct Stats {
         uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
     };
     static constexpr int kMaxFlatK = 1024; // kdb_flat_scan_batch: k <= 1024
     explicit BasicMicroBatcher(IndexT &idx) : idx_(idx) {}
-    BasicMicroBatcher(IndexT &idx, const Options &o) : idx_(idx), opt_(o) {}
+    BasicMicroBatcher(IndexT &idx, const Options &o) : idx_(idx), opt_(o) {
+        if (opt_.maxInFlight == 0) opt_.maxInFlight = 1;
+    }
     ~BasicMicroBatcher() { Stop(); }
     BasicMicroBatcher(const BasicMicroBatcher &) = delete;
     BasicMicroBatcher &operator=(const BasicMicroBatcher &) = delete;
@@ -218,7 +232,7 @@ class BasicMicroBatcher {
     void Stop() {
         std::lock_guard<std::mutex> lk(mu_);
         closed_ = true;
-        for (auto &kv : groups_) kv.second->cv.notify_all();
+        turn_cv_.notify_all();
     }
     Stats stats() const {
         std::lock_guard<std::mutex> lk(mu_);
@@ -245,26 +259,26 @@ class BasicMicroBatcher {
         if (g->queries.size() >= opt_.maxBatch) { // full: later callers start the next group
             groups_.erase(key);
             g->sealed = true;
-            g->cv.notify_all();
+            if (!leader) turn_cv_.notify_all(); // (a leader waiting out its window)
         }
         if (!leader) {
-            g->cv.wait(lk, [&] { return g->done; });
-            return me < g->results.size() ? std::move(g->results[me]) : std::vector<SearchResult>();
+            lk.unlock();
+            g->wait_done();
+            return std::move(g->results[me]); // (results has one entry per member, always)
         }
         // (wait_until on the system clock = pthread_cond_timedwait, which thread sanitizers intercept; wait_for would use
         // pthread_cond_clockwait, invisible to GCC 11's TSan)
-        g->cv.wait_until(lk, std::chrono::system_clock::now() + opt_.window, [&] { return g->sealed || closed_; });
-        // one GPU call at a time: while the previous group's call runs, this group stays open and keeps growing
-        // (batch size adapts to the load: everything that arrived during one call goes into the next)
-        lk.unlock();
-        std::unique_lock<std::mutex> turn(exec_mu_);
-        lk.lock();
+        if (opt_.window.count() > 0 && inflight_ == 0)
+            turn_cv_.wait_until(lk, std::chrono::system_clock::now() + opt_.window, [&] { return g->sealed || closed_; });
+        // a turn on the device; while all are taken this group stays open and keeps growing
+        turn_cv_.wait(lk, [&] { return inflight_ < opt_.maxInFlight || closed_; });
         if (!g->sealed) {
             auto cur = groups_.find(key);
             if (cur != groups_.end() && cur->second == g) groups_.erase(cur);
             g->sealed = true;
         }
         const bool stopped = closed_;
+        if (!stopped) inflight_++;
         const uint32_t B = (uint32_t)g->queries.size(); // nobody can join a sealed group
         lk.unlock();
         std::vector<std::vector<SearchResult>> out;
@@ -296,14 +310,16 @@ class BasicMicroBatcher {
             }
         }
         lk.lock();
+        if (!stopped) inflight_--;
         stats_.batches++;
         if (flat) stats_.flatBatches++;
         if (B > stats_.largest) stats_.largest = B;
+        lk.unlock();
+        turn_cv_.notify_all(); // (leaders only: one per open group)
+        out.resize(B);
+        std::vector<SearchResult> mine = std::move(out[me]);
         g->results = std::move(out);
-        g->results.resize(B);
-        g->done = true;
-        std::vector<SearchResult> mine = std::move(g->results[me]);
-        g->cv.notify_all();
+        g->set_done();
         return mine;
     }
 
@@ -312,14 +328,23 @@ class BasicMicroBatcher {
     struct Group {
         std::vector<const float *> queries; // callers' buffers: they are blocked in SearchWithScores until done
         std::vector<std::vector<SearchResult>> results;
-        bool sealed = false, done = false;
-        std::condition_variable cv;
+        bool sealed = false;               // (under mu_)
+        std::atomic<uint32_t> done{0};     // futex word
+        void wait_done() {
+            while (done.load(std::memory_order_acquire) == 0u)
+                (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&done), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+        }
+        void set_done() {
+            done.store(1u, std::memory_order_release);
+            (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&done), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+        }
     };
     IndexT &idx_;
     Options opt_;
     mutable std::mutex mu_;
-    std::mutex exec_mu_; // taken before mu_, never while holding it
+    std::condition_variable turn_cv_; // leaders waiting for a turn (or out their window)
     std::map<Key, std::shared_ptr<Group>> groups_;
+    uint32_t inflight_ = 0;
     bool closed_ = false;
     Stats stats_;
 };

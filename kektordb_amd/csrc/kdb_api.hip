@@ -11,6 +11,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <limits.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include <algorithm>
 
 static thread_local char g_err[512] = "";
@@ -294,6 +298,15 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     KDB_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
     KDB_TRY(hipStreamCreateWithFlags(&idx->stream2, hipStreamNonBlocking));
     KDB_TRY(hipEventCreateWithFlags(&idx->ev_io, hipEventDisableTiming));
+    {   // slots of the concurrent host-pointer calls: their streams get the highest priority the device offers, so that a one-query
+        // walk is not queued behind the waves of a large batch
+        const char *e = getenv("KDB_SLOTS");
+        int ns = e ? atoi(e) : 8;
+        idx->n_slots = ns < 1 ? 1 : ns > KDB_MAX_SLOTS ? KDB_MAX_SLOTS : ns;
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        for (int i = 0; i < idx->n_slots; i++) KDB_TRY(hipStreamCreateWithPriority(&idx->slots[i].stream, hipStreamNonBlocking, prio_hi));
+    }
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         KDB_TRY(hipEventCreate(&idx->ring_ev0[i]));
         KDB_TRY(hipEventCreate(&idx->ring_ev1[i]));
@@ -335,6 +348,7 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
 
 extern "C" void kdb_index_destroy(kdb_index *idx) {
     if (!idx) return;
+    { KdbWriteLock w(idx); } // host-pointer calls still in flight finish first (Close waits for the read locks, hnsw_index.go:3533)
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     (void)hipDeviceSynchronize(); // callers' streams may still run kernels of this index
@@ -353,10 +367,14 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
         if (idx->ring_ev0[i]) (void)hipEventDestroy(idx->ring_ev0[i]);
         if (idx->ring_ev1[i]) (void)hipEventDestroy(idx->ring_ev1[i]);
     }
+    for (kdb_slot &sl : idx->slots) {
+        if (sl.d_io) (void)hipFree(sl.d_io);
+        if (sl.h_pin) (void)hipHostFree(sl.h_pin);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     if (idx->stream2) (void)hipStreamDestroy(idx->stream2);
     if (idx->ev_io) (void)hipEventDestroy(idx->ev_io);
-    if (idx->h_pin) (void)hipHostFree(idx->h_pin);
     delete idx;
 }
 
@@ -367,7 +385,7 @@ static int upload_rows_impl(kdb_index *idx, uint32_t first_id, uint32_t n, const
         kdb_set_error("upload_rows: ids %u..%llu outside 1..%u", first_id, (unsigned long long)first_id + n - 1, idx->cap);
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);
     if (lane.rc) return lane.rc;
@@ -434,7 +452,7 @@ extern "C" int kdb_index_upload_norms(kdb_index *idx, uint32_t first_id, uint32_
         kdb_set_error("upload_norms: bad id range");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     KDB_HIP(hipSetDevice(idx->device));
     KDB_HIP(hipMemcpyAsync(idx->d_norms + first_id, norms, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     KDB_HIP(hipStreamSynchronize(idx->stream));
@@ -460,7 +478,7 @@ extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
         kdb_set_error("set_count: %u exceeds capacity %u", count, idx->cap);
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     if (count != idx->count) idx->graph_epoch++; // the derived upper-slot table tests ids against count
     idx->count = count;
     return KDB_OK;
@@ -472,7 +490,7 @@ extern "C" int kdb_index_set_count(kdb_index *idx, uint32_t count) {
 // capacity: they are dropped and re-made by the next search.  No-op when the capacity is already that large.
 extern "C" int kdb_index_reserve(kdb_index *idx, uint32_t new_capacity) {
     KDB_CHECK_IDX(idx);
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     if (new_capacity <= idx->cap) return KDB_OK;
     if (new_capacity > KDB_ID_MASK - 1) {
         kdb_set_error("reserve: capacity %u exceeds the 2^30-1 ids of an index", new_capacity);
@@ -542,7 +560,7 @@ extern "C" int kdb_index_reserve(kdb_index *idx, uint32_t new_capacity) {
 // it again (or never, with refuse_for_good != 0 -- the effect of KDB_INDEX_NO_F16_SHADOW from then on).
 extern "C" int kdb_index_drop_f16_shadow(kdb_index *idx, int refuse_for_good) {
     KDB_CHECK_IDX(idx);
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     KDB_HIP(hipSetDevice(idx->device));
     if (idx->d_rows16) {
         KDB_HIP(hipDeviceSynchronize()); // scans of callers' streams may still rank on it
@@ -564,7 +582,7 @@ extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
         kdb_set_error("upload_graph: entry point %u outside 1..%u", g->entry, g->count);
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     idx->graph_epoch++; // (every writer of levels / up_idx / upper lists: the derived slot table is rebuilt by the next search)
     KDB_HIP(hipSetDevice(idx->device));
     const uint32_t n = g->count;
@@ -647,7 +665,7 @@ extern "C" int kdb_index_upload_graph(kdb_index *idx, const kdb_graph_view *g) {
 extern "C" int kdb_index_append_nodes(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels) {
     KDB_CHECK_IDX(idx);
     if (n == 0) return KDB_OK;
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     if (!levels || first_id != idx->count + 1 || (uint64_t)first_id + n - 1 > idx->cap) {
         kdb_set_error("append_nodes: ids must continue at count+1 = %u and stay within capacity %u", idx->count + 1, idx->cap);
         return KDB_ERR_INVALID;
@@ -708,7 +726,7 @@ extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_
         kdb_set_error("patch_adjacency: null buffer");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     if (level >= 1) idx->graph_epoch++; // level-0 lists are no input of the derived upper-slot table
     if (idx->h_levels.size() != (size_t)idx->count + 1) {
         kdb_set_error("patch_adjacency: no graph to patch");
@@ -755,7 +773,7 @@ extern "C" int kdb_index_patch_adjacency(kdb_index *idx, uint32_t level, uint32_
 
 extern "C" int kdb_index_set_entry(kdb_index *idx, uint32_t entry, int32_t max_level) {
     KDB_CHECK_IDX(idx);
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     if (max_level >= 0 && (entry == 0 || entry > idx->count)) {
         kdb_set_error("set_entry: entry point %u outside 1..%u", entry, idx->count);
         return KDB_ERR_INVALID;
@@ -774,7 +792,7 @@ extern "C" int kdb_index_mark_deleted(kdb_index *idx, const uint32_t *ids, uint3
     KDB_CHECK_IDX(idx);
     if (n == 0) return KDB_OK;
     if (!ids) return KDB_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     KDB_HIP(hipSetDevice(idx->device));
     const size_t n1 = (size_t)idx->cap + 1;
     const size_t dw32 = ((n1 + 31) / 32 + 3) & ~(size_t)3;
@@ -973,92 +991,270 @@ extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint
     return search_dev_locked(idx, d_queries, B, k, ef, d_allow_bits, flags, d_out_ids, d_out_dist, d_out_count, s);
 }
 
-// host-pointer wrapper: stage in, run, stage out (inputs consumed before return)
-template <typename F>
-static int with_staged_io(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits,
-                          uint32_t *out_ids, float *out_dist, uint32_t *out_count, F run, size_t dist_bytes = 4,
-                          bool direct_out = false) {
-    const size_t qbytes = (size_t)B * idx->desc.dim * 4;
-    const size_t aw = allow_bits ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
-    const size_t obytes = (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 16;
+// ---------------------------------------------------------------------------------------------
+// Host-pointer calls: slots and groups (kdb_slot / kdb_group, kdb_internal.h)
+//
+// hnsw.Index.SearchWithScores takes activeMu.RLock (hnsw_index.go:343-352) and the engine calls it from one goroutine per request
+// (pkg/engine/ops.go:1003-1007): any number of one-query calls are inside the index at once.  Here idx->mu is held only to pick a
+// slot and to enqueue; staging copies, the wait for the answers and the copy back happen outside it.
+//   * a call that finds a free slot goes out at once, alone (a lone caller never waits for company);
+//   * a call that finds every slot busy joins -- or founds -- the group that waits for the next free slot: calls of up to
+//     KDB_COMBINE_MAX_B queries with the same (k, ef, flags) and no allow list become ONE launch; the founder (leader) stages
+//     and launches, every member sleeps on the group's futex word and copies its own answers out of the slot's page-locked buffer;
+//   * writers wait until no such call is in flight and hold new ones back meanwhile (KdbWriteLock);
+//   * calls too large for a slot (KDB_HOST_PIN_MAX), traced calls and KDB_SEARCH_FAIL_ON_DROP take turns on the index's own
+//     staging buffer (big_mu), still without holding idx->mu while they wait.
+// ---------------------------------------------------------------------------------------------
+struct StagedLayout { // one call's (or group's) buffers inside a slot: the same offsets on the device and in page-locked memory
+    size_t qbytes, aw, o_allow, o_ids, o_dist, o_cnt, out_span, total;
+};
+static StagedLayout staged_layout(const kdb_index *idx, uint32_t B, uint32_t k, bool allow, size_t dist_bytes) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    int rc = ensure_iobuf(idx, al(qbytes) + al(aw) + al(obytes) + 1024);
-    if (rc) return rc;
-    unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
-    float *d_q = reinterpret_cast<float *>(p);
-    uint64_t *d_allow = allow_bits ? reinterpret_cast<uint64_t *>(p + al(qbytes)) : nullptr;
-    uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + al(qbytes) + al(aw));
-    float *d_dist = reinterpret_cast<float *>(p + al(qbytes) + al(aw) + (((size_t)B * k * 4 + 7) & ~(size_t)7)); // 8-byte aligned: may hold doubles
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_dist) + (size_t)B * k * dist_bytes);
-    hipStream_t s = idx->stream;
-    // The caller's buffers are ordinary (pageable) memory -- a Go slice through cgo.  Every copy from / to pageable memory
-    // holds the calling thread and goes through the runtime's own staging.  Calls of up to KDB_HOST_PIN_MAX bytes (4 MiB:
-    // 1024 queries of 768 floats) go through the index's own page-locked buffer instead: one memcpy in, one copy of queries |
-    // allow list, ONE device-to-host copy of ids | distances | counts (contiguous on both sides), one memcpy out.  1M x 768,
-    // ef=60, per call (scripts/host_probe.py): 1 query 0.179 ms (0.228 through the runtime's copies), 64: 0.346 (0.397),
-    // 256: 0.459 (0.512), 1024: 0.664 (0.662); above that the host memcpy costs more than it saves (2048: 1.23 vs 1.14).
-    static const size_t pin_max = [] { const char *e = getenv("KDB_HOST_PIN_MAX"); return e ? (size_t)atoll(e) : (size_t)4 << 20; }();
-    const size_t out_span = (size_t)(reinterpret_cast<unsigned char *>(d_cnt) - reinterpret_cast<unsigned char *>(d_ids)) + (size_t)B * 4;
-    const size_t pin_need = al(qbytes) + al(aw) + al(out_span);
-    if (pin_need <= pin_max) {
-        if (idx->h_pin_bytes < pin_need) {
-            if (idx->h_pin) {
-                KDB_HIP(hipStreamSynchronize(s));
-                (void)hipHostFree(idx->h_pin);
-                idx->h_pin = nullptr;
-                idx->h_pin_bytes = 0;
-            }
-            size_t want = pin_need * 2 < ((size_t)1 << 20) ? ((size_t)1 << 20) : pin_need * 2;
-            if (want > pin_max) want = pin_max;
-            KDB_HIP(hipHostMalloc(&idx->h_pin, want, hipHostMallocDefault));
-            idx->h_pin_bytes = want;
-        }
-        unsigned char *h = reinterpret_cast<unsigned char *>(idx->h_pin);
-        unsigned char *h_allow = h + al(qbytes), *h_out = h + al(qbytes) + al(aw);
-        memcpy(h, queries, qbytes);
-        if (allow_bits) memcpy(h_allow, allow_bits, aw);
-        // queries and allow list sit side by side on both sides: one copy
-        KDB_HIP(hipMemcpyAsync(d_q, h, allow_bits ? al(qbytes) + aw : qbytes, hipMemcpyHostToDevice, s));
-        // Graph search, a few queries: the kernel writes its answers straight into the page-locked buffer (posted writes over
-        // PCIe; the end of the kernel makes them visible) -- no device-to-host copy command behind the kernel.  (Reading the
-        // QUERIES from there as well was measured slower: 1 query 0.180 against 0.171 ms.)
-        static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
-        const bool direct = direct_out && out_span <= direct_max;
-        if (direct) {
-            const size_t o_dist = (size_t)(reinterpret_cast<unsigned char *>(d_dist) - reinterpret_cast<unsigned char *>(d_ids));
-            const size_t o_cnt = (size_t)(reinterpret_cast<unsigned char *>(d_cnt) - reinterpret_cast<unsigned char *>(d_ids));
-            rc = run(d_q, d_allow, reinterpret_cast<uint32_t *>(h_out), reinterpret_cast<float *>(h_out + o_dist),
-                     reinterpret_cast<uint32_t *>(h_out + o_cnt), s);
-        } else {
-            rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
-        }
-        if (rc) {
-            (void)hipStreamSynchronize(s);
-            return rc;
-        }
-        if (!direct) KDB_HIP(hipMemcpyAsync(h_out, d_ids, out_span, hipMemcpyDeviceToHost, s));
-        KDB_HIP(hipStreamSynchronize(s));
-        memcpy(out_ids, h_out, (size_t)B * k * 4);
-        memcpy(out_dist, h_out + (reinterpret_cast<unsigned char *>(d_dist) - reinterpret_cast<unsigned char *>(d_ids)), (size_t)B * k * dist_bytes);
-        memcpy(out_count, h_out + (reinterpret_cast<unsigned char *>(d_cnt) - reinterpret_cast<unsigned char *>(d_ids)), (size_t)B * 4);
-        return KDB_OK;
-    }
-    KDB_HIP(hipMemcpyAsync(d_q, queries, qbytes, hipMemcpyHostToDevice, s));
-    if (allow_bits) KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, s));
-    rc = run(d_q, d_allow, d_ids, d_dist, d_cnt, s);
-    if (rc) return rc;
-    KDB_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * dist_bytes, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-    KDB_HIP(hipStreamSynchronize(s));
+    StagedLayout L;
+    L.qbytes = (size_t)B * idx->desc.dim * 4;
+    L.aw = allow ? ((size_t)(idx->count >> 6) + 1) * 8 : 0;
+    L.o_allow = al(L.qbytes);
+    L.o_ids = L.o_allow + al(L.aw);
+    L.o_dist = L.o_ids + (((size_t)B * k * 4 + 7) & ~(size_t)7); // 8-byte aligned: may hold doubles
+    L.o_cnt = L.o_dist + (size_t)B * k * dist_bytes;
+    L.out_span = L.o_cnt + (size_t)B * 4 - L.o_ids;
+    L.total = al(L.o_cnt + (size_t)B * 4) + 1024;
+    return L;
+}
+
+static void futex_wait_set(std::atomic<uint32_t> &w) {
+    while (w.load(std::memory_order_acquire) == 0u)
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+}
+static void futex_wake_all(std::atomic<uint32_t> &w) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
+static int slot_find_free(const kdb_index *idx) {
+    for (int i = 0; i < idx->n_slots; i++)
+        if (!idx->slots[i].busy) return i;
+    return -1;
+}
+
+// under idx->mu, slot idle (its last group has synchronised its stream and every member has left)
+static int slot_ensure(kdb_slot &sl, size_t bytes) {
+    if (sl.bytes >= bytes) return KDB_OK;
+    if (sl.d_io) (void)hipFree(sl.d_io);
+    if (sl.h_pin) (void)hipHostFree(sl.h_pin);
+    sl.d_io = sl.h_pin = nullptr;
+    sl.bytes = 0;
+    size_t want = bytes * 2 < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + bytes / 4;
+    KDB_HIP(hipMalloc(&sl.d_io, want));
+    // (coherent: the kernels of small calls write their answers straight into this buffer)
+    KDB_HIP(hipHostMalloc(&sl.h_pin, want, hipHostMallocCoherent));
+    sl.bytes = want;
     return KDB_OK;
 }
 
-// Host-pointer search of a large batch in chunks that alternate between two streams (and the two scratch lanes): the
+static size_t host_pin_max() { // calls whose buffers exceed this go through the index's own staging buffer, from / to pageable memory
+    static const size_t v = [] { const char *e = getenv("KDB_HOST_PIN_MAX"); return e ? (size_t)atoll(e) : (size_t)4 << 20; }();
+    return v;
+}
+
+// One host-pointer call through a slot.  run(d_q, d_allow, d_ids, d_dist, d_cnt, stream, nq) enqueues the work (under idx->mu).
+// kind: 1 graph search (combinable), 2 exact scan.  Page-locked staging: one memcpy in, one copy of queries | allow list, ONE
+// device-to-host copy of ids | distances | counts, one memcpy out -- or, for a graph search of a few queries, none: the kernel
+// writes its answers straight into the page-locked buffer (posted writes over PCIe; the end of the kernel makes them visible).
+// 1M x 768, ef=60, per call (scripts/host_probe.py, round 3): 1 query 0.179 ms (0.228 through the runtime's pageable copies).
+template <typename F>
+static int staged_slot_call(kdb_index *idx, uint32_t kind, const float *queries, uint32_t B, uint32_t k, uint32_t ef, const uint64_t *allow_bits,
+                            uint32_t flags, uint32_t *out_ids, void *out_dist, uint32_t *out_count, size_t dist_bytes, bool direct_out, F run) {
+    static const uint32_t combine_max_b = [] { const char *e = getenv("KDB_COMBINE_MAX_B"); return e ? (uint32_t)atoi(e) : 16u; }();
+    static const uint32_t group_cap = [] { const char *e = getenv("KDB_COMBINE_GROUP"); return e ? (uint32_t)atoi(e) : 256u; }();
+    static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
+    const size_t dim = idx->desc.dim;
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
+    const bool combinable = kind == 1 && !allow_bits && B <= combine_max_b && B <= group_cap;
+    kdb_group *g = nullptr;
+    uint32_t my_off = 0;
+    if (combinable && idx->forming) {
+        kdb_group *f = idx->forming;
+        if (f->kind == kind && f->k == k && f->ef == ef && f->flags == flags && f->nq + B <= f->cap_q) {
+            g = f;
+            my_off = g->nq;
+            g->nq += B;
+            g->refs++;
+            g->members.push_back({queries, B});
+        }
+    }
+    auto leave = [&](kdb_group *grp) { // under mu: the last member out gives the slot back
+        if (--grp->refs == 0) {
+            if (grp->slot >= 0) idx->slots[grp->slot].busy = false;
+            delete grp;
+            idx->slot_cv.notify_all();
+        }
+    };
+    auto take = [&](const kdb_group *grp, uint32_t off) { // a member's own answers, out of the slot's page-locked buffer
+        memcpy(out_ids, grp->h_ids + (size_t)off * k * 4, (size_t)B * k * 4);
+        memcpy(out_dist, grp->h_dist + (size_t)off * k * grp->dist_bytes, (size_t)B * k * grp->dist_bytes);
+        memcpy(out_count, grp->h_cnt + (size_t)off * 4, (size_t)B * 4);
+    };
+    if (g) { // ---- follower
+        lk.unlock();
+        futex_wait_set(g->done);
+        const int rc = g->rc;
+        if (rc == KDB_OK) take(g, my_off);
+        else kdb_set_error("%s", g->err);
+        lk.lock();
+        leave(g);
+        return rc;
+    }
+    // ---- leader (of a group of one unless others join while it waits for a slot)
+    g = new (std::nothrow) kdb_group();
+    if (!g) return KDB_ERR_OOM;
+    g->kind = kind;
+    g->k = k;
+    g->ef = ef;
+    g->flags = flags;
+    g->cap_q = combinable ? group_cap : B;
+    g->nq = B;
+    g->refs = 1;
+    g->dist_bytes = dist_bytes;
+    g->members.push_back({queries, B});
+    int si = slot_find_free(idx);
+    if (si < 0) {
+        if (combinable && !idx->forming) idx->forming = g;
+        idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
+        if (idx->forming == g) idx->forming = nullptr; // sealed: later callers found the next group
+    }
+    kdb_slot &sl = idx->slots[si];
+    sl.busy = true;
+    g->slot = si;
+    idx->inflight++;
+    const uint32_t nq = g->nq;
+    idx->n_groups++;
+    idx->n_group_members += g->members.size();
+    if (nq > idx->largest_group) idx->largest_group = nq;
+    const StagedLayout L = staged_layout(idx, nq, k, allow_bits != nullptr, dist_bytes);
+    int rc = slot_ensure(sl, L.total);
+    unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin), *const d = reinterpret_cast<unsigned char *>(sl.d_io);
+    bool queued = false;
+    if (rc == KDB_OK) {
+        lk.unlock(); // stage in outside the lock (inflight > 0 keeps writers out: count and capacity cannot move)
+        size_t o = 0;
+        for (const kdb_group::Member &m : g->members) {
+            memcpy(h + o, m.q, (size_t)m.B * dim * 4);
+            o += (size_t)m.B * dim * 4;
+        }
+        if (allow_bits) memcpy(h + L.o_allow, allow_bits, L.aw);
+        lk.lock();
+        const bool direct = direct_out && L.out_span <= direct_max;
+        unsigned char *const o_base = direct ? h : d;
+        {
+            KdbLaneGuard lane(idx, sl.stream);
+            rc = lane.rc;
+            // queries and allow list sit side by side on both sides: one copy
+            if (rc == KDB_OK && hipMemcpyAsync(d, h, allow_bits ? L.o_allow + L.aw : L.qbytes, hipMemcpyHostToDevice, sl.stream) != hipSuccess) {
+                kdb_set_error("staging copy to the device failed");
+                rc = KDB_ERR_HIP;
+            }
+            queued = rc == KDB_OK;
+            if (rc == KDB_OK)
+                rc = run(reinterpret_cast<float *>(d), allow_bits ? reinterpret_cast<uint64_t *>(d + L.o_allow) : nullptr,
+                         reinterpret_cast<uint32_t *>(o_base + L.o_ids), reinterpret_cast<float *>(o_base + L.o_dist),
+                         reinterpret_cast<uint32_t *>(o_base + L.o_cnt), sl.stream, nq);
+        }
+        if (rc == KDB_OK && !direct && hipMemcpyAsync(h + L.o_ids, d + L.o_ids, L.out_span, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) {
+            kdb_set_error("staging copy from the device failed");
+            rc = KDB_ERR_HIP;
+        }
+        lk.unlock();
+        if (queued && hipStreamSynchronize(sl.stream) != hipSuccess && rc == KDB_OK) { // (queued copies read the slot's buffer: wait on errors too)
+            kdb_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = KDB_ERR_HIP;
+        }
+    } else {
+        lk.unlock();
+    }
+    g->rc = rc;
+    if (rc) snprintf(g->err, sizeof g->err, "%s", kdb_last_error());
+    g->h_ids = h + L.o_ids;
+    g->h_dist = h + L.o_dist;
+    g->h_cnt = h + L.o_cnt;
+    const bool company = g->members.size() > 1;
+    g->done.store(1u, std::memory_order_release);
+    if (company) futex_wake_all(g->done);
+    if (rc == KDB_OK) take(g, 0);
+    lk.lock();
+    idx->inflight--;
+    if (idx->inflight == 0 && idx->writers_waiting) idx->slot_cv.notify_all();
+    leave(g);
+    return rc;
+}
+
+// Calls that do not fit a slot: the index's own staging buffer, copies from / to the caller's pageable memory (they hold the
+// calling thread), one such call at a time (big_mu) -- idx->mu only around the enqueue.  Traced calls and KDB_SEARCH_FAIL_ON_DROP
+// come here too (the trace arrays and the "last launch" belong to one call at a time).
+template <typename F>
+static int staged_big_call(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits, uint32_t *out_ids, void *out_dist,
+                           uint32_t *out_count, size_t dist_bytes, bool fail_on_drop, F run) {
+    std::lock_guard<std::mutex> big(idx->big_mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
+    const StagedLayout L = staged_layout(idx, B, k, allow_bits != nullptr, dist_bytes);
+    int rc = ensure_iobuf(idx, L.total);
+    if (rc) return rc;
+    idx->inflight++;
+    struct Done { // every exit: the stream is idle (queued copies touch the CALLER's buffers) and the call no longer counts
+        kdb_index *i;
+        std::unique_lock<std::mutex> &l;
+        ~Done() {
+            if (l.owns_lock()) l.unlock();
+            (void)hipStreamSynchronize(i->stream);
+            l.lock();
+            i->inflight--;
+            if (i->inflight == 0 && i->writers_waiting) i->slot_cv.notify_all();
+        }
+    } done{idx, lk};
+    unsigned char *const d = reinterpret_cast<unsigned char *>(idx->d_iobuf);
+    hipStream_t s = idx->stream;
+    const uint32_t n_deleted = idx->n_deleted;
+    lk.unlock();
+    KDB_HIP(hipMemcpyAsync(d, queries, L.qbytes, hipMemcpyHostToDevice, s));
+    if (allow_bits) KDB_HIP(hipMemcpyAsync(d + L.o_allow, allow_bits, L.aw, hipMemcpyHostToDevice, s));
+    lk.lock();
+    uint64_t seq = 0;
+    int kind = 0;
+    {
+        KdbLaneGuard lane(idx, s);
+        if (lane.rc) return lane.rc;
+        rc = run(reinterpret_cast<float *>(d), allow_bits ? reinterpret_cast<uint64_t *>(d + L.o_allow) : nullptr, reinterpret_cast<uint32_t *>(d + L.o_ids),
+                 reinterpret_cast<float *>(d + L.o_dist), reinterpret_cast<uint32_t *>(d + L.o_cnt), s, B);
+        seq = idx->launch_seq;
+        kind = idx->last_kind;
+    }
+    lk.unlock();
+    if (rc) return rc;
+    KDB_HIP(hipMemcpyAsync(out_ids, d + L.o_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_dist, d + L.o_dist, (size_t)B * k * dist_bytes, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipMemcpyAsync(out_count, d + L.o_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
+    if (fail_on_drop && n_deleted > 2047u && seq > 0 && kind == 1) {
+        unsigned long long c[4] = {0, 0, 0, 0};
+        KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)((seq - 1) % kdb_index::RING) * 4, 32, hipMemcpyDeviceToHost));
+        if (c[3]) {
+            kdb_set_error("search: %llu pending traversal-only candidates were discarded (more than 2047 deleted nodes waiting in one "
+                          "walk): answers may differ from the reference's", c[3]);
+            return KDB_ERR_DIVERGED;
+        }
+    }
+    return KDB_OK;
+}
+
+// Host-pointer search of a large batch in chunks that alternate between two streams (and two scratch lanes): the
 // H2D copy of chunk c+1 and the D2H copy of chunk c-1 run under the walk of chunk c, and the waves that idle at the end of
 // one chunk's launch start on the next.  SURVEY 8d counts the copies into the QPS of this entry point.
 static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef, const uint64_t *allow_bits,
                                 uint32_t flags, uint32_t *out_ids, float *out_dist, uint32_t *out_count, uint32_t chunk) {
+    std::lock_guard<std::mutex> big(idx->big_mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
     const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
     const size_t dim = idx->desc.dim;
     const size_t qbytes = (size_t)B * dim * 4;
@@ -1067,16 +1263,32 @@ static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B
     const size_t ids_bytes = al((size_t)B * k * 4), dst_bytes = al((size_t)B * k * dist_bytes), cnt_bytes = al((size_t)B * 4);
     int rc = ensure_iobuf(idx, al(qbytes) + al(aw) + ids_bytes + dst_bytes + cnt_bytes + 1024);
     if (rc) return rc;
+    idx->inflight++;
+    // every exit -- the error paths too -- waits for both streams: queued copies read and write the CALLER's host buffers
+    struct Done {
+        kdb_index *i;
+        std::unique_lock<std::mutex> &l;
+        ~Done() {
+            if (l.owns_lock()) l.unlock();
+            (void)hipStreamSynchronize(i->stream);
+            (void)hipStreamSynchronize(i->stream2);
+            l.lock();
+            i->inflight--;
+            if (i->inflight == 0 && i->writers_waiting) i->slot_cv.notify_all();
+        }
+    } done{idx, lk};
     unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
     float *d_q = reinterpret_cast<float *>(p);
     uint64_t *d_allow = allow_bits ? reinterpret_cast<uint64_t *>(p + al(qbytes)) : nullptr;
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + al(qbytes) + al(aw));
     unsigned char *d_dist = p + al(qbytes) + al(aw) + ids_bytes;
     uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_dist + dst_bytes);
+    hipStream_t s1 = idx->stream, s2 = idx->stream2;
+    lk.unlock();
     if (allow_bits) {
-        KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, idx->stream));
-        KDB_HIP(hipEventRecord(idx->ev_io, idx->stream));
-        KDB_HIP(hipStreamWaitEvent(idx->stream2, idx->ev_io, 0));
+        KDB_HIP(hipMemcpyAsync(d_allow, allow_bits, aw, hipMemcpyHostToDevice, s1));
+        KDB_HIP(hipEventRecord(idx->ev_io, s1));
+        KDB_HIP(hipStreamWaitEvent(s2, idx->ev_io, 0));
     }
     // copies from / to pageable host memory hold the calling thread until they are done: the results of chunk c-1 are
     // fetched AFTER chunk c has been queued, so the device always has the next walk in its queue
@@ -1087,23 +1299,16 @@ static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B
         KDB_HIP(hipMemcpyAsync(out_count + b0, d_cnt + b0, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
         return KDB_OK;
     };
-    // every exit -- the error paths too -- waits for both streams: queued copies read and write the CALLER's host buffers
-    struct SyncBoth {
-        kdb_index *i;
-        ~SyncBoth() {
-            (void)hipStreamSynchronize(i->stream);
-            (void)hipStreamSynchronize(i->stream2);
-        }
-    } sync_both{idx};
     uint32_t c = 0, prev_b0 = 0, prev_nb = 0;
     hipStream_t prev_s = nullptr;
     for (uint32_t b0 = 0; b0 < B; b0 += chunk, c++) {
         const uint32_t nb = B - b0 < chunk ? B - b0 : chunk;
-        hipStream_t s = (c & 1u) ? idx->stream2 : idx->stream;
+        hipStream_t s = (c & 1u) ? s2 : s1;
+        KDB_HIP(hipMemcpyAsync(d_q + (size_t)b0 * dim, queries + (size_t)b0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, s));
         {
+            std::lock_guard<std::mutex> enq(idx->mu); // idx->mu only around the enqueue: small calls go on meanwhile
             KdbLaneGuard lane(idx, s);
             if (lane.rc) return lane.rc;
-            KDB_HIP(hipMemcpyAsync(d_q + (size_t)b0 * dim, queries + (size_t)b0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, s));
             rc = search_dev_locked(idx, d_q + (size_t)b0 * dim, nb, k, ef, d_allow, flags, d_ids + (size_t)b0 * k,
                                    reinterpret_cast<float *>(d_dist + (size_t)b0 * k * dist_bytes), d_cnt + b0, s);
             if (rc) return rc;
@@ -1120,8 +1325,8 @@ static int search_staged_chunks(kdb_index *idx, const float *queries, uint32_t B
         rc = fetch(prev_b0, prev_nb, prev_s);
         if (rc) return rc;
     }
-    KDB_HIP(hipStreamSynchronize(idx->stream));
-    KDB_HIP(hipStreamSynchronize(idx->stream2));
+    KDB_HIP(hipStreamSynchronize(s1));
+    KDB_HIP(hipStreamSynchronize(s2));
     return KDB_OK;
 }
 
@@ -1167,31 +1372,36 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
         kdb_set_error("search: null buffer or k == 0");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
     static const uint32_t chunk_min = [] { const char *e = getenv("KDB_HOST_CHUNK_MIN"); return e ? (uint32_t)atoi(e) : 8192u; }();
-    if (B >= chunk_min && chunk_min > 0 && !idx->trace_ndist && !(flags & KDB_SEARCH_FAIL_ON_DROP)) {
+    const bool traced = idx->trace_ndist != nullptr; // (set by the caller's own thread before the call: kdb_search_set_trace)
+    if (B >= chunk_min && chunk_min > 0 && !traced && !(flags & KDB_SEARCH_FAIL_ON_DROP)) {
         uint32_t chunk = ((B + 3u) / 4u + 255u) & ~255u; // four chunks, not below 4096 queries each
         if (chunk < 4096u) chunk = 4096u;
         return search_staged_chunks(idx, queries, B, k, ef, allow_bits, flags, out_ids, out_dist, out_count, chunk);
     }
-    KdbLaneGuard lane(idx, idx->stream);
-    if (lane.rc) return lane.rc;
-    int rc = with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
-                            [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
-                                return search_dev_locked(idx, d_q, B, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                            }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4, true);
-    if (rc == KDB_OK && (flags & KDB_SEARCH_FAIL_ON_DROP) && idx->n_deleted > 2047u && idx->launch_seq > 0 && idx->last_kind == 1) {
-        // (the call is complete: with_staged_io synchronised the stream)
-        unsigned long long c[4] = {0, 0, 0, 0};
-        KDB_HIP(hipMemcpy(c, idx->d_ctr + (size_t)((idx->launch_seq - 1) % kdb_index::RING) * 4, 32, hipMemcpyDeviceToHost));
-        if (c[3]) {
-            kdb_set_error("search: %llu pending traversal-only candidates were discarded (more than 2047 deleted nodes waiting in one "
-                          "walk): answers may differ from the reference's", c[3]);
-            return KDB_ERR_DIVERGED;
-        }
-    }
-    return rc;
+    const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
+    auto run = [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s, uint32_t nq) {
+        return search_dev_locked(idx, d_q, nq, k, ef, d_allow, flags, d_ids, d_dist, d_cnt, s);
+    };
+    // (an upper bound of the layout: the allow list is sized by the count the caller saw)
+    const size_t need = (size_t)B * idx->desc.dim * 4 + (allow_bits ? ((size_t)(idx->cap >> 6) + 1) * 8 : 0) + (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 4096;
+    if (traced || (flags & KDB_SEARCH_FAIL_ON_DROP) || need > host_pin_max())
+        return staged_big_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, (flags & KDB_SEARCH_FAIL_ON_DROP) != 0, run);
+    return staged_slot_call(idx, 1u, queries, B, k, ef, allow_bits, flags, out_ids, out_dist, out_count, dist_bytes, true, run);
+}
+
+// statistics of the combiner: out[0] launches of host-pointer calls that went through a slot, out[1] calls they carried,
+// out[2] the largest number of queries one launch carried, out[3] slots of this index
+extern "C" int kdb_index_caller_stats(kdb_index *idx, uint64_t *out) {
+    KDB_CHECK_IDX(idx);
+    if (!out) return KDB_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    out[0] = idx->n_groups;
+    out[1] = idx->n_group_members;
+    out[2] = idx->largest_group;
+    out[3] = (uint64_t)idx->n_slots;
+    return KDB_OK;
 }
 
 extern "C" int kdb_search_set_trace(kdb_index *idx, uint32_t *per_query_ndist, uint32_t *per_query_nhops, int on_device) {
@@ -1331,14 +1541,14 @@ extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_
         kdb_set_error("flat_scan: null buffer or k == 0");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
     KDB_HIP(hipSetDevice(idx->device));
-    KdbLaneGuard lane(idx, idx->stream);
-    if (lane.rc) return lane.rc;
-    return with_staged_io(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count,
-                          [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s) {
-                              return flat_dev_locked(idx, d_q, B, k, d_allow, flags, d_ids, d_dist, d_cnt, s);
-                          }, (flags & KDB_SEARCH_DIST_F64) ? 8 : 4);
+    const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
+    auto run = [&](float *d_q, uint64_t *d_allow, uint32_t *d_ids, float *d_dist, uint32_t *d_cnt, hipStream_t s, uint32_t nq) {
+        return flat_dev_locked(idx, d_q, nq, k, d_allow, flags, d_ids, d_dist, d_cnt, s);
+    };
+    const size_t need = (size_t)B * idx->desc.dim * 4 + (allow_bits ? ((size_t)(idx->cap >> 6) + 1) * 8 : 0) + (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 4096;
+    if (need > host_pin_max()) return staged_big_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, false, run);
+    return staged_slot_call(idx, 2u, queries, B, k, 0u, allow_bits, flags, out_ids, out_dist, out_count, dist_bytes, false, run);
 }
 
 static int distance_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids, uint32_t C,
@@ -1379,30 +1589,51 @@ extern "C" int kdb_distance_batch(kdb_index *idx, const float *queries, uint32_t
         kdb_set_error("distance_batch: null buffer");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu); // one lock for staging + launch + read-back
     KDB_HIP(hipSetDevice(idx->device));
-    KdbLaneGuard lane(idx, idx->stream);
-    if (lane.rc) return lane.rc;
+    // the index's own staging buffer, one such call at a time (big_mu); idx->mu only around the enqueue
+    std::lock_guard<std::mutex> big(idx->big_mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
     const size_t qbytes = ((size_t)B * idx->desc.dim * 4 + 255) & ~(size_t)255;
     const size_t ibytes = ((size_t)B * C * 4 + 255) & ~(size_t)255;
     int rc = ensure_iobuf(idx, qbytes + 2 * ibytes + 256);
     if (rc) return rc;
+    idx->inflight++;
+    struct Done {
+        kdb_index *i;
+        std::unique_lock<std::mutex> &l;
+        ~Done() {
+            if (l.owns_lock()) l.unlock();
+            (void)hipStreamSynchronize(i->stream);
+            l.lock();
+            i->inflight--;
+            if (i->inflight == 0 && i->writers_waiting) i->slot_cv.notify_all();
+        }
+    } done{idx, lk};
     unsigned char *p = reinterpret_cast<unsigned char *>(idx->d_iobuf);
     float *d_q = reinterpret_cast<float *>(p);
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(p + qbytes);
     float *d_out = reinterpret_cast<float *>(p + qbytes + ibytes);
-    KDB_HIP(hipMemcpyAsync(d_q, queries, (size_t)B * idx->desc.dim * 4, hipMemcpyHostToDevice, idx->stream));
-    KDB_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * C * 4, hipMemcpyHostToDevice, idx->stream));
-    rc = distance_dev_locked(idx, d_q, B, d_ids, C, flags, d_out, idx->stream);
+    hipStream_t s = idx->stream;
+    lk.unlock();
+    KDB_HIP(hipMemcpyAsync(d_q, queries, (size_t)B * idx->desc.dim * 4, hipMemcpyHostToDevice, s));
+    KDB_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * C * 4, hipMemcpyHostToDevice, s));
+    lk.lock();
+    {
+        KdbLaneGuard lane(idx, s);
+        if (lane.rc) return lane.rc;
+        rc = distance_dev_locked(idx, d_q, B, d_ids, C, flags, d_out, s);
+    }
+    lk.unlock();
     if (rc) return rc;
-    KDB_HIP(hipMemcpyAsync(out, d_out, (size_t)B * C * 4, hipMemcpyDeviceToHost, idx->stream));
-    KDB_HIP(hipStreamSynchronize(idx->stream));
+    KDB_HIP(hipMemcpyAsync(out, d_out, (size_t)B * C * 4, hipMemcpyDeviceToHost, s));
+    KDB_HIP(hipStreamSynchronize(s));
     return KDB_OK;
 }
 
 extern "C" int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_params *params) {
     KDB_CHECK_IDX(idx);
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     idx->graph_epoch++;
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);
@@ -1417,7 +1648,7 @@ extern "C" int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n
         kdb_set_error("add_batch: unknown flag");
         return KDB_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
+    KdbWriteLock wl(idx); // excludes host-pointer calls in flight
     idx->graph_epoch++;
     KDB_HIP(hipSetDevice(idx->device));
     KdbLaneGuard lane(idx, idx->stream);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -51,7 +53,37 @@ struct KdbMultiAllow {
 // used the set if that ran on ANOTHER stream, and leaves its own event behind.  Two callers driving two streams
 // therefore overlap on the GPU (the waves idling at the end of one batch's launch run the next batch's first queries)
 // without sharing visited bitsets, entry-point tables, prepared queries or scan lists.
-#define KDB_LANES 2
+// Host-pointer calls of concurrent callers (hnsw_index.go:343-352: SearchWithScores runs under activeMu.RLock, any number of
+// goroutines at once) run in SLOTS: a slot = one stream + one pair of staging buffers (device / page-locked host).  idx->mu is
+// held to pick a slot and to enqueue; the wait for the answers happens OUTSIDE it, so up to n_slots calls are on the device at
+// once, each with the scratch lane of its stream.  Callers that find every slot busy are COMBINED: one-query calls with the same
+// (k, ef, flags) join the group that waits for the next free slot and go out as one launch (kdb_group).
+#define KDB_MAX_SLOTS 16
+#define KDB_LANES (2 + KDB_MAX_SLOTS)
+struct kdb_slot {
+    hipStream_t stream = nullptr;
+    void *d_io = nullptr;   // queries | allow list | ids | distances | counts (device side)
+    void *h_pin = nullptr;  // the same layout, page-locked host memory
+    size_t bytes = 0;
+    bool busy = false;
+};
+struct kdb_group {
+    uint32_t kind = 0, k = 0, ef = 0, flags = 0; // the key callers must share to join
+    uint32_t cap_q = 0;                          // queries it may hold
+    uint32_t nq = 0;                             // queries joined so far (final once the group has its slot)
+    uint32_t refs = 0;                           // callers that have not taken their answers yet
+    int slot = -1;
+    int rc = 0;
+    char err[256] = "";
+    std::atomic<uint32_t> done{0};               // futex word: followers sleep on it, the leader sets and wakes
+    struct Member {
+        const float *q;
+        uint32_t B;
+    };
+    std::vector<Member> members;                 // callers' query buffers (every member is blocked in its call until `done`)
+    const unsigned char *h_ids = nullptr, *h_dist = nullptr, *h_cnt = nullptr; // the answers, page-locked
+    size_t dist_bytes = 4;
+};
 struct kdb_lane {
     uint32_t *d_visited = nullptr;
     uint32_t vis_slots = 0;
@@ -111,10 +143,8 @@ struct kdb_index {
     size_t scratch_bytes = 0;
     void *d_qbuf = nullptr;         // prepared queries (stored form, padded to ld) + query norms
     size_t qbuf_bytes = 0;
-    void *d_iobuf = nullptr;        // staging for the host-pointer entry points
+    void *d_iobuf = nullptr;        // staging of the host-pointer calls that do not fit a slot (big_mu)
     size_t iobuf_bytes = 0;
-    void *h_pin = nullptr;          // page-locked twin of the staging buffer: small host-pointer calls copy through it
-    size_t h_pin_bytes = 0;
     uint32_t *d_gentry = nullptr;    // entry point per allow list of a search batch (hnsw_index.go:437-447), chosen on the device
     uint32_t gentry_cap = 0;
     void *d_tie = nullptr;           // (current lane's) scratch of the heap-order second pass (search_heap.hip)
@@ -139,6 +169,15 @@ struct kdb_index {
     uint32_t ring_B[RING] = {}, ring_C[RING] = {};
     uint64_t launch_seq = 0;
     std::mutex mu;
+    // concurrent host-pointer calls (see kdb_slot): all guarded by mu
+    kdb_slot slots[KDB_MAX_SLOTS];
+    int n_slots = 0;
+    uint32_t inflight = 0;         // host-pointer calls whose kernels may still run (writers wait for 0: the reference's RWMutex)
+    uint32_t writers_waiting = 0;  // ... and new calls wait while a writer does (no writer starvation)
+    std::condition_variable slot_cv; // leaders waiting for a slot, writers waiting for inflight == 0
+    kdb_group *forming = nullptr;  // the group that waits for the next free slot and may still be joined
+    std::mutex big_mu;             // calls too large for a slot share d_iobuf / stream / stream2: one at a time
+    uint64_t n_groups = 0, n_group_members = 0, largest_group = 0; // statistics of the combiner (kdb_index_caller_stats)
     // scratch lanes: the fields d_visited / d_scratch / d_qbuf / d_gentry / d_work above always name the CURRENT lane's
     // buffers (kdb_lane_acquire copies them in, kdb_lane_release copies them back: calls are serialised by `mu`)
     kdb_lane lanes[KDB_LANES];
@@ -152,6 +191,20 @@ struct kdb_index {
 int kdb_lane_acquire(kdb_index *idx, hipStream_t s);
 // ... and leave it: records the call's completion event on s
 int kdb_lane_release(kdb_index *idx, hipStream_t s);
+// Writers (upload, delete, build, reserve ...) exclude host-pointer calls in flight the way the reference's activeMu.Lock excludes
+// its RLock holders: take mu, announce, wait until no call's kernels can still be running.  (Calls of the _dev entry points run on
+// streams of the caller, who orders them -- as before.)
+struct KdbWriteLock {
+    std::unique_lock<std::mutex> lk;
+    explicit KdbWriteLock(kdb_index *idx) : lk(idx->mu) {
+        if (idx->inflight) {
+            idx->writers_waiting++;
+            idx->slot_cv.wait(lk, [&] { return idx->inflight == 0; });
+            idx->writers_waiting--;
+            if (idx->writers_waiting == 0) idx->slot_cv.notify_all();
+        }
+    }
+};
 struct KdbLaneGuard { // RAII: release on every return path
     kdb_index *idx;
     hipStream_t s;

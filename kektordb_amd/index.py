@@ -142,6 +142,12 @@ class HipIndex:
         """HIP events around the graph-search launches (launch_stats' kernel_ms); off saves two queue packets per call"""
         check(self.L.kdb_index_set_launch_timing(self.h, 1 if on else 0), "kdb_index_set_launch_timing")
 
+    def caller_stats(self):
+        """concurrent host-pointer calls: launches that left through a slot, the calls they carried, the largest launch, slots"""
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.L.kdb_index_caller_stats(self.h, _ptr(out)), "kdb_index_caller_stats")
+        return {"launches": int(out[0]), "calls": int(out[1]), "largest": int(out[2]), "slots": int(out[3])}
+
     def reserve(self, new_capacity: int):
         """growNodes (hnsw_index.go:2732-2768): raise the capacity of a live index, on the device"""
         check(self.L.kdb_index_reserve(self.h, new_capacity), "kdb_index_reserve")

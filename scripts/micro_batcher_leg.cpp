@@ -55,14 +55,17 @@ class BorrowedIndex {
 } // namespace
 
 // T threads, `per` calls each, queries taken round-robin from the nq given; lat_us: [T * per] per-call latencies (thread-major).
-// window_us < 0: no batcher -- every caller makes its own one-query kdb_search_batch call (what the unpatched seam would do).
+// window_us < 0: no batcher -- every caller makes its own one-query kdb_search_batch call (what the unpatched seam would do; the
+// library serves such calls from its slots and combines those that find every slot busy); *batches = the launches it made.
 extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision, const float *queries, uint32_t nq, int k,
                                            int ef, int T, int per, int window_us, double *lat_us, double *wall_s, uint64_t *batches, uint64_t *largest,
                                            uint64_t *answers) {
     BorrowedIndex idx(h, dim, metric, precision);
     kektor::hnsw::BasicMicroBatcher<BorrowedIndex>::Options o;
-    o.window = std::chrono::microseconds(window_us > 0 ? window_us : 1);
+    o.window = std::chrono::microseconds(window_us > 0 ? window_us : 0); // 0: the default -- a leader that finds a turn free goes at once
     kektor::hnsw::BasicMicroBatcher<BorrowedIndex> mb(idx, o);
+    uint64_t cs0[4] = {0, 0, 0, 0}, cs1[4] = {0, 0, 0, 0};
+    (void)kdb_index_caller_stats(h, cs0);
     std::atomic<uint64_t> got{0};
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
@@ -89,8 +92,10 @@ extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t 
     for (auto &x : th) x.join();
     *wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const auto st = mb.stats();
-    *batches = st.batches;
-    *largest = st.largest;
+    (void)kdb_index_caller_stats(h, cs1);
+    // direct callers: the launches the library made for them (it combines the calls that find every slot busy)
+    *batches = window_us < 0 ? cs1[0] - cs0[0] : st.batches;
+    *largest = window_us < 0 ? cs1[2] : st.largest;
     *answers = got.load();
     return 0;
 }

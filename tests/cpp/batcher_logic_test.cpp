@@ -1,4 +1,4 @@
-// The micro-batcher's concurrency logic on a test double (no GPU): built with -fsanitize=thread by
+// The micro-batcher's concurrency logic (grouping, two groups in flight, futex hand-over, Stop) on a test double (no GPU): built with -fsanitize=thread by
 // tests/test_cpp_host.py.  Many threads issue one-query calls with a few (k, ef, allow list) combinations; every
 // caller must get the answer computed from ITS query, calls must be coalesced, Stop() must release everybody.
 #include <atomic>
@@ -10,11 +10,15 @@
 #include "kektor_hip.hpp"
 
 struct FakeIndex {
-    std::atomic<int> calls{0}, flat_calls{0};
+    std::atomic<int> calls{0}, flat_calls{0}, running{0}, peak{0};
     uint32_t Dim() const { return 8; }
     uint32_t Count() const { return 1000; }
     std::vector<std::vector<kektor::SearchResult>> answer(const float *q, uint32_t B, int k, int tag) {
+        const int now = ++running; // calls inside the index at once: the batcher pipelines, up to Options::maxInFlight
+        int p = peak.load();
+        while (now > p && !peak.compare_exchange_weak(p, now)) {}
         std::this_thread::sleep_for(std::chrono::microseconds(300)); // a GPU call
+        --running;
         std::vector<std::vector<kektor::SearchResult>> out(B);
         for (uint32_t b = 0; b < B; b++)
             for (int i = 0; i < k; i++) out[b].push_back({(uint32_t)q[(size_t)b * 8] * 10u + (uint32_t)i, (double)tag});
@@ -62,6 +66,16 @@ int main() {
     const auto st = mb.stats();
     if (st.calls != 24 * 60 || st.batches >= st.calls || st.largest > 16 || st.flatBatches == 0) bad++;
     if (idx.calls.load() + idx.flat_calls.load() != (int)st.batches) bad++;
+    if (idx.peak.load() != 2) bad++; // two groups in flight (the default), never more
+    {   // a lone caller never waits for company (no window by default): well under the 2 ms a window would cost
+        kektor::hnsw::BasicMicroBatcher<FakeIndex> mb1(idx);
+        std::vector<float> q(8, 0.f);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 20; i++)
+            if (mb1.SearchWithScores(q, 2, nullptr, 9).size() != 2) bad++;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 20 * 0.3 + 40.0) bad++;
+    }
     // a selective filter with k > 1024 must still be answered (by the walk: the exact scan takes k <= 1024), and a scan that
     // refuses its arguments falls back to the walk instead of returning []
     {

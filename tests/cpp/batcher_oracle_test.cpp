@@ -8,6 +8,7 @@
 //   per case: u32 row, ef, allow_kind (0 none, 1 even ids, 2 few ids), cnt, u32 ids[k], f64 scores[k]
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -111,6 +112,44 @@ int main(int argc, char **argv) {
         bad++;
     }
     mb.Stop();
+    // The same calls WITHOUT the batcher: 32 threads call SearchWithScores on one handle (the unpatched seam: one query per call,
+    // hnsw_index.go:343).  The library serves them from its slots and combines the calls that find every slot busy
+    // (kektor_hip.h "Conventions"): same answers bit for bit, fewer launches than calls.  A second handle with TWO slots makes
+    // the combining certain whatever the host's speed.
+    {
+        setenv("KDB_SLOTS", "2", 1);
+        kektor::hnsw::Index idx2(dim, KDB_METRIC_L2, KDB_PREC_F32, 8, 20, n);
+        unsetenv("KDB_SLOTS");
+        idx2.UploadRows(1, n, X.data());
+        idx2.UploadGraph(g);
+        for (kektor::hnsw::Index *ix : {&idx, &idx2}) {
+            next.store(0);
+            std::atomic<int> wrong2{0};
+            std::vector<std::thread> th2;
+            for (int t = 0; t < 32; t++)
+                th2.emplace_back([&] {
+                    for (;;) {
+                        const uint32_t i = next.fetch_add(1);
+                        if (i >= nc) return;
+                        const Case &c = cases[i];
+                        if (c.kind == 2) continue; // (routing to the exact scan is the batcher's business)
+                        std::vector<float> q(X.begin() + (size_t)(c.row - 1) * dim, X.begin() + (size_t)c.row * dim);
+                        auto got = ix->SearchWithScores(q, (int)k, c.kind == 1 ? &even : nullptr, (int)c.ef);
+                        bool ok = got.size() == c.cnt;
+                        for (size_t j = 0; ok && j < got.size(); j++) ok = got[j].DocID == c.ids[j] && got[j].Score == c.scores[j];
+                        if (!ok && wrong2.fetch_add(1) < 5) std::printf("direct call, case %u (row %u ef %u allow %u): wrong answer\n", i, c.row, c.ef, c.kind);
+                    }
+                });
+            for (auto &x : th2) x.join();
+            bad += wrong2.load();
+            uint64_t cs[4] = {0, 0, 0, 0};
+            if (kdb_index_caller_stats(ix->handle(), cs)) bad++;
+            std::printf("direct callers, %llu slots: %llu launches for %llu calls, largest %llu queries\n", (unsigned long long)cs[3], (unsigned long long)cs[0],
+                        (unsigned long long)cs[1], (unsigned long long)cs[2]);
+            if (ix == &idx2 && (cs[3] != 2 || cs[0] >= cs[1] || cs[2] < 2)) bad++; // two slots, 32 callers: calls shared launches
+        }
+        idx2.Close();
+    }
     idx.Close();
     std::printf(bad ? "FAIL %d\n" : "ok %u cases, %llu GPU calls (%llu exact scans)\n", bad ? bad : nc, (unsigned long long)st.batches,
                 (unsigned long long)st.flatBatches);

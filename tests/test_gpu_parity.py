@@ -780,6 +780,77 @@ def test_concurrent_search_delete_and_scan(oracle, hip):
         assert np.array_equal(ids[b, :int(cnt[b])], oi)
 
 
+def test_concurrent_one_query_callers_share_launches(oracle, hip, monkeypatch):
+    """The reference's seam is one query per SearchWithScores call under a READ lock (hnsw_index.go:343-352, called from a
+    goroutine per request, pkg/engine/ops.go:1003-1007).  24 threads make one-query calls (plus two-query calls, filtered calls,
+    heap-order calls and exact scans) on ONE handle: every answer equals the one the same query gets in a single batch -- ids,
+    distance bits, counts -- whether the call went out alone or combined with others; with two slots the calls must have shared
+    launches; a writer (row uploads) that runs in between excludes them like the write lock."""
+    import threading
+    from kektordb_amd.index import dense_bitset
+    O = oracle
+    n, dim, k, ef = 6000, 96, 10, 48
+    X = make_corpus(n, dim, "normal", seed=501)
+    X[100:140] = X[99]                      # duplicate rows: tied distances -> the heap-order second pass inside combined launches
+    for slots in ("2", "8"):
+        monkeypatch.setenv("KDB_SLOTS", slots)
+        orc, idx = build_pair(O, hip, X, 1, efc=60)
+        monkeypatch.delenv("KDB_SLOTS")
+        Q = make_corpus(192, dim, "normal", seed=502)
+        Q[:8] = X[99] + 1e-3 * Q[:8]
+        rng = np.random.default_rng(7)
+        allowed = np.nonzero(rng.random(n + 1) < 0.5)[0]
+        ab = dense_bitset(allowed[allowed >= 1], n)
+        want = idx.search_batch(Q, k, ef)
+        want_h = idx.search_batch(Q, k, ef, heap_order=True)
+        want_a = idx.search_batch(Q, k, ef, allow_bits=ab)
+        want_f = idx.flat_scan_batch(Q, k)
+        s0 = idx.caller_stats()
+        errors = []
+
+        def caller(t):
+            try:
+                for it in range(40):
+                    b = (t * 40 + it) % Q.shape[0]
+                    mode = it % 8
+                    if mode == 5:
+                        got, ref, nb = idx.search_batch(Q[b:b + 1], k, ef, allow_bits=ab), want_a, 1
+                    elif mode == 6:
+                        got, ref, nb = idx.flat_scan_batch(Q[b:b + 1], k), want_f, 1
+                    elif mode == 7:
+                        got, ref, nb = idx.search_batch(Q[b:b + 1], k, ef, heap_order=True), want_h, 1
+                    elif mode == 4 and b + 2 <= Q.shape[0]:
+                        got, ref, nb = idx.search_batch(Q[b:b + 2], k, ef), want, 2
+                    else:
+                        got, ref, nb = idx.search_batch(Q[b:b + 1], k, ef), want, 1
+                    for a, r in zip(got, ref):
+                        assert np.array_equal(a, r[b:b + nb]), (t, it, mode)
+            except Exception as e:  # pragma: no cover - reported below
+                errors.append(repr(e))
+
+        def writer():
+            try:
+                stored = orc.rows()[1:]
+                for d in range(3000, 3040):
+                    idx.upload_rows(stored[d - 1:d], d)   # a writer that leaves every row as it was: the answers above stay valid
+            except Exception as e:  # pragma: no cover
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=writer)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:3]
+        s1 = idx.caller_stats()
+        assert s1["slots"] == int(slots)
+        assert s1["calls"] - s0["calls"] == 24 * 40
+        if slots == "2":
+            assert s1["launches"] - s0["launches"] < 24 * 40, "no call shared a launch"
+            assert s1["largest"] >= 2
+        idx.close()
+
+
 def test_search_heterogeneous_allow_lists(oracle, hip):
     """kdb_search_batch_multi_dev: every query carries its own allow list (or none); per query the answer is
     bit-exact what the oracle returns for that query with that list -- entry-point substitution, the non-nil EMPTY
