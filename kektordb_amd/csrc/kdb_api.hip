@@ -11,10 +11,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
-#include <limits.h>
-#include <unistd.h>
-#include <sys/syscall.h>
-#include <linux/futex.h>
+#include <sched.h>
+#include <time.h>
+#include <sys/prctl.h>
 #include <algorithm>
 
 static thread_local char g_err[512] = "";
@@ -27,6 +26,12 @@ void kdb_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *kdb_last_error(void) { return g_err; }
+
+// Kernels of different streams run side by side only on different HARDWARE queues, and the runtime gives a process four unless
+// told otherwise (measured: scripts/micro/launch_rate.hip -- 8 threads with a 150 us kernel each reach 25.6 k launches/s on four
+// queues, 42.7 k on eight).  The slots of concurrent callers want one each: ask for eight, if nobody has decided yet and the
+// runtime has not started (it reads the variable at its first call).
+__attribute__((constructor)) static void kdb_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 extern "C" int kdb_abi_version(void) { return KDB_ABI_VERSION; }
 
 extern "C" int kdb_hip_device_count(void) {
@@ -166,6 +171,12 @@ int kdb_ensure_visited(kdb_index *idx, uint32_t slots, hipStream_t s) {
         idx->vis_slots = 0;
     }
     uint32_t words = (((idx->cap >> 5) + 1) + 3u) & ~3u;
+    // growth in powers of two while that costs less than 1 GiB (batches of concurrent callers come in every size: no re-allocation --
+    // a device-wide synchronisation -- per new size), exact beyond
+    uint32_t want = 16u;
+    while (want < slots) want *= 2u;
+    if ((size_t)want * words * 4 > ((size_t)1 << 30)) want = slots;
+    slots = want;
     KDB_HIP(hipMalloc(&idx->d_visited, (size_t)slots * words * 4));
     KDB_HIP(hipMemsetAsync(idx->d_visited, 0, (size_t)slots * words * 4, s)); // on the stream the walk will run on
     idx->vis_slots = slots;
@@ -306,6 +317,10 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int i = 0; i < idx->n_slots; i++) KDB_TRY(hipStreamCreateWithPriority(&idx->slots[i].stream, hipStreamNonBlocking, prio_hi));
+        // completion words of the combined launches: page-locked, coherent, written by the kernels at system scope
+        KDB_TRY(hipHostMalloc(reinterpret_cast<void **>(&idx->h_done_pool), (size_t)KDB_GROUP_POOL * KDB_GROUP_CAP * 4, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(idx->h_done_pool, 0, (size_t)KDB_GROUP_POOL * KDB_GROUP_CAP * 4);
+        for (int i = 0; i < KDB_GROUP_POOL; i++) idx->groups[i].h_done = idx->h_done_pool + (size_t)i * KDB_GROUP_CAP;
     }
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         KDB_TRY(hipEventCreate(&idx->ring_ev0[i]));
@@ -367,6 +382,7 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
         if (idx->ring_ev0[i]) (void)hipEventDestroy(idx->ring_ev0[i]);
         if (idx->ring_ev1[i]) (void)hipEventDestroy(idx->ring_ev1[i]);
     }
+    if (idx->h_done_pool) (void)hipHostFree(idx->h_done_pool);
     for (kdb_slot &sl : idx->slots) {
         if (sl.d_io) (void)hipFree(sl.d_io);
         if (sl.h_pin) (void)hipHostFree(sl.h_pin);
@@ -887,6 +903,11 @@ static uint32_t effective_ef(uint32_t ef, uint32_t flags) {
     return ef;
 }
 
+struct KdbDone { // completion words of a combined launch (KdbMultiAllow::done_flags)
+    uint32_t *flags;
+    uint32_t gen;
+};
+
 struct MultiLists { // heterogeneous batch (kdb_search_batch_multi_dev): G lists back to back + the list of every query
     uint32_t G = 0;
     uint64_t words64 = 0;
@@ -895,7 +916,7 @@ struct MultiLists { // heterogeneous batch (kdb_search_batch_multi_dev): G lists
 
 static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef,
                              const uint64_t *d_allow_bits, uint32_t flags, uint32_t *d_out_ids, float *d_out_dist,
-                             uint32_t *d_out_count, hipStream_t s, const MultiLists *ml = nullptr) {
+                             uint32_t *d_out_count, hipStream_t s, const MultiLists *ml = nullptr, const KdbDone *done = nullptr) {
     KdbView v = kdb_make_view(idx);
     if (B == 0) return KDB_OK;
     if (k == 0) {
@@ -905,6 +926,10 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
     if (idx->max_level < 0 || idx->count == 0) { // empty index returns [] (hnsw_index.go:383-385)
         KDB_HIP(hipMemsetAsync(d_out_count, 0, (size_t)B * 4, s));
         KDB_HIP(hipMemsetAsync(d_out_ids, 0, (size_t)B * k * 4, s));
+        if (done) { // (combined callers watch their completion words: publish them behind the zeros, from the host)
+            KDB_HIP(hipStreamSynchronize(s));
+            for (uint32_t b = 0; b < B; b++) __atomic_store_n(done->flags + b, done->gen, __ATOMIC_RELEASE);
+        }
         return KDB_OK;
     }
     if (!idx->has_graph) {
@@ -919,6 +944,10 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
     }
     const uint32_t *d_allow = reinterpret_cast<const uint32_t *>(d_allow_bits);
     KdbMultiAllow ma;
+    if (done) {
+        ma.done_flags = done->flags;
+        ma.done_gen = done->gen;
+    }
     if (ml && ml->G) { // one entry point per list, chosen on the device: no host round trip for any of the G lists
         int rc = kdb_ensure_group_entries(idx, ml->G);
         if (rc) return rc;
@@ -998,9 +1027,10 @@ extern "C" int kdb_search_batch_dev(kdb_index *idx, const float *d_queries, uint
 // (pkg/engine/ops.go:1003-1007): any number of one-query calls are inside the index at once.  Here idx->mu is held only to pick a
 // slot and to enqueue; staging copies, the wait for the answers and the copy back happen outside it.
 //   * a call that finds a free slot goes out at once, alone (a lone caller never waits for company);
-//   * a call that finds every slot busy joins -- or founds -- the group that waits for the next free slot: calls of up to
-//     KDB_COMBINE_MAX_B queries with the same (k, ef, flags) and no allow list become ONE launch; the founder (leader) stages
-//     and launches, every member sleeps on the group's futex word and copies its own answers out of the slot's page-locked buffer;
+//   * a search of up to KDB_COMBINE_MAX_B queries without an allow list that finds every slot busy joins -- or founds -- the group
+//     that waits for the next free slot: same (k, ef, flags) = ONE launch.  The thread that frees a slot launches the group
+//     (nobody is woken for it); the kernel reads the queries from the slot's page-locked buffer, writes the answers there and
+//     publishes a completion word per query; every member watches its own words and leaves when ITS walk is done;
 //   * writers wait until no such call is in flight and hold new ones back meanwhile (KdbWriteLock);
 //   * calls too large for a slot (KDB_HOST_PIN_MAX), traced calls and KDB_SEARCH_FAIL_ON_DROP take turns on the index's own
 //     staging buffer (big_mu), still without holding idx->mu while they wait.
@@ -1022,21 +1052,13 @@ static StagedLayout staged_layout(const kdb_index *idx, uint32_t B, uint32_t k, 
     return L;
 }
 
-static void futex_wait_set(std::atomic<uint32_t> &w) {
-    while (w.load(std::memory_order_acquire) == 0u)
-        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
-}
-static void futex_wake_all(std::atomic<uint32_t> &w) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
-}
-
 static int slot_find_free(const kdb_index *idx) {
     for (int i = 0; i < idx->n_slots; i++)
         if (!idx->slots[i].busy) return i;
     return -1;
 }
 
-// under idx->mu, slot idle (its last group has synchronised its stream and every member has left)
+// under idx->mu, slot idle (its last call has left)
 static int slot_ensure(kdb_slot &sl, size_t bytes) {
     if (sl.bytes >= bytes) return KDB_OK;
     if (sl.d_io) (void)hipFree(sl.d_io);
@@ -1045,8 +1067,13 @@ static int slot_ensure(kdb_slot &sl, size_t bytes) {
     sl.bytes = 0;
     size_t want = bytes * 2 < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + bytes / 4;
     KDB_HIP(hipMalloc(&sl.d_io, want));
-    // (coherent: the kernels of small calls write their answers straight into this buffer)
-    KDB_HIP(hipHostMalloc(&sl.h_pin, want, hipHostMallocCoherent));
+    // (coherent + mapped: the kernels of small calls read their queries from and write their answers straight into this buffer)
+    KDB_HIP(hipHostMalloc(&sl.h_pin, want, hipHostMallocCoherent | hipHostMallocMapped));
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, sl.h_pin, 0) != hipSuccess || dp != sl.h_pin) { // (one address space on this platform: kernels take the host pointer)
+        kdb_set_error("page-locked staging memory is not addressable by the device under its host address");
+        return KDB_ERR_HIP;
+    }
     sl.bytes = want;
     return KDB_OK;
 }
@@ -1056,73 +1083,42 @@ static size_t host_pin_max() { // calls whose buffers exceed this go through the
     return v;
 }
 
-// One host-pointer call through a slot.  run(d_q, d_allow, d_ids, d_dist, d_cnt, stream, nq) enqueues the work (under idx->mu).
-// kind: 1 graph search (combinable), 2 exact scan.  Page-locked staging: one memcpy in, one copy of queries | allow list, ONE
-// device-to-host copy of ids | distances | counts, one memcpy out -- or, for a graph search of a few queries, none: the kernel
-// writes its answers straight into the page-locked buffer (posted writes over PCIe; the end of the kernel makes them visible).
-// 1M x 768, ef=60, per call (scripts/host_probe.py, round 3): 1 query 0.179 ms (0.228 through the runtime's pageable copies).
-template <typename F>
-static int staged_slot_call(kdb_index *idx, uint32_t kind, const float *queries, uint32_t B, uint32_t k, uint32_t ef, const uint64_t *allow_bits,
-                            uint32_t flags, uint32_t *out_ids, void *out_dist, uint32_t *out_count, size_t dist_bytes, bool direct_out, F run) {
-    static const uint32_t combine_max_b = [] { const char *e = getenv("KDB_COMBINE_MAX_B"); return e ? (uint32_t)atoi(e) : 16u; }();
-    static const uint32_t group_cap = [] { const char *e = getenv("KDB_COMBINE_GROUP"); return e ? (uint32_t)atoi(e) : 256u; }();
-    static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
-    const size_t dim = idx->desc.dim;
-    std::unique_lock<std::mutex> lk(idx->mu);
-    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
-    const bool combinable = kind == 1 && !allow_bits && B <= combine_max_b && B <= group_cap;
-    kdb_group *g = nullptr;
-    uint32_t my_off = 0;
-    if (combinable && idx->forming) {
-        kdb_group *f = idx->forming;
-        if (f->kind == kind && f->k == k && f->ef == ef && f->flags == flags && f->nq + B <= f->cap_q) {
-            g = f;
-            my_off = g->nq;
-            g->nq += B;
-            g->refs++;
-            g->members.push_back({queries, B});
+static uint64_t now_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+// ---- combined searches -------------------------------------------------------------------------
+static kdb_group *group_get(kdb_index *idx) { // under mu
+    for (kdb_group &g : idx->groups)
+        if (!g.in_use) {
+            g.in_use = true;
+            g.gen++;
+            if (g.gen == 0u) g.gen = 1u; // (0 is what a fresh pool holds)
+            g.nq = g.refs = 0;
+            g.slot = -1;
+            g.rc = KDB_OK;
+            g.err[0] = 0;
+            g.launched.store(0u, std::memory_order_relaxed);
+            g.failed.store(0u, std::memory_order_relaxed);
+            g.members.clear();
+            return &g;
         }
-    }
-    auto leave = [&](kdb_group *grp) { // under mu: the last member out gives the slot back
-        if (--grp->refs == 0) {
-            if (grp->slot >= 0) idx->slots[grp->slot].busy = false;
-            delete grp;
-            idx->slot_cv.notify_all();
-        }
-    };
-    auto take = [&](const kdb_group *grp, uint32_t off) { // a member's own answers, out of the slot's page-locked buffer
-        memcpy(out_ids, grp->h_ids + (size_t)off * k * 4, (size_t)B * k * 4);
-        memcpy(out_dist, grp->h_dist + (size_t)off * k * grp->dist_bytes, (size_t)B * k * grp->dist_bytes);
-        memcpy(out_count, grp->h_cnt + (size_t)off * 4, (size_t)B * 4);
-    };
-    if (g) { // ---- follower
-        lk.unlock();
-        futex_wait_set(g->done);
-        const int rc = g->rc;
-        if (rc == KDB_OK) take(g, my_off);
-        else kdb_set_error("%s", g->err);
-        lk.lock();
-        leave(g);
-        return rc;
-    }
-    // ---- leader (of a group of one unless others join while it waits for a slot)
-    g = new (std::nothrow) kdb_group();
-    if (!g) return KDB_ERR_OOM;
-    g->kind = kind;
-    g->k = k;
-    g->ef = ef;
-    g->flags = flags;
-    g->cap_q = combinable ? group_cap : B;
-    g->nq = B;
-    g->refs = 1;
-    g->dist_bytes = dist_bytes;
-    g->members.push_back({queries, B});
-    int si = slot_find_free(idx);
-    if (si < 0) {
-        if (combinable && !idx->forming) idx->forming = g;
-        idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
-        if (idx->forming == g) idx->forming = nullptr; // sealed: later callers found the next group
-    }
+    return nullptr;
+}
+
+static void group_fail(kdb_group *g, int rc) {
+    g->rc = rc;
+    snprintf(g->err, sizeof g->err, "%s", kdb_last_error());
+    g->failed.store(1u, std::memory_order_release);
+}
+
+// Launch group g (sealed: no longer idx->forming) on the free slot si.  Under idx->mu on entry and exit; the lock is dropped
+// while the members' queries are copied into the slot's page-locked buffer.  ONE kernel launch (two with KDB_SEARCH_HEAP_ORDER):
+// no copy commands -- the kernel reads the queries from the page-locked buffer, writes the answers there and publishes a
+// completion word per query.  Any thread may do this for any group: the founder when a slot is free, else whoever frees one.
+static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk, kdb_group *g, int si) {
     kdb_slot &sl = idx->slots[si];
     sl.busy = true;
     g->slot = si;
@@ -1131,17 +1127,195 @@ static int staged_slot_call(kdb_index *idx, uint32_t kind, const float *queries,
     idx->n_groups++;
     idx->n_group_members += g->members.size();
     if (nq > idx->largest_group) idx->largest_group = nq;
-    const StagedLayout L = staged_layout(idx, nq, k, allow_bits != nullptr, dist_bytes);
+    const StagedLayout L = staged_layout(idx, nq, g->k, false, g->dist_bytes);
     int rc = slot_ensure(sl, L.total);
-    unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin), *const d = reinterpret_cast<unsigned char *>(sl.d_io);
-    bool queued = false;
     if (rc == KDB_OK) {
-        lk.unlock(); // stage in outside the lock (inflight > 0 keeps writers out: count and capacity cannot move)
+        unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin);
+        const size_t dim = idx->desc.dim;
+        lk.unlock(); // (inflight > 0 keeps writers out; the group is sealed: its member list is final)
         size_t o = 0;
         for (const kdb_group::Member &m : g->members) {
             memcpy(h + o, m.q, (size_t)m.B * dim * 4);
             o += (size_t)m.B * dim * 4;
         }
+        lk.lock();
+        g->h_ids = h + L.o_ids;
+        g->h_dist = h + L.o_dist;
+        g->h_cnt = h + L.o_cnt;
+        g->t_launch_ns = now_ns();
+        g->launched.store(1u, std::memory_order_release); // (before the kernel can publish a word: a member that sees its word set finds these fields)
+        KdbDone done{g->h_done, g->gen};
+        KdbLaneGuard lane(idx, sl.stream);
+        rc = lane.rc;
+        if (rc == KDB_OK)
+            rc = search_dev_locked(idx, reinterpret_cast<float *>(h), nq, g->k, g->ef, nullptr, g->flags, reinterpret_cast<uint32_t *>(h + L.o_ids),
+                                   reinterpret_cast<float *>(h + L.o_dist), reinterpret_cast<uint32_t *>(h + L.o_cnt), sl.stream, nullptr, &done);
+    }
+    if (rc) group_fail(g, rc);
+}
+
+void kdb_launch_forming(kdb_index *idx, std::unique_lock<std::mutex> &lk) {
+    if (!idx->forming || idx->writers_waiting) return;
+    const int si = slot_find_free(idx);
+    if (si < 0) return;
+    kdb_group *g = idx->forming;
+    idx->forming = nullptr;
+    (void)hipSetDevice(idx->device);
+    launch_search_group(idx, lk, g, si);
+}
+
+// A member watches its own completion words.  The first few watchers of an index spin politely (what hipStreamSynchronize does,
+// without its queue of signals); the others sleep: once for most of the expected time, then in short naps -- 64 callers must not
+// burn 64 cores (a serving process usually runs under a CPU quota).
+static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t B) {
+    static const uint32_t spin_max = [] { const char *e = getenv("KDB_SPIN_WATCHERS"); return e ? (uint32_t)atoi(e) : 4u; }();
+    static thread_local bool slack_set = false;
+    const uint32_t gen = g->gen;
+    const uint32_t *w = g->h_done + off;
+    auto ready = [&] {
+        for (uint32_t i = 0; i < B; i++)
+            if (__atomic_load_n(w + i, __ATOMIC_ACQUIRE) != gen) return false;
+        return true;
+    };
+    const uint64_t t0 = now_ns();
+    const bool spin = idx->flag_waiters.fetch_add(1u, std::memory_order_relaxed) < spin_max;
+    int rc = KDB_OK;
+    if (!spin && !slack_set) { // naps of 15 us need a timer slack below the default 50 us (this thread only)
+        (void)prctl(PR_SET_TIMERSLACK, 2000ul, 0ul, 0ul, 0ul);
+        slack_set = true;
+    }
+    auto nap = [](uint64_t ns) {
+        struct timespec ts = {(time_t)(ns / 1000000000ull), (long)(ns % 1000000000ull)};
+        (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+    };
+    bool first = true;
+    uint64_t last_check = t0;
+    for (;;) {
+        if (ready()) break;
+        if (g->failed.load(std::memory_order_acquire)) {
+            rc = g->rc ? g->rc : KDB_ERR_HIP;
+            kdb_set_error("%s", g->err);
+            break;
+        }
+        const uint64_t el = now_ns() - t0;
+        if (spin && el < 2000000ull) {
+            sched_yield();
+            continue;
+        }
+        if (first && !spin) {
+            first = false;
+            const uint64_t est = idx->walk_ns.load(std::memory_order_relaxed);
+            if (est > el + 40000ull) {
+                nap(est - el - 25000ull > 400000ull ? 400000ull : est - el - 25000ull);
+                continue;
+            }
+        }
+        nap(el < 1000000ull ? 15000ull : el < 5000000ull ? 50000ull : el < 100000000ull ? 200000ull : 1000000ull);
+        // a device fault leaves the words unset for ever: now and then ask the stream (any member may; the answer is for all)
+        const uint64_t t = now_ns();
+        if (t - t0 > 2000000000ull && t - last_check > 500000000ull && g->launched.load(std::memory_order_acquire) && !g->failed.load(std::memory_order_acquire)) {
+            last_check = t;
+            const hipError_t e = hipStreamQuery(idx->slots[g->slot].stream);
+            if (e != hipErrorNotReady && !ready()) {
+                kdb_set_error(e == hipSuccess ? "combined search: the launch finished without publishing every answer" : "combined search: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+                group_fail(g, KDB_ERR_HIP);
+            }
+        }
+    }
+    idx->flag_waiters.fetch_sub(1u, std::memory_order_relaxed);
+    if (rc == KDB_OK) { // running estimate (1/8 weights) of what a caller waits, for the next watcher's first sleep
+        const uint64_t el = now_ns() - t0;
+        const uint32_t old = idx->walk_ns.load(std::memory_order_relaxed);
+        const uint64_t upd = ((uint64_t)old * 7u + (el > 2000000ull ? 2000000ull : el)) / 8u;
+        idx->walk_ns.store((uint32_t)upd, std::memory_order_relaxed);
+    }
+    return rc;
+}
+
+static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t flags, uint32_t *out_ids,
+                                void *out_dist, uint32_t *out_count) {
+    const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
+    kdb_group *g = idx->forming;
+    uint32_t off = 0;
+    if (g && g->k == k && g->ef == ef && g->flags == flags && g->nq + B <= KDB_GROUP_CAP) { // join the group that waits for a slot
+        off = g->nq;
+        g->nq += B;
+        g->refs++;
+        g->members.push_back({queries, B});
+    } else {
+        while (!(g = group_get(idx))) idx->slot_cv.wait(lk); // (more founders than group objects: wait for one to come back)
+        g->k = k;
+        g->ef = ef;
+        g->flags = flags;
+        g->dist_bytes = dist_bytes;
+        g->nq = B;
+        g->refs = 1;
+        g->members.push_back({queries, B});
+        int si = idx->writers_waiting ? -1 : slot_find_free(idx);
+        if (si >= 0) {
+            launch_search_group(idx, lk, g, si); // a free slot: out at once, alone
+        } else if (!idx->forming) {
+            idx->forming = g; // whoever frees a slot (or ends a write) launches it; callers arriving meanwhile join
+        } else { // the forming group is full or has another key: wait for a slot like any other call
+            idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
+            launch_search_group(idx, lk, g, si);
+        }
+    }
+    lk.unlock();
+    int rc = watch_done_words(idx, g, off, B);
+    if (rc == KDB_OK) {
+        while (!g->launched.load(std::memory_order_acquire)) sched_yield(); // (set before the launch: orders the reads below behind the launcher's writes)
+        memcpy(out_ids, g->h_ids + (size_t)off * k * 4, (size_t)B * k * 4);
+        memcpy(out_dist, g->h_dist + (size_t)off * k * dist_bytes, (size_t)B * k * dist_bytes);
+        memcpy(out_count, g->h_cnt + (size_t)off * 4, (size_t)B * 4);
+    }
+    lk.lock();
+    if (--g->refs == 0) { // the last member out: every walk of the launch is done (its words are set), the slot and the group object are free
+        if (g->failed.load(std::memory_order_acquire) && g->slot >= 0) {
+            lk.unlock();
+            (void)hipStreamSynchronize(idx->slots[g->slot].stream); // (whatever was queued must not outlive the slot's next use)
+            lk.lock();
+        }
+        if (g->slot >= 0) {
+            idx->slots[g->slot].busy = false;
+            idx->inflight--;
+        } else if (idx->forming == g) {
+            idx->forming = nullptr;
+        }
+        g->in_use = false;
+        kdb_launch_forming(idx, lk); // the group that gathered meanwhile leaves NOW, launched by this thread
+        idx->slot_cv.notify_all();
+    }
+    return rc;
+}
+
+// One host-pointer call through a slot, alone: exact scans, filtered searches, searches of more than KDB_COMBINE_MAX_B queries.
+// run(d_q, d_allow, d_ids, d_dist, d_cnt, stream, B) enqueues the work (under idx->mu).  Page-locked staging: one memcpy in, one
+// copy of queries | allow list, ONE device-to-host copy of ids | distances | counts, one memcpy out -- or, for a graph search of
+// a few queries, none: the kernel writes its answers straight into the page-locked buffer (posted writes over PCIe; the end of
+// the kernel makes them visible).
+template <typename F>
+static int staged_slot_call(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits, uint32_t *out_ids, void *out_dist,
+                            uint32_t *out_count, size_t dist_bytes, bool direct_out, F run) {
+    static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
+    std::unique_lock<std::mutex> lk(idx->mu);
+    int si = -1;
+    idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
+    kdb_slot &sl = idx->slots[si];
+    sl.busy = true;
+    idx->inflight++;
+    idx->n_groups++;
+    idx->n_group_members++;
+    const StagedLayout L = staged_layout(idx, B, k, allow_bits != nullptr, dist_bytes);
+    int rc = slot_ensure(sl, L.total);
+    unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin), *const d = reinterpret_cast<unsigned char *>(sl.d_io);
+    bool queued = false;
+    if (rc == KDB_OK) {
+        lk.unlock(); // stage in outside the lock (inflight > 0 keeps writers out: count and capacity cannot move)
+        memcpy(h, queries, L.qbytes);
         if (allow_bits) memcpy(h + L.o_allow, allow_bits, L.aw);
         lk.lock();
         const bool direct = direct_out && L.out_span <= direct_max;
@@ -1158,7 +1332,7 @@ static int staged_slot_call(kdb_index *idx, uint32_t kind, const float *queries,
             if (rc == KDB_OK)
                 rc = run(reinterpret_cast<float *>(d), allow_bits ? reinterpret_cast<uint64_t *>(d + L.o_allow) : nullptr,
                          reinterpret_cast<uint32_t *>(o_base + L.o_ids), reinterpret_cast<float *>(o_base + L.o_dist),
-                         reinterpret_cast<uint32_t *>(o_base + L.o_cnt), sl.stream, nq);
+                         reinterpret_cast<uint32_t *>(o_base + L.o_cnt), sl.stream, B);
         }
         if (rc == KDB_OK && !direct && hipMemcpyAsync(h + L.o_ids, d + L.o_ids, L.out_span, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) {
             kdb_set_error("staging copy from the device failed");
@@ -1169,22 +1343,17 @@ static int staged_slot_call(kdb_index *idx, uint32_t kind, const float *queries,
             kdb_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
             rc = KDB_ERR_HIP;
         }
-    } else {
-        lk.unlock();
+        if (rc == KDB_OK) {
+            memcpy(out_ids, h + L.o_ids, (size_t)B * k * 4);
+            memcpy(out_dist, h + L.o_dist, (size_t)B * k * dist_bytes);
+            memcpy(out_count, h + L.o_cnt, (size_t)B * 4);
+        }
+        lk.lock();
     }
-    g->rc = rc;
-    if (rc) snprintf(g->err, sizeof g->err, "%s", kdb_last_error());
-    g->h_ids = h + L.o_ids;
-    g->h_dist = h + L.o_dist;
-    g->h_cnt = h + L.o_cnt;
-    const bool company = g->members.size() > 1;
-    g->done.store(1u, std::memory_order_release);
-    if (company) futex_wake_all(g->done);
-    if (rc == KDB_OK) take(g, 0);
-    lk.lock();
+    sl.busy = false;
     idx->inflight--;
-    if (idx->inflight == 0 && idx->writers_waiting) idx->slot_cv.notify_all();
-    leave(g);
+    kdb_launch_forming(idx, lk);
+    idx->slot_cv.notify_all();
     return rc;
 }
 
@@ -1388,7 +1557,9 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     const size_t need = (size_t)B * idx->desc.dim * 4 + (allow_bits ? ((size_t)(idx->cap >> 6) + 1) * 8 : 0) + (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 4096;
     if (traced || (flags & KDB_SEARCH_FAIL_ON_DROP) || need > host_pin_max())
         return staged_big_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, (flags & KDB_SEARCH_FAIL_ON_DROP) != 0, run);
-    return staged_slot_call(idx, 1u, queries, B, k, ef, allow_bits, flags, out_ids, out_dist, out_count, dist_bytes, true, run);
+    static const uint32_t combine_max_b = [] { const char *e = getenv("KDB_COMBINE_MAX_B"); return e ? (uint32_t)atoi(e) : 16u; }();
+    if (!allow_bits && B <= combine_max_b && B <= KDB_GROUP_CAP) return combined_search_call(idx, queries, B, k, ef, flags, out_ids, out_dist, out_count);
+    return staged_slot_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, true, run);
 }
 
 // statistics of the combiner: out[0] launches of host-pointer calls that went through a slot, out[1] calls they carried,
@@ -1548,7 +1719,7 @@ extern "C" int kdb_flat_scan_batch(kdb_index *idx, const float *queries, uint32_
     };
     const size_t need = (size_t)B * idx->desc.dim * 4 + (allow_bits ? ((size_t)(idx->cap >> 6) + 1) * 8 : 0) + (size_t)B * k * (4 + dist_bytes) + (size_t)B * 4 + 4096;
     if (need > host_pin_max()) return staged_big_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, false, run);
-    return staged_slot_call(idx, 2u, queries, B, k, 0u, allow_bits, flags, out_ids, out_dist, out_count, dist_bytes, false, run);
+    return staged_slot_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, false, run);
 }
 
 static int distance_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B, const uint32_t *d_ids, uint32_t C,

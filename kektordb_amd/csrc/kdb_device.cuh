@@ -6,6 +6,13 @@
 
 #define KDB_WAVE 64
 
+// Completion word of one query of a combined launch (KdbMultiAllow::done_flags): every store of this wave -- the answer, in
+// page-locked host memory -- is acknowledged before lane 0 publishes the word (release at system scope, no invalidate).
+__device__ __forceinline__ void kdb_publish_done(uint32_t *flag, uint32_t gen) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ int kdb_lane() { return (int)(threadIdx.x & 63u); }
 
 __device__ __forceinline__ unsigned kdb_mbcnt(unsigned long long m) {

@@ -46,6 +46,11 @@ struct KdbMultiAllow {
     const uint32_t *of_query = nullptr;
     const uint32_t *group_entry = nullptr;
     uint32_t words32 = 0;
+    // Per-query completion words (combined one-query callers, kdb_group): when set, the wave that has written query b's final
+    // answer stores done_gen into done_flags[b] at SYSTEM scope -- the words live in page-locked host memory, each caller watches
+    // its own and leaves as soon as ITS walk is done, not when the slowest walk of the launch is.
+    uint32_t *done_flags = nullptr;
+    uint32_t done_gen = 0;
 };
 
 // Per-call scratch of the asynchronous entry points.  An index keeps KDB_LANES sets; a call takes the set last used on
@@ -56,10 +61,15 @@ struct KdbMultiAllow {
 // Host-pointer calls of concurrent callers (hnsw_index.go:343-352: SearchWithScores runs under activeMu.RLock, any number of
 // goroutines at once) run in SLOTS: a slot = one stream + one pair of staging buffers (device / page-locked host).  idx->mu is
 // held to pick a slot and to enqueue; the wait for the answers happens OUTSIDE it, so up to n_slots calls are on the device at
-// once, each with the scratch lane of its stream.  Callers that find every slot busy are COMBINED: one-query calls with the same
-// (k, ef, flags) join the group that waits for the next free slot and go out as one launch (kdb_group).
+// once (as many as the process has hardware queues: GPU_MAX_HW_QUEUES), each with the scratch lane of its stream.  Searches of a
+// few queries without an allow list are COMBINED (kdb_group): a call that finds every slot busy joins the group that waits for
+// the next free slot; the thread that frees a slot launches that group at once (nobody has to be woken for it); the kernel reads
+// the queries from and writes the answers to page-locked memory and publishes a completion word per query, so every caller
+// leaves when ITS walk is done.
 #define KDB_MAX_SLOTS 16
 #define KDB_LANES (2 + KDB_MAX_SLOTS)
+#define KDB_GROUP_POOL (KDB_MAX_SLOTS + 2)
+#define KDB_GROUP_CAP 256u  // queries one combined launch may carry (completion words per group)
 struct kdb_slot {
     hipStream_t stream = nullptr;
     void *d_io = nullptr;   // queries | allow list | ids | distances | counts (device side)
@@ -68,19 +78,23 @@ struct kdb_slot {
     bool busy = false;
 };
 struct kdb_group {
-    uint32_t kind = 0, k = 0, ef = 0, flags = 0; // the key callers must share to join
-    uint32_t cap_q = 0;                          // queries it may hold
-    uint32_t nq = 0;                             // queries joined so far (final once the group has its slot)
+    uint32_t k = 0, ef = 0, flags = 0;           // the key callers must share to join
+    uint32_t nq = 0;                             // queries joined so far (final once the group is sealed)
     uint32_t refs = 0;                           // callers that have not taken their answers yet
     int slot = -1;
+    bool in_use = false;
     int rc = 0;
     char err[256] = "";
-    std::atomic<uint32_t> done{0};               // futex word: followers sleep on it, the leader sets and wakes
+    uint32_t gen = 0;                            // value of a completion word that means "done" for THIS use of the group object
+    uint32_t *h_done = nullptr;                  // KDB_GROUP_CAP completion words, page-locked (written by the kernels)
+    std::atomic<uint32_t> launched{0};           // set (release) by the launching thread once the fields below are valid
+    std::atomic<uint32_t> failed{0};             // the launch failed / the device faulted: rc and err say why
+    uint64_t t_launch_ns = 0;
     struct Member {
         const float *q;
         uint32_t B;
     };
-    std::vector<Member> members;                 // callers' query buffers (every member is blocked in its call until `done`)
+    std::vector<Member> members;                 // callers' query buffers (every member is blocked in its call until its words are set)
     const unsigned char *h_ids = nullptr, *h_dist = nullptr, *h_cnt = nullptr; // the answers, page-locked
     size_t dist_bytes = 4;
 };
@@ -176,6 +190,10 @@ struct kdb_index {
     uint32_t writers_waiting = 0;  // ... and new calls wait while a writer does (no writer starvation)
     std::condition_variable slot_cv; // leaders waiting for a slot, writers waiting for inflight == 0
     kdb_group *forming = nullptr;  // the group that waits for the next free slot and may still be joined
+    kdb_group groups[KDB_GROUP_POOL];
+    uint32_t *h_done_pool = nullptr;          // KDB_GROUP_POOL x KDB_GROUP_CAP completion words, page-locked
+    std::atomic<uint32_t> flag_waiters{0};    // callers watching completion words right now (the first few spin, the others sleep)
+    std::atomic<uint32_t> walk_ns{150000};    // running estimate of join -> own answer, nanoseconds (first sleep of a watcher)
     std::mutex big_mu;             // calls too large for a slot share d_iobuf / stream / stream2: one at a time
     uint64_t n_groups = 0, n_group_members = 0, largest_group = 0; // statistics of the combiner (kdb_index_caller_stats)
     // scratch lanes: the fields d_visited / d_scratch / d_qbuf / d_gentry / d_work above always name the CURRENT lane's
@@ -194,14 +212,21 @@ int kdb_lane_release(kdb_index *idx, hipStream_t s);
 // Writers (upload, delete, build, reserve ...) exclude host-pointer calls in flight the way the reference's activeMu.Lock excludes
 // its RLock holders: take mu, announce, wait until no call's kernels can still be running.  (Calls of the _dev entry points run on
 // streams of the caller, who orders them -- as before.)
+void kdb_launch_forming(kdb_index *idx, std::unique_lock<std::mutex> &lk); // kdb_api.hip: under mu; no-op unless a group waits and a slot is free
 struct KdbWriteLock {
+    kdb_index *idx;
     std::unique_lock<std::mutex> lk;
-    explicit KdbWriteLock(kdb_index *idx) : lk(idx->mu) {
+    explicit KdbWriteLock(kdb_index *i) : idx(i), lk(i->mu) {
         if (idx->inflight) {
             idx->writers_waiting++;
             idx->slot_cv.wait(lk, [&] { return idx->inflight == 0; });
             idx->writers_waiting--;
-            if (idx->writers_waiting == 0) idx->slot_cv.notify_all();
+        }
+    }
+    ~KdbWriteLock() { // calls that gathered meanwhile: launch the waiting group, wake the callers that wait for a slot themselves
+        if (idx->writers_waiting == 0) {
+            kdb_launch_forming(idx, lk);
+            idx->slot_cv.notify_all();
         }
     }
 };

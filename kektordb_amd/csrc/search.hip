@@ -204,6 +204,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
             if (requeue) tie_list[2u + atomicAdd(tie_list, 1u)] = qi;
         }
+        if (ma.done_flags && !requeue) kdb_publish_done(ma.done_flags + qi, ma.done_gen); // (a requeued query is published by the second pass)
         tot_tied += b.tied;
         if (requeue) ctr.n_dist = ctr.n_hops = ctr.n_dropped = 0u;
         KDB_T(if (lane == 0 && qi < 64u) printf("q %u waves %d: hops %u dist %u inserts %u | cycles: total %llu upper-layers %llu | level 0: pop %llu list %llu visited %llu rows %llu predict+post %llu predict+post+insert %llu wait-for-wave-1 %llu | wave 1: visit %llu cycles, hint hits %u\n", qi, WIDE, ctr.n_hops, ctr.n_dist, ctr.n_ins, __builtin_readcyclecounter() - tq_start, ctr.t_upper, ctr.t_pop, ctr.t_adj, ctr.t_vis, ctr.t_dist, ctr.t_pred, ctr.t_ins, ctr.t_wait, WIDE > 1 ? *reinterpret_cast<unsigned long long *>(s.ctl + 12) : 0ull, WIDE > 1 ? s.ctl[14] : 0u);)

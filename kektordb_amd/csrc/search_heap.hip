@@ -334,6 +334,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
         if (over) { // the candidate heap outgrew its scratch: the fast walk's answer stays, the tie stays reported
             unresolved++;
             if (lane == 0 && (a.raw & 8u)) a.out_count[qi] |= 0x80000000u;
+            if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
             continue;
         }
         for (uint32_t p = (uint32_t)lane; p < a.k; p += 64) {
@@ -353,6 +354,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
             if (a.tr_ndist) a.tr_ndist[qi] = ctr.n_dist;
             if (a.tr_nhops) a.tr_nhops[qi] = ctr.n_hops;
         }
+        if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         wave_lds_fence();

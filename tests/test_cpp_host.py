@@ -95,7 +95,7 @@ def test_micro_batcher_against_oracle(tmp_path, oracle):
     assert p.returncode == 0, p.stderr
     r = subprocess.run([exe, path], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
-    assert r.stdout.strip().startswith("ok"), r.stdout
+    assert r.stdout.strip().splitlines()[-1].startswith("ok"), r.stdout   # (the lines before it report the direct callers' launches)
 
 
 def test_micro_batcher_logic_under_thread_sanitizer(tmp_path):

@@ -11,11 +11,11 @@ Bars:  * traversal / index / counter work is BIT-EXACT against the oracle run wi
 import numpy as np
 import pytest
 
-from conftest import make_corpus
+from conftest import make_corpus, assert_same_results_tol, TOL_SWAPS  # noqa: F401 (other test modules import the checker from here)
 
 pytestmark = pytest.mark.gpu
 
-REL, ABS = 1e-4, 1e-6
+from conftest import REL, ABS  # noqa: E402
 
 
 def build_pair(O, hip, X, metric, precision=0, m=16, efc=100, seed=7, deleted=()):
@@ -43,18 +43,6 @@ def flat_stats(idx):
     the low / high word of kdb_counters.n_hops"""
     h = idx.launch_stats(1)[0]["n_hops"]
     return h & 0xffffffff, h >> 32
-
-
-def assert_same_results_tol(ids_a, d_a, ids_b, d_b):
-    """same ids, distances within tolerance; swaps/differences allowed only between near-ties"""
-    n = min(len(ids_a), len(ids_b))
-    assert len(ids_a) == len(ids_b)
-    np.testing.assert_allclose(d_a, d_b, rtol=REL, atol=ABS)
-    for i in range(n):
-        if ids_a[i] != ids_b[i]:
-            # must be a near-tie: the other list contains this id at a position whose distance ties
-            tol = REL * abs(d_a[i]) + ABS
-            assert np.any(np.abs(d_b - d_a[i]) <= tol), (i, ids_a, ids_b)
 
 
 @pytest.mark.parametrize("metric", [0, 1])
