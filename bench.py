@@ -801,11 +801,13 @@ def heap_order_leg(idx, Q, k, ef, dev):
 
 
 def micro_batcher_leg(idx, Q, k, ef, per=150):
-    """The seam of the reference is ONE query per SearchWithScores call (hnsw_index.go:343); a lone query is a tie with one CPU core at
-    best (a hop is ~2 us of dependent latency on either machine).  What the shim does about it: 32 / 64 concurrent one-query callers
-    through kektor::hnsw::MicroBatcher (include/kektor_hip.hpp, the compiled counterpart of the Go batcher) over THIS index --
-    per-caller latency (p50 / p99) and the rate all callers see together, host buffers, beside the same callers making their own
-    one-query calls.  scripts/micro_batcher_leg.cpp, built here with g++."""
+    """The seam of the reference is ONE query per SearchWithScores call (hnsw_index.go:343) under a read lock, called from a goroutine per
+    request (pkg/engine/ops.go:1003-1007).  1 / 16 / 32 / 64 / 256 concurrent one-query callers on THIS index, host buffers: every
+    caller making its own kdb_search_batch call (the library serves them from its slots and combines the calls that find every slot
+    busy: kektor_hip.h "Conventions"), and the same callers through kektor::hnsw::MicroBatcher (include/kektor_hip.hpp, the compiled
+    counterpart of the Go shim's batcher, which hands unfiltered calls through to a combining index) -- per-caller latency
+    (p50 / p99), the rate all callers see together, the launches the library made, and where a call's time went.
+    scripts/micro_batcher_leg.cpp, built here with g++."""
     import ctypes as C
     so = f"/tmp/libkdb_mb_leg_{os.getpid()}.so"
     libdir = os.path.join(ROOT, "kektordb_amd", "lib")
@@ -816,17 +818,28 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
     idx.set_launch_timing(False)   # what a serving mirror runs (the host mirrors switch the per-launch events off)
     out = {}
     try:
-        for T, win in ((1, -1), (16, -1), (32, -1), (64, -1), (256, -1), (32, 0), (64, 0), (256, 0), (64, 150)):
+        try:
+            quota = open("/sys/fs/cgroup/cpu.max").read().split()
+            ncpu = max(1, int(int(quota[0]) / int(quota[1]))) if quota[0] != "max" else 0
+        except Exception:
+            ncpu = 0
+        out["caller_threads_pinned_to_cpus"] = ncpu  # (= the cgroup's CPU quota; 0 = not pinned) -- see scripts/micro_batcher_leg.cpp
+        for T, win in ((1, -1), (16, -1), (32, -1), (64, -1), (256, -1), (64, 0), (256, 0)):
             lat = np.zeros(T * per, dtype=np.float64)
+            phases = np.zeros(8, dtype=np.float64)
             wall, nb, lg, ans = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
             rc = L.kdb_bench_one_query_callers(C.c_void_p(idx.h.value), idx.dim, idx.metric, idx.precision, q.ctypes.data_as(C.c_void_p), q.shape[0], k, ef,
-                                               T, per, win, lat.ctypes.data_as(C.c_void_p), C.byref(wall), C.byref(nb), C.byref(lg), C.byref(ans))
+                                               T, per, win, lat.ctypes.data_as(C.c_void_p), C.byref(wall), C.byref(nb), C.byref(lg), C.byref(ans),
+                                               ncpu, phases.ctypes.data_as(C.c_void_p))
             assert rc == 0
             lat = lat.reshape(T, per)[:, per // 10:]   # (the first tenth of every caller's calls: start-up)
-            name = f"{T}_callers_" + ("direct_one_query_calls" if win < 0 else f"batcher_window_{win}us")
+            name = f"{T}_callers_" + ("direct_one_query_calls" if win < 0 else "through_the_batcher")
             out[name] = {"qps": round(T * per / wall.value, 1), "per_caller_p50_ms": round(float(np.percentile(lat, 50)) / 1e3, 4),
                          "per_caller_p99_ms": round(float(np.percentile(lat, 99)) / 1e3, 4), "gpu_calls": int(nb.value),
                          "largest_batch": int(lg.value), "answers_per_call": round(ans.value / (T * per), 2)}
+            if phases[4] > 0:
+                out[name]["combined_call_us"] = {"waiting_for_launch": round(float(phases[0]), 1), "launch_to_own_answer": round(float(phases[1]), 1),
+                                                 "a_thread_launching_a_group": round(float(phases[2]), 1), "naps_per_call": round(float(phases[3]), 2)}
     finally:
         idx.set_launch_timing(True)
         try:

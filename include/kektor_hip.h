@@ -35,7 +35,7 @@
  *   - handles are opaque, usable from any thread, and CONCURRENT callers are served concurrently, as the reference's
  *     read lock allows (hnsw_index.go:343-352; pkg/engine/ops.go:1003-1007 calls SearchWithScores from a goroutine per
  *     request).  The host-pointer entry points (kdb_search_batch, kdb_flat_scan_batch, kdb_distance_batch) hold the handle's
- *     lock only to pick one of KDB_SLOTS (8, at most 16) slots -- a stream and a pair of staging buffers -- and to enqueue;
+ *     lock only to pick one of KDB_SLOTS (4, at most 16) slots -- a stream and a pair of staging buffers -- and to enqueue;
  *     they wait for their answers outside it.  One-query callers that find every slot busy are combined: calls of up to
  *     KDB_COMBINE_MAX_B (16) queries with the same (k, ef, flags) and no allow list leave as ONE launch as soon as a slot is
  *     free (no window, no timer: a lone caller never waits); kdb_index_caller_stats counts launches and the calls they carried.
@@ -317,7 +317,9 @@ KDB_API int kdb_index_build(kdb_index *idx, uint32_t count, const kdb_build_para
  * Any number of nodes per call (the reference's Compress re-inserts 5000 at a time, core.go:1240): a target whose union of links
  * and requests outgrows LDS (4096 entries) is sorted in HBM scratch.  A re-used slot that is asked for links above its new
  * level GROWS, as the reference's node does (:2049-2053): afterwards its level is the highest one asked for.  efConstruction
- * up to 512.  A failure leaves the index as it was (same count, entry point, levels).  float32 / float16 / int8.      */
+ * up to 512.  A failure BEFORE the first link is written (arguments, allocations: everything is allocated up front) leaves the index as
+ * it was; a device failure later restores count, entry point and levels on the host, but lists already rewritten -- the re-used
+ * slot's among them -- stay as they are: upload the graph again.  float32 / float16 / int8.                              */
 #define KDB_ADD_REFERENCE_LINKS 1u /* (the only linking this entry point has; accepted for symmetry with kdb_build_params.flags) */
 KDB_API int kdb_index_add_batch(kdb_index *idx, uint32_t first_id, uint32_t n, const uint8_t *levels, uint32_t ef_construction,
                                 uint32_t flags);
@@ -409,9 +411,11 @@ KDB_API int kdb_get_launch_stats(kdb_index *idx, uint32_t last_n, kdb_counters *
 /* The graph-search launches are bracketed by two HIP events (kdb_counters.last_kernel_ms).  on = 0 drops them: two packets
  * less in the queue per call (9 us of a small-batch call); the counters stay, last_kernel_ms reads 0.  Default: on. */
 KDB_API int kdb_index_set_launch_timing(kdb_index *idx, int on);
-/* Statistics of the concurrent host-pointer calls (see "Conventions"): out[0] launches that left through a slot, out[1] the calls
- * they carried (out[1] / out[0] = callers per launch), out[2] the largest number of queries one launch carried, out[3] the
- * number of slots of this index. */
+/* Statistics of the concurrent host-pointer calls (see "Conventions"), out[10]: [0] launches that left through a slot, [1] the calls
+ * they carried ([1] / [0] = callers per launch), [2] the largest number of queries one launch carried, [3] the number of slots of
+ * this index; combined searches only: [4] calls, [5] nanoseconds they waited for their group's launch (sum), [6] nanoseconds from
+ * the launch until the caller saw its own answer complete (sum), [7] nanoseconds threads spent launching groups (sum), [8] timed
+ * naps of the waiting callers, [9] the running estimate of a call's wait (ns) that sizes the first nap. */
 KDB_API int kdb_index_caller_stats(kdb_index *idx, uint64_t *out);
 /* Block until all work queued on the index's internal stream has finished. */
 KDB_API int kdb_index_sync(kdb_index *idx);

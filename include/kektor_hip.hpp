@@ -151,6 +151,9 @@ class Index {
         return out;
     }
     kdb_index *handle() const { return h_; }
+    // concurrent kdb_search_batch calls of a few queries share launches inside the library (kektor_hip.h, "Conventions"): a
+    // batcher in front of this index passes unfiltered one-query calls through
+    bool CombinesConcurrentCalls() const { return true; }
     uint32_t Dim() const { return dim_; }
     uint32_t Count() const { // nodeCounter of the mirror
         uint32_t count = 0, entry = 0;
@@ -204,6 +207,10 @@ class Index {
 //     device idle wait that long for company (off by default);
 //   * followers sleep on their group's futex word and are woken by one FUTEX_WAKE -- no condition variable, no mutex to
 //     queue on when sixty answers arrive at once; no service thread, no timer thread;
+//   * an index that combines concurrent calls itself (IndexT::CombinesConcurrentCalls(): kektor::hnsw::Index does -- the library
+//     gathers one-query calls that find its slots busy into one launch and lets every caller leave when ITS walk is done, which
+//     a batch call cannot) gets unfiltered queries handed through one by one; the batcher then only groups what the library does
+//     not: queries that share an allow list (one upload of the list per group), and the routing below;
 //   * a filter that allows less than `flatScanSelectivity` of the ids takes the exact scan: the reference's filtered
 //     walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549) and falls apart there (the crossover is
 //     measured: bench.py's filter_routing leg).
@@ -218,6 +225,7 @@ class BasicMicroBatcher {
     };
     struct Stats {
         uint64_t calls = 0, batches = 0, flatBatches = 0, largest = 0;
+        uint64_t passedThrough = 0; // unfiltered calls handed to an index that combines concurrent calls itself
     };
     static constexpr int kMaxFlatK = 1024; // kdb_flat_scan_batch: k <= 1024
     explicit BasicMicroBatcher(IndexT &idx) : idx_(idx) {}
@@ -241,6 +249,16 @@ class BasicMicroBatcher {
 
     std::vector<SearchResult> SearchWithScores(const std::vector<float> &query, int k, const AllowList *allowList, int efSearch) {
         if (k <= 0 || query.size() != idx_.Dim()) return {};
+        if (!allowList && combines(idx_, 0)) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (closed_) return {};
+                stats_.calls++;
+                stats_.passedThrough++;
+            }
+            auto out = idx_.SearchBatch(query.data(), 1, k, nullptr, efSearch);
+            return out.empty() ? std::vector<SearchResult>() : std::move(out[0]);
+        }
         std::unique_lock<std::mutex> lk(mu_);
         if (closed_) return {};
         stats_.calls++;
@@ -324,6 +342,9 @@ class BasicMicroBatcher {
     }
 
   private:
+    // IndexT::CombinesConcurrentCalls() if it exists, else false (a test double, an index behind another transport)
+    template <class T> static auto combines(const T &i, int) -> decltype(i.CombinesConcurrentCalls()) { return i.CombinesConcurrentCalls(); }
+    template <class T> static bool combines(const T &, long) { return false; }
     using Key = std::tuple<int, int, const AllowList *>;
     struct Group {
         std::vector<const float *> queries; // callers' buffers: they are blocked in SearchWithScores until done

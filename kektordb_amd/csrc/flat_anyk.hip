@@ -9,7 +9,10 @@
 //                         (float bits made monotone | low word of the int8 float64 key) to HBM scratch [query][row position];
 //   2. anyk_select_kernel one workgroup per query: an 8-pass radix select of the k-th smallest key over those keys (they sit in
 //                         L2 / Infinity Cache: 8 MB per query at 1M rows), the entries below it plus -- in id order -- as many
-//                         at it as are needed (total order distance, then id), sorted in LDS, written out.
+//                         at it as are needed (total order distance, then id), sorted in LDS, written out.  The id order is
+//                         that of the IDS, not of the list positions: a filtered scan's id list is compacted by blocks that
+//                         claim their ranges in arrival order, so when more rows tie at the k-th distance than fit, a four-pass
+//                         radix select over their ids finds the largest id that still belongs.
 // HBM-bound on the rows (each query of a chunk streams them once: 3 GB per query at 1M x 768 f32, ~0.5 ms); that is the price
 // of a rarely used path that must be exact for any k, not a design for throughput -- k <= 128 keeps the matrix-core kernels.
 #include "kdb_search_core.cuh"
@@ -57,7 +60,7 @@ anyk_dist_kernel(KdbView v, const void *__restrict__ queries, const float *__res
     }
 }
 
-// the k smallest (key, position) of keys[0..n) -- positions ascend with ids -- sorted, converted and written out
+// the k smallest (key, id) of keys[0..n) -- position i holds id scan_ids[i], or i + 1 without a list -- sorted, converted, written out
 template <int PREC, int METRIC>
 __global__ void __launch_bounds__(256)
 anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, const uint32_t *__restrict__ scan_ids, const uint32_t *__restrict__ n_scan_dev,
@@ -68,7 +71,7 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
     uint32_t P = 64;
     while (P < k) P <<= 1;
     unsigned long long *e_key = reinterpret_cast<unsigned long long *>(smem); // [P]
-    uint32_t *e_pos = reinterpret_cast<uint32_t *>(e_key + P);                // [P]
+    uint32_t *e_pos = reinterpret_cast<uint32_t *>(e_key + P);                // [P] the entries' ids
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -110,7 +113,55 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
     }
     const bool take_all = kk >= n;
     const unsigned long long T = prefix;
-    const uint32_t need_eq = take_all ? 0u : kk - below; // entries AT the threshold, taken in position (= id) order
+    uint32_t need_eq = take_all ? 0u : kk - below; // entries AT the threshold, taken in id order
+    // With an id list positions do not ascend with ids: the need_eq smallest IDS among the entries at T are wanted.  Count them; if
+    // more tie than fit, select the need_eq-th smallest id among them (four 8-bit digits) and treat "at T with id <= that" as below T.
+    uint32_t id_cut = 0xffffffffu;
+    bool cut_by_id = false;
+    if (scan_ids && need_eq > 0u) {
+        if (tid == 0) sh[4] = 0u;
+        __syncthreads();
+        uint32_t mine = 0u;
+        for (uint32_t i = tid; i < n; i += 256u) mine += my[i] == T ? 1u : 0u;
+        if (mine) atomicAdd(&sh[4], mine);
+        __syncthreads();
+        const uint32_t eq_all = sh[4];
+        __syncthreads();
+        if (eq_all > need_eq) {
+            uint32_t idp = 0u, idb = 0u; // prefix of the id found so far, ids below it among the entries at T
+            for (int d = 3; d >= 0; d--) {
+                hist[tid] = 0u;
+                __syncthreads();
+                const int sb = d * 8;
+                const uint32_t hm = d == 3 ? 0u : (0xffffffffu << (sb + 8));
+                for (uint32_t i = tid; i < n; i += 256u)
+                    if (my[i] == T) {
+                        const uint32_t id = scan_ids[i];
+                        if ((id & hm) == (idp & hm)) atomicAdd(&hist[(id >> sb) & 255u], 1u);
+                    }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t acc = 0u, want = need_eq - idb, dig = 255u;
+                    for (uint32_t b = 0; b < 256u; b++) {
+                        if (acc + hist[b] >= want) {
+                            dig = b;
+                            break;
+                        }
+                        acc += hist[b];
+                    }
+                    sh[0] = dig;
+                    sh[1] = idb + acc;
+                }
+                __syncthreads();
+                idp |= sh[0] << sb;
+                idb = sh[1];
+                __syncthreads();
+            }
+            id_cut = idp; // ids are distinct: exactly need_eq entries at T have an id <= id_cut
+            cut_by_id = true;
+            need_eq = 0u;
+        }
+    }
     // ---- gather: one pass in position order (256 positions per step; the ranks of the entries at T need the order)
     if (tid == 0) {
         sh[2] = 0u; // entries gathered
@@ -120,7 +171,9 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
     for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         const uint32_t i = i0 + tid;
         const unsigned long long x = i < n ? my[i] : ~0ull;
-        const bool lt = i < n && (take_all || x < T), eq = i < n && !take_all && x == T;
+        const uint32_t my_id = i < n ? (scan_ids ? scan_ids[i] : i + 1u) : 0u;
+        const bool at_T = i < n && !take_all && x == T;
+        const bool lt = i < n && (take_all || x < T || (cut_by_id && at_T && my_id <= id_cut)), eq = at_T && !cut_by_id;
         const unsigned long long m_eq = __ballot(eq), m_lt = __ballot(lt);
         if (lane == 0) {
             hist[wave] = (uint32_t)__builtin_popcountll(m_eq);
@@ -140,14 +193,14 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
             const uint32_t slot = lt_before + lt_off + kdb_mbcnt(m_lt);
             if (slot < P) {
                 e_key[slot] = x;
-                e_pos[slot] = i;
+                e_pos[slot] = my_id;
             }
         }
         if (eq && my_eq_rank < need_eq) {
             const uint32_t slot = lt_before + lt_total + (my_eq_rank - eq_taken_before);
             if (slot < P) {
                 e_key[slot] = x;
-                e_pos[slot] = i;
+                e_pos[slot] = my_id;
             }
         }
         __syncthreads();
@@ -163,7 +216,7 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
         e_pos[i] = 0xffffffffu;
     }
     __syncthreads();
-    // ---- sort by (key, position) -- positions ascend with ids
+    // ---- sort by (key, id)
     for (uint32_t k2 = 2; k2 <= P; k2 <<= 1)
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
             for (uint32_t i = tid; i < P; i += 256u) {
@@ -185,8 +238,7 @@ anyk_select_kernel(const unsigned long long *__restrict__ keys, size_t stride, c
         }
     for (uint32_t i = tid; i < k; i += 256u) {
         const bool have = i < got;
-        const uint32_t pos = have ? e_pos[i] : 0u;
-        out_ids[(size_t)qi * k + i] = have ? (scan_ids ? scan_ids[pos] : pos + 1u) : 0u;
+        out_ids[(size_t)qi * k + i] = have ? e_pos[i] : 0u;
         const float key = have ? unord32((uint32_t)(e_key[i] >> 32)) : INFINITY;
         if constexpr (WK) {
             const double dv = have ? kdb_i8_key_double(key, (uint32_t)e_key[i]) : (double)INFINITY;

@@ -85,6 +85,7 @@ struct FsParams {
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
     uint32_t fb_grow;         // 1: compaction rounds thin out once the thresholds have settled (KDB_FB_NOGROW: A/B switch)
     uint32_t fb_seeded;       // 1: a seed launch published first thresholds into g_pub (KDB_FB_NOSEED: A/B switch)
+    uint32_t fb_seed_nstr;    // the number of stripes the HOST derived when it decided so: both kernels check it against fs_resolve's
     uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
     uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
     float *part_key;          // [n_stripes][n_qtiles*FS_TQ][kl]
@@ -2074,6 +2075,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
             uint32_t seed_min_tiles = 32u;
             if (const char *e = getenv("KDB_FB_SEED_MIN_TILES")) seed_min_tiles = (uint32_t)atoi(e); // (tests: the seed path on small cases)
             if (n_str >= 2u && last_rows >= (uint64_t)FB_T && share <= 16u && tiles_per >= seed_min_tiles) p.fb_seeded = 1u;
+            p.fb_seed_nstr = n_str;
         }
         p.fb_period = fb_period;
         { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }

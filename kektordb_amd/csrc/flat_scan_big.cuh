@@ -127,7 +127,16 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     uint32_t row_begin = stripe * geo.rows_per_stripe;
     uint32_t row_end = row_begin + geo.rows_per_stripe < geo.n_scan ? row_begin + geo.rows_per_stripe : geo.n_scan;
     uint32_t q0 = qtile * FB_T;
-    if (SEED) row_end = row_begin + FB_T; // (the host launches it only when every stripe holds a whole tile)
+    // The host decides on the seed launch from ITS copy of the stripe geometry ("same integer arithmetic as fs_resolve_n",
+    // flat_scan.hip).  Both launches re-check on the device, with the same expression: every stripe holds a whole tile, a stripe's
+    // share of the kl best fits the sixteen block maxima, and the host's stripe count is fs_resolve's.  Should the two ever drift,
+    // the seed publishes nothing and the scan reads nothing -- open thresholds, slower, still exact.
+    const bool seed_ok = p.fb_seeded && p.fb_seed_nstr == geo.n_stripes && geo.n_stripes >= 2u &&
+                         (geo.n_stripes - 1u) * geo.rows_per_stripe + FB_T <= geo.n_scan && (p.kl + geo.n_stripes - 1u) / geo.n_stripes <= 16u;
+    if (SEED) {
+        if (!seed_ok) return;
+        row_end = row_begin + FB_T;
+    }
     if (FB_DBG & 64u) { row_begin = 0; row_end = geo.rows_per_stripe; }   // measurement: every workgroup walks stripe 0
     if (FB_DBG & 128u) q0 = 0;                                             // measurement: every workgroup uses query tile 0
     const uint32_t qstride = p.n_qtiles * FS_TQ;
@@ -251,7 +260,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             }
         }
     };
-    if (!SEED && p.fb_seeded && p.g_pub) { // thresholds of the seed launch
+    if (!SEED && seed_ok && p.g_pub) { // thresholds of the seed launch
         read_published();
         __syncthreads();
     }
@@ -507,7 +516,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
         //  tile's first MFMA steps -- measured no different: 12.25 vs 12.26 ms)
         uint32_t per = p.fb_period;
         if (p.fb_grow) per = t < 64u ? per : t < 128u ? 2u * per : t < 256u ? 4u * per : 8u * per; // (powers of two: rounds stay aligned)
-        const bool compact_now = ((t == 0u && !p.fb_seeded) || (t + 1u) % per == 0u || flags[2] != 0u) && has_next;
+        const bool compact_now = ((t == 0u && !seed_ok) || (t + 1u) % per == 0u || flags[2] != 0u) && has_next;
         if (tm_on && (FB_DBG & 2048u)) tm_cmp += __builtin_readcyclecounter() - tm1; // 2048: the wait at this barrier alone
         if (compact_now) { // (the first tile keeps everything: thresholds start open)
             if (flags[0] && !(FB_DBG & 8u)) {

@@ -312,7 +312,7 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
     {   // slots of the concurrent host-pointer calls: their streams get the highest priority the device offers, so that a one-query
         // walk is not queued behind the waves of a large batch
         const char *e = getenv("KDB_SLOTS");
-        int ns = e ? atoi(e) : 8;
+        int ns = e ? atoi(e) : 4; // (four: the hardware queues a process has unless GPU_MAX_HW_QUEUES says otherwise; measured 4 vs 8: DESIGN 5.7)
         idx->n_slots = ns < 1 ? 1 : ns > KDB_MAX_SLOTS ? KDB_MAX_SLOTS : ns;
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1119,6 +1119,7 @@ static void group_fail(kdb_group *g, int rc) {
 // no copy commands -- the kernel reads the queries from the page-locked buffer, writes the answers there and publishes a
 // completion word per query.  Any thread may do this for any group: the founder when a slot is free, else whoever frees one.
 static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk, kdb_group *g, int si) {
+    const uint64_t t_in = now_ns();
     kdb_slot &sl = idx->slots[si];
     sl.busy = true;
     g->slot = si;
@@ -1152,6 +1153,7 @@ static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk
                                    reinterpret_cast<float *>(h + L.o_dist), reinterpret_cast<uint32_t *>(h + L.o_cnt), sl.stream, nullptr, &done);
     }
     if (rc) group_fail(g, rc);
+    idx->ns_in_launch.fetch_add(now_ns() - t_in, std::memory_order_relaxed);
 }
 
 void kdb_launch_forming(kdb_index *idx, std::unique_lock<std::mutex> &lk) {
@@ -1189,7 +1191,12 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
         (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
     };
     bool first = true;
-    uint64_t last_check = t0;
+    uint64_t last_check = t0, naps = 0;
+    const uint64_t est0 = idx->walk_ns.load(std::memory_order_relaxed);
+    // short naps, but no more than about ten per call however long calls take under the present load
+    static const uint64_t nap_div = [] { const char *e = getenv("KDB_NAP_DIV"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 10ull; }();
+    static const uint64_t nap_min = [] { const char *e = getenv("KDB_NAP_MIN_NS"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 15000ull; }();
+    const uint64_t nap_ns = est0 / nap_div < nap_min ? nap_min : est0 / nap_div > 150000ull ? 150000ull : est0 / nap_div;
     for (;;) {
         if (ready()) break;
         if (g->failed.load(std::memory_order_acquire)) {
@@ -1202,15 +1209,15 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
             sched_yield();
             continue;
         }
+        naps++;
         if (first && !spin) {
             first = false;
-            const uint64_t est = idx->walk_ns.load(std::memory_order_relaxed);
-            if (est > el + 40000ull) {
-                nap(est - el - 25000ull > 400000ull ? 400000ull : est - el - 25000ull);
+            if (est0 * 3u / 4u > el + nap_ns) { // most of the expected time in one piece
+                nap(est0 * 3u / 4u - el > 1000000ull ? 1000000ull : est0 * 3u / 4u - el);
                 continue;
             }
         }
-        nap(el < 1000000ull ? 15000ull : el < 5000000ull ? 50000ull : el < 100000000ull ? 200000ull : 1000000ull);
+        nap(el < 2000000ull ? nap_ns : el < 100000000ull ? 200000ull : 1000000ull);
         // a device fault leaves the words unset for ever: now and then ask the stream (any member may; the answer is for all)
         const uint64_t t = now_ns();
         if (t - t0 > 2000000000ull && t - last_check > 500000000ull && g->launched.load(std::memory_order_acquire) && !g->failed.load(std::memory_order_acquire)) {
@@ -1224,8 +1231,13 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
         }
     }
     idx->flag_waiters.fetch_sub(1u, std::memory_order_relaxed);
+    idx->n_naps.fetch_add(naps, std::memory_order_relaxed);
     if (rc == KDB_OK) { // running estimate (1/8 weights) of what a caller waits, for the next watcher's first sleep
-        const uint64_t el = now_ns() - t0;
+        const uint64_t t1 = now_ns(), el = t1 - t0;
+        const uint64_t tl = g->t_launch_ns;
+        idx->n_combined_calls.fetch_add(1u, std::memory_order_relaxed);
+        idx->ns_to_launch.fetch_add(tl > t0 ? tl - t0 : 0u, std::memory_order_relaxed);
+        idx->ns_launch_to_done.fetch_add(tl > t0 ? t1 - tl : el, std::memory_order_relaxed);
         const uint32_t old = idx->walk_ns.load(std::memory_order_relaxed);
         const uint64_t upd = ((uint64_t)old * 7u + (el > 2000000ull ? 2000000ull : el)) / 8u;
         idx->walk_ns.store((uint32_t)upd, std::memory_order_relaxed);
@@ -1562,8 +1574,10 @@ extern "C" int kdb_search_batch(kdb_index *idx, const float *queries, uint32_t B
     return staged_slot_call(idx, queries, B, k, allow_bits, out_ids, out_dist, out_count, dist_bytes, true, run);
 }
 
-// statistics of the combiner: out[0] launches of host-pointer calls that went through a slot, out[1] calls they carried,
-// out[2] the largest number of queries one launch carried, out[3] slots of this index
+// statistics of the concurrent host-pointer calls, out[10]: [0] launches that left through a slot, [1] calls they carried, [2] the largest
+// number of queries one launch carried, [3] slots of this index; combined searches: [4] calls, [5] ns they waited for a launch (sum),
+// [6] ns from launch to their own completion word seen (sum), [7] ns threads spent launching groups (sum), [8] naps, [9] the running
+// estimate of a call's wait in ns
 extern "C" int kdb_index_caller_stats(kdb_index *idx, uint64_t *out) {
     KDB_CHECK_IDX(idx);
     if (!out) return KDB_ERR_INVALID;
@@ -1572,6 +1586,12 @@ extern "C" int kdb_index_caller_stats(kdb_index *idx, uint64_t *out) {
     out[1] = idx->n_group_members;
     out[2] = idx->largest_group;
     out[3] = (uint64_t)idx->n_slots;
+    out[4] = idx->n_combined_calls.load();
+    out[5] = idx->ns_to_launch.load();
+    out[6] = idx->ns_launch_to_done.load();
+    out[7] = idx->ns_in_launch.load();
+    out[8] = idx->n_naps.load();
+    out[9] = idx->walk_ns.load();
     return KDB_OK;
 }
 

@@ -167,7 +167,7 @@ struct kdb_index {
     size_t build_bytes = 0;
     int last_kind = 0;              // 1 search, 2 flat scan, 3 distance tile
     uint32_t last_B = 0, last_C = 0;
-    uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words; 32..39 = the graph search's self-resetting accumulators)
+    uint32_t *d_work = nullptr;     // work counters / misc small device words (64 words; 8: first allowed id, 12: max norm bits, 13: LDS poison sink, 32..41 = the graph search's self-resetting accumulators {n_dist, n_hops, work | done, dropped, tied} as five 64-bit words)
     unsigned long long *d_ctr = nullptr; // n_dist, n_hops
     // trace
     uint32_t *trace_ndist = nullptr, *trace_nhops = nullptr;
@@ -196,6 +196,7 @@ struct kdb_index {
     std::atomic<uint32_t> walk_ns{150000};    // running estimate of join -> own answer, nanoseconds (first sleep of a watcher)
     std::mutex big_mu;             // calls too large for a slot share d_iobuf / stream / stream2: one at a time
     uint64_t n_groups = 0, n_group_members = 0, largest_group = 0; // statistics of the combiner (kdb_index_caller_stats)
+    std::atomic<uint64_t> ns_to_launch{0}, ns_launch_to_done{0}, ns_in_launch{0}, n_naps{0}, n_combined_calls{0}; // where a combined call's time goes
     // scratch lanes: the fields d_visited / d_scratch / d_qbuf / d_gentry / d_work above always name the CURRENT lane's
     // buffers (kdb_lane_acquire copies them in, kdb_lane_release copies them back: calls are serialised by `mu`)
     kdb_lane lanes[KDB_LANES];

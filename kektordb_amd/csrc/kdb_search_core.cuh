@@ -1385,7 +1385,7 @@ __device__ __forceinline__ bool pop_candidate(BeamT &b, NrT &nr, uint32_t ef, ui
 template <int PREC, int METRIC, class BeamT>
 __device__ __forceinline__ void kdb_tiny_dot_rule(BeamT &b, unsigned long long pass, float my_d) {
     if constexpr (PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE) {
-        if (__ballot(((pass >> kdb_lane()) & 1ull) && fabsf(my_d) < 1.8e-9f)) b.tied = 1u;
+        if (__ballot(((pass >> kdb_lane()) & 1ull) && fabsf(my_d) < 0x1p-29f)) b.tied = 1u; // (the exact bound: 1.8e-9 would miss dots in [1.8e-9, 2^-29))
     }
 }
 

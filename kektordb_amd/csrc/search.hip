@@ -654,7 +654,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         if (rc) return rc;
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         // the launch's accumulators {n_dist, n_hops, work | done, dropped}: zero between launches (see the kernel's end).  They
-        // belong to the call's SCRATCH LANE (words 32..39 of its d_work), not to the statistics ring: two launches that share
+        // belong to the call's SCRATCH LANE (words 32..41 of its d_work), not to the statistics ring: two launches that share
         // a lane are ordered by the lane protocol (same stream, or an event wait on the previous user), so a launch never
         // finds the words of another one that is still running -- whatever the number of launches in flight on other streams
         unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(idx->d_work + 32);

@@ -144,9 +144,10 @@ class HipIndex:
 
     def caller_stats(self):
         """concurrent host-pointer calls: launches that left through a slot, the calls they carried, the largest launch, slots"""
-        out = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(10, dtype=np.uint64)
         check(self.L.kdb_index_caller_stats(self.h, _ptr(out)), "kdb_index_caller_stats")
-        return {"launches": int(out[0]), "calls": int(out[1]), "largest": int(out[2]), "slots": int(out[3])}
+        return {"launches": int(out[0]), "calls": int(out[1]), "largest": int(out[2]), "slots": int(out[3]), "combined_calls": int(out[4]),
+                "ns_to_launch": int(out[5]), "ns_launch_to_done": int(out[6]), "ns_in_launch": int(out[7]), "naps": int(out[8]), "wait_estimate_ns": int(out[9])}
 
     def reserve(self, new_capacity: int):
         """growNodes (hnsw_index.go:2732-2768): raise the capacity of a live index, on the device"""

@@ -4,6 +4,8 @@
 // with g++ into a small shared library and called through ctypes, so the leg measures the C++ batcher, not a Python imitation:
 //   g++ -std=c++17 -O2 -shared -fPIC -I include scripts/micro_batcher_leg.cpp -L kektordb_amd/lib -lkektor_hip -pthread -o /tmp/libkdb_mb_leg.so
 #include <atomic>
+#include <pthread.h>
+#include <sched.h>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -18,6 +20,7 @@ class BorrowedIndex {
   public:
     BorrowedIndex(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {}
     uint32_t Dim() const { return dim_; }
+    bool CombinesConcurrentCalls() const { return true; } // (as kektor::hnsw::Index)
     uint32_t Count() const {
         uint32_t count = 0, entry = 0;
         int32_t maxLevel = -1;
@@ -59,12 +62,28 @@ class BorrowedIndex {
 // library serves such calls from its slots and combines those that find every slot busy); *batches = the launches it made.
 extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision, const float *queries, uint32_t nq, int k,
                                            int ef, int T, int per, int window_us, double *lat_us, double *wall_s, uint64_t *batches, uint64_t *largest,
-                                           uint64_t *answers) {
+                                           uint64_t *answers, int pin_cpus, double *phases) {
+    // pin_cpus > 0: the caller threads may run on the first pin_cpus CPUs this process is allowed only.  A process under a CPU QUOTA
+    // (this box: 16 CPUs' worth on 256 cores) that spreads 256 short-running threads over 256 cores strands its quota in per-core
+    // slices and is throttled for tens of milliseconds at a time -- what a quota without a cpuset does, not what the library does.
+    cpu_set_t pinned;
+    CPU_ZERO(&pinned);
+    if (pin_cpus > 0) {
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        sched_getaffinity(0, sizeof allowed, &allowed);
+        int got = 0;
+        for (int c = 0; c < CPU_SETSIZE && got < pin_cpus; c++)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, &pinned);
+                got++;
+            }
+    }
     BorrowedIndex idx(h, dim, metric, precision);
     kektor::hnsw::BasicMicroBatcher<BorrowedIndex>::Options o;
     o.window = std::chrono::microseconds(window_us > 0 ? window_us : 0); // 0: the default -- a leader that finds a turn free goes at once
     kektor::hnsw::BasicMicroBatcher<BorrowedIndex> mb(idx, o);
-    uint64_t cs0[4] = {0, 0, 0, 0}, cs1[4] = {0, 0, 0, 0};
+    uint64_t cs0[10] = {}, cs1[10] = {};
     (void)kdb_index_caller_stats(h, cs0);
     std::atomic<uint64_t> got{0};
     std::atomic<int> ready{0};
@@ -72,6 +91,7 @@ extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t 
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++)
         th.emplace_back([&, t] {
+            if (pin_cpus > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof pinned, &pinned);
             std::vector<float> q(dim);
             ready++;
             while (!go.load()) std::this_thread::yield();
@@ -94,8 +114,18 @@ extern "C" int kdb_bench_one_query_callers(kdb_index *h, uint32_t dim, uint32_t 
     const auto st = mb.stats();
     (void)kdb_index_caller_stats(h, cs1);
     // direct callers: the launches the library made for them (it combines the calls that find every slot busy)
-    *batches = window_us < 0 ? cs1[0] - cs0[0] : st.batches;
-    *largest = window_us < 0 ? cs1[2] : st.largest;
+    // (an index that combines concurrent calls itself gets the unfiltered calls passed through: the launches are the library's then too)
+    const bool lib = window_us < 0 || st.passedThrough > 0;
+    *batches = lib ? cs1[0] - cs0[0] : st.batches;
+    *largest = lib ? cs1[2] : st.largest;
     *answers = got.load();
+    if (phases) { // where a combined call's time went (kdb_index_caller_stats), microseconds
+        const double calls = (double)(cs1[4] - cs0[4]), groups = (double)(cs1[0] - cs0[0]);
+        phases[0] = calls > 0 ? (double)(cs1[5] - cs0[5]) / calls / 1e3 : 0.0;   // waiting for the group's launch
+        phases[1] = calls > 0 ? (double)(cs1[6] - cs0[6]) / calls / 1e3 : 0.0;   // launch -> own completion word seen
+        phases[2] = groups > 0 ? (double)(cs1[7] - cs0[7]) / groups / 1e3 : 0.0; // a thread launching a group
+        phases[3] = calls > 0 ? (double)(cs1[8] - cs0[8]) / calls : 0.0;         // naps per call
+        phases[4] = calls;
+    }
     return 0;
 }

@@ -1459,3 +1459,33 @@ def test_flat_scan_k_above_128(oracle, hip, metric, prec, dim):
     for b in range(2):
         oi, od = orc.flat_scan(Q[b], 400, allow=narrow)
         assert int(cnt[b]) == len(oi) < 400 and np.array_equal(ids[b, :len(oi)], oi)
+
+
+def test_flat_scan_k_above_128_ties_with_an_id_list(oracle, hip):
+    """with a filter or deleted rows the any-k scan walks a COMPACTED id list whose blocks claim their ranges in
+    arrival order (more than 8192 entries: not ascending), so "ties at the cut go to the smaller id" must look at the ids, not at the
+    list positions.  20000 rows, 700 copies of one row, 300 deleted, half of the ids allowed, k = 256 / 300: the cut runs through
+    the copies; ids IN ORDER and distance bits of the oracle's exact scan, five times over (the list's order may change per call)."""
+    O = oracle
+    rng = np.random.default_rng(23)
+    n, dim = 20000, 64
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[rng.choice(n, 700, replace=False)] = X[11]
+    deleted = (rng.choice(n, 300, replace=False) + 1).tolist()
+    orc, idx = build_pair(O, hip, X, 0, m=8, efc=20, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    from kektordb_amd.index import dense_bitset
+    allowed = np.nonzero(rng.random(n + 1) < 0.5)[0]
+    allow = dense_bitset(allowed[allowed >= 1], n)
+    Q = (X[11:12] + 0.001 * rng.standard_normal((4, dim))).astype(np.float32)
+    for k in (256, 300):
+        for ab in (allow, None):
+            want = [orc.flat_scan(Q[b], k, allow=ab) for b in range(Q.shape[0])]
+            for rep in range(5):
+                ids, dist, cnt = idx.flat_scan_batch(Q, k, allow_bits=ab)
+                for b in range(Q.shape[0]):
+                    oi, od = want[b]
+                    c = int(cnt[b])
+                    assert c == len(oi) == k
+                    assert np.array_equal(ids[b, :c], oi), (k, rep, b, np.nonzero(ids[b, :c] != oi)[0][:5])
+                    assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (k, rep, b)
