@@ -93,6 +93,15 @@ KdbView kdb_make_view(const kdb_index *idx) {
     return v;
 }
 
+// Scratch grows in powers of two while small (batches of concurrent callers come in every size: a re-allocation is a device-wide
+// synchronisation), by a quarter beyond
+static size_t grown(size_t bytes) {
+    if (bytes >= ((size_t)32 << 20)) return bytes + bytes / 4;
+    size_t w = (size_t)64 << 10;
+    while (w < bytes) w <<= 1;
+    return w;
+}
+
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
     if (idx->scratch_bytes >= bytes) return KDB_OK;
     if (idx->d_scratch) {
@@ -101,7 +110,7 @@ int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
         idx->d_scratch = nullptr;
         idx->scratch_bytes = 0;
     }
-    size_t want = bytes + bytes / 4;
+    size_t want = grown(bytes);
     KDB_HIP(hipMalloc(&idx->d_scratch, want));
     idx->scratch_bytes = want;
     return KDB_OK;
@@ -206,8 +215,8 @@ int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes) {
         idx->d_tie = nullptr;
         idx->tie_bytes = 0;
     }
-    KDB_HIP(hipMalloc(&idx->d_tie, bytes + bytes / 4));
-    idx->tie_bytes = bytes + bytes / 4;
+    KDB_HIP(hipMalloc(&idx->d_tie, grown(bytes)));
+    idx->tie_bytes = grown(bytes);
     return KDB_OK;
 }
 
@@ -232,8 +241,8 @@ static int ensure_qbuf(kdb_index *idx, size_t bytes) {
         idx->d_qbuf = nullptr;
         idx->qbuf_bytes = 0;
     }
-    KDB_HIP(hipMalloc(&idx->d_qbuf, bytes + bytes / 4));
-    idx->qbuf_bytes = bytes + bytes / 4;
+    KDB_HIP(hipMalloc(&idx->d_qbuf, grown(bytes)));
+    idx->qbuf_bytes = grown(bytes);
     return KDB_OK;
 }
 

@@ -269,11 +269,19 @@ int kdb_launch_search(kdb_index *idx, const KdbView &v, const void *d_q, const f
                       float *d_out_dist, uint32_t *d_out_count, uint32_t *d_tr_ndist, uint32_t *d_tr_nhops,
                       hipStream_t s);
 // search_heap.hip: the heap-order walk of the queries the search kernel queued in d_tie_list (KDB_SEARCH_HEAP_ORDER)
-size_t kdb_heap_walk_scratch_bytes(uint32_t grid, uint32_t nl_c, uint32_t cap_c);
-uint32_t kdb_heap_walk_lds_entries(const KdbView &v, uint32_t ef, uint32_t k);
+struct KdbHeapPlan {
+    uint32_t hsize;    // words of the LDS visited hash (0: the HBM bitset)
+    uint32_t nl_c;     // candidate-heap entries in LDS
+    uint32_t cap_c;    // ... and in all (the rest in HBM scratch, per workgroup)
+    uint32_t grid;     // workgroups (one wave each)
+    uint32_t reg_results; // the result heap lives in registers (ef + 2 <= 64)
+    size_t lds;        // bytes of LDS per workgroup
+    size_t tail_bytes; // HBM scratch of all workgroups' candidate-heap tails
+};
+int kdb_heap_walk_plan(kdb_index *idx, const KdbView &v, uint32_t ef, uint32_t k, uint32_t B, KdbHeapPlan *out);
 int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B, uint32_t k, uint32_t ef,
-                         const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_tie_list, unsigned char *d_tails, uint32_t grid,
-                         uint32_t nl_c, uint32_t cap_c, unsigned long long *d_ctr, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                         const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_tie_list, unsigned char *d_tails, const KdbHeapPlan &plan,
+                         unsigned long long *d_ctr, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
                          uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s);
 int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes);
 int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,

@@ -632,19 +632,16 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // KDB_SEARCH_HEAP_ORDER (raw & 16): queries whose walk meets equal distances are queued by the kernel and walked again by
         // heap_walk_kernel (search_heap.hip) behind it -- everything it needs is allocated and armed BEFORE the launch
         const bool heap_pass = (raw & 16u) != 0u;
-        uint32_t hgrid = 0, nl_c = 0, cap_c = 0;
+        uint32_t hgrid = 0;
+        KdbHeapPlan hplan{};
         uint32_t *d_tie_list = nullptr;
         unsigned char *d_tails = nullptr;
         if (heap_pass) {
-            hgrid = B < 2u * ncu ? B : 2u * ncu;
-            nl_c = kdb_heap_walk_lds_entries(v, eff, k);
-            // the candidate heap holds every accepted neighbour of a layer search: bounded by the nodes, sized for walks of ~64 ef
-            // evaluations (a walk that outgrows it keeps the fast answer and is counted)
-            const uint64_t want = (uint64_t)64u * eff > 65536u ? (uint64_t)64u * eff : 65536u;
-            cap_c = (uint32_t)(want < (uint64_t)v.count + 1u ? want : (uint64_t)v.count + 1u);
-            if (cap_c < nl_c) cap_c = nl_c;
+            int rc0 = kdb_heap_walk_plan(idx, v, eff, k, B, &hplan);
+            if (rc0) return rc0;
+            hgrid = hplan.grid;
             const size_t list_bytes = (((size_t)B + 2u) * 4u + 255u) & ~(size_t)255u;
-            int rc0 = kdb_ensure_tie_scratch(idx, list_bytes + kdb_heap_walk_scratch_bytes(hgrid, nl_c, cap_c) + 256u);
+            rc0 = kdb_ensure_tie_scratch(idx, list_bytes + hplan.tail_bytes + 256u);
             if (rc0) return rc0;
             d_tie_list = reinterpret_cast<uint32_t *>(idx->d_tie);
             d_tails = reinterpret_cast<unsigned char *>(idx->d_tie) + list_bytes;
@@ -665,7 +662,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         KDB_HIP(hipGetLastError());
         if (heap_pass) { // (its workgroups return at once when the search kernel queued nothing; the closing event covers both passes:
             // the second one adds its counters to the slot the first one published)
-            rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, hgrid, nl_c, cap_c, d_ctr, d_out_ids,
+            rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, hplan, d_ctr, d_out_ids,
                                       d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s);
             if (rc) return rc;
         }
