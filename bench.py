@@ -168,6 +168,9 @@ def main():
                          "call as Compress re-inserts them) instead of the fast builder: ef needed for the recall bar, and QPS there")
     ap.add_argument("--shapes", action="store_true",
                     help="side leg only: the reference's published benchmark shapes (GloVe-100/200/300, SIFT-1M) on synthetic rows")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the per-rank HBM plan of this command (rows, graph, scratch, builder workspace) and exit: 0 if it fits "
+                         "288 GB per GPU, 2 if not -- no GPU needed")
     ap.add_argument("--preset", default="", choices=["", "config4"],
                     help="config4 = BASELINE configs[3]: 12.5M x 768 cosine rows PER RANK (100M over 8 GPUs), clustered law (ii), 8192 queries")
     a = ap.parse_args()
@@ -189,6 +192,10 @@ def main():
     if a.preset == "config4":
         a.n, a.dim, a.batch, a.corpus = 12_500_000, 768, 8192, "clustered"
         a.no_extras = True
+    if a.dry_run:
+        plan = memory_plan(a)
+        print(json.dumps(plan), flush=True)
+        sys.exit(0 if plan["fits"] else 2)
 
     # ---- N > 1 from the plain command line: `python bench.py --gpus N` with no launcher around it starts its own N ranks
     #      (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and relays their output
@@ -423,8 +430,10 @@ def main():
                          ("pcie_inclusive", lambda: pcie_inclusive(idx, Q, k, ef)),
                          ("heap_order", lambda: heap_order_leg(idx, Q, k, ef, dev)),
                          ("micro_batcher", lambda: micro_batcher_leg(idx, Q, k, ef)),
+                         ("filter_routing_headline_table", lambda: filter_routing_leg(idx, Q[:1024].contiguous(), n, k, dev, torch.Generator(device=dev).manual_seed(21), build=False)),
                          ("flat_scan_leg", lambda: flat_leg(idx, Q, k, n, dim, a.flat_batch, dev)),
                          ("corpus_iid", lambda: iid_leg(K, n, dim, k, a, dev)),
+                         ("reference_linked_graph", lambda: ref_graph_leg(K, a, dev, centers, Q, Qh, gt, gth, k)),
                          ("reference_benchmark_shapes", lambda: reference_shapes_leg(K, dev)),
                          ("baseline_configs_2_and_4", lambda: big_configs_leg(K, dev))):
             if a.legs and name not in a.legs.split(","):
@@ -437,6 +446,8 @@ def main():
         pi = res.get("pcie_inclusive") or {}
         if str(B) in pi:
             res["value_pcie_inclusive"] = pi[str(B)]["qps"]
+            # SURVEY 8d's wall-clock QPS (H2D of the queries + D2H of the answers inside the timed region) inside a field the driver parses
+            res["config"]["pcie_inclusive_qps"] = pi[str(B)]["qps"]
         if not a.no_pmc:
             inner = ["--ef", str(ef), "--steps", "4", "--warmup", "1", "--rows", str(n), "--dim", str(dim), "--k", str(k),
                      "--batch", str(B), "--efc", str(a.efc), "--build-batch", str(a.build_batch), "--corpus", a.corpus,
@@ -476,7 +487,7 @@ def main():
                     fl["roofline"]["mfma_busy_frac"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / (b["SQ_BUSY_CYCLES"] * 32.0), 4)
                 fl["roofline"]["mfma_counters"] = {kk: round(vv, 1) for kk, vv in b.items()}
 
-    if rank == 0 and world == 1 and a.ref_graph:
+    if rank == 0 and world == 1 and a.ref_graph and "reference_linked_graph" not in res:  # (--no-extras --ref-graph)
         try:
             res["reference_linked_graph"] = ref_graph_leg(K, a, dev, centers, Q, Qh, gt, gth, k)
         except Exception as e:
@@ -506,6 +517,46 @@ def main():
     flush_all()
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+HBM_PER_GPU = 288e9   # MI355X (MI355X_MICROARCH.md)
+
+
+def memory_plan(a, waves_resident=4096, upload_chunk=2_000_000):
+    """Per-rank HBM of `bench.py --gpus N ...` BEFORE anything is allocated: the arrays of one shard, the scratch
+    of the search lanes the bench drives, the fast builder's workspace (build.hip build_impl: keys beside both adjacency arrays,
+    16 request slots per node and level, candidate lists of two batches of tasks) and the torch tensors of the harness.  Every rank
+    holds the same (weak scaling: --rows per rank), so the plan of one rank is the plan of all."""
+    n, dim, B, k, m = a.n, a.dim, a.batch, a.k, 16
+    n1 = n + 1
+    ld = (dim + 15) // 16 * 16
+    ld16 = (ld + 63) // 64 * 64
+    deg0, deg_up, rcap = 2 * m, m, 16
+    slots = int(n / (m - 1)) + 1024                    # sum over nodes of their level: geometric with ratio 1/m (randomLevel)
+    vis_words = ((n >> 5) + 1 + 3) // 4 * 4
+    batch = a.build_batch
+    tasks = 2 * batch + 64
+    efc = a.efc
+    parts = {
+        "rows_f32": n1 * ld * 4,
+        "adjacency_level0": n1 * deg0 * 4,
+        "adjacency_upper_pool_and_slot_table": 2 * (slots * deg_up + 4) * 4,
+        "norms_levels_up_idx_deleted": n1 * 4 + n1 + n1 * 4 + (n1 + 31) // 32 * 4,
+        "visited_bitsets_two_lanes": 2 * waves_resident * vis_words * 4,     # one bitset per resident wave (spill target of the LDS hash)
+        "builder_workspace": n1 * (deg0 * 4 + 4 + rcap * 4 + rcap * 4) + (slots + 1) * (deg_up * 4 + 4 + rcap * 8) + tasks * (efc * 8 + 4 + 32 * 4) + tasks * deg0 * 12,
+        "queries_answers_exchange_buffers": 2 * B * dim * 4 + (a.gpus + 3) * (2 * B * k + B) * 4 * 2,
+        "harness_upload_chunk_torch": 2 * min(n, upload_chunk) * dim * 4,    # gen_corpus: the chunk and its normalised copy
+        "ranking_copy_f16_if_an_exact_scan_runs": n1 * ld16 * 2,
+    }
+    total = sum(parts.values())
+    plan = {"command": f"--gpus {a.gpus} --rows {n} --dim {dim} --batch {B}" + (f" --preset {a.preset}" if a.preset else ""),
+            "per_rank_bytes": {k_: int(v) for k_, v in parts.items()}, "per_rank_total_GB": round(total / 1e9, 2),
+            "hbm_per_gpu_GB": HBM_PER_GPU / 1e9, "corpus_rows_total": n * a.gpus, "ranks": a.gpus,
+            "fits": bool(total <= 0.92 * HBM_PER_GPU),
+            "note": "fits = total <= 92 % of 288 GB (the runtime, RCCL's buffers and fragmentation take the rest)"}
+    if not plan["fits"]:
+        log(f"[bench] this command needs {total / 1e9:.1f} GB per GPU: more than an MI355X holds -- fewer rows per rank, or more ranks")
+    return plan
 
 
 def cluster_main(a):
@@ -1144,10 +1195,64 @@ def big_configs_leg(K, dev, rows=10_000_000, nq=1024):
     out["configs[4]"]["one_filter_shared_by_the_batch"] = {
         "allowed_rows": int(allowed[int(cats[0])].size), "ms_per_batch": round(wall * 1e3, 2), "ranking_kernel_ms": round(kms, 2),
         "qps": round(nq / wall, 1), "answers_inside_filter": bool(np.isin(got[got > 0], allowed[int(cats[0])]).all())}
+    try:
+        out["configs[4]"]["filter_routing"] = filter_routing_leg(idx, Q, n, k, dev, g)
+    except Exception as e:  # never lose the scan numbers
+        out["configs[4]"]["filter_routing"] = f"failed: {e!r}"
     idx.Close()
     del idx
     torch.cuda.empty_cache()
     return out
+
+
+def filter_routing_leg(idx, Q, n, k, dev, g, build=True):
+    """The reference's filtered walk prunes non-allowed neighbours while traversing (hnsw_index.go:2545-2549): the fewer ids a filter
+    allows, the fewer of a node's neighbours survive and the less of the graph the walk can reach.  On configs[4]'s own table (10M x 1536,
+    graph built here by the GPU builder) a random fraction s of the ids is allowed, one filter shared by the batch: recall@10 of the
+    filtered walk against the EXACT filtered answer at efSearch 100 (the published default, BENCHMARKS.md) and 400, its rate, and the
+    rate of the exact filtered scan -- the measured basis of the mirrors' routing constant (kektor_hip.hpp flatScanSelectivity,
+    integration/go: below it a filtered query takes the exact scan and the drop-in deliberately returns the exact answer where the
+    reference returns the walk's)."""
+    from kektordb_amd.index import dense_bitset
+    t0 = time.time()
+    if build:
+        idx.build(n, batch=16384, ef_construction=200, seed=9)
+    res = {"graph_build_s": round(time.time() - t0, 1) if build else None, "rows": n, "queries": int(Q.shape[0]), "selectivity": {}}
+    nq = Q.shape[0]
+
+    def timed(fn, reps=3):
+        fn()
+        idx.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        idx.sync()
+        return (time.perf_counter() - t1) / reps
+
+    crossover = None
+    for sel in (0.01, 0.02, 0.05, 0.1, 0.2, 0.5):
+        mask = torch.rand(n + 1, device=dev, generator=g) < sel
+        mask[0] = False
+        ids = (torch.nonzero(mask).flatten()).cpu().numpy().astype(np.uint32)
+        ab = torch.from_numpy(dense_bitset(ids, n).view(np.int64)).to(dev)
+        o = outs(nq, k, dev)
+        w_scan = timed(lambda: idx.flat_scan_batch_dev(Q, k, *o, d_allow=ab))
+        exact = o[0].cpu().numpy().view(np.uint32)
+        row = {"allowed_rows": int(ids.size), "exact_scan": {"ms_per_batch": round(w_scan * 1e3, 2), "qps": round(nq / w_scan, 1)}, "filtered_walk": {}}
+        for ef in (100, 400):
+            h = outs(nq, k, dev)
+            w = timed(lambda: idx.search_batch_dev(Q, k, ef, *h, d_allow=ab))
+            got = h[0].cpu().numpy().view(np.uint32)
+            row["filtered_walk"][str(ef)] = {"recall_at_10_vs_exact_filtered": round(recall_at_k(got, exact, k), 4), "ms_per_batch": round(w * 1e3, 2),
+                                             "qps": round(nq / w, 1), "answers_per_query": round(float(h[2].float().mean().item()), 2)}
+        res["selectivity"][str(sel)] = row
+        fw = row["filtered_walk"]["100"]
+        if crossover is None and fw["recall_at_10_vs_exact_filtered"] >= 0.95 and fw["qps"] > row["exact_scan"]["qps"]:
+            crossover = sel
+    res["smallest_selectivity_where_the_walk_at_ef_100_reaches_recall_0.95_and_beats_the_scan"] = crossover
+    full = [float(s_) for s_, r in res["selectivity"].items() if r["filtered_walk"]["100"]["answers_per_query"] >= k - 0.01]
+    res["smallest_selectivity_where_the_walk_at_ef_100_still_returns_k_answers"] = min(full) if full else None
+    return res
 
 
 def cpu_baseline(idx, Q, k, ef, n, dim, a):

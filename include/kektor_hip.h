@@ -343,6 +343,9 @@ KDB_API int kdb_test_select_neighbors(kdb_index *idx, uint32_t n_lists, uint32_t
 KDB_API int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, uint32_t B, uint32_t k,
                    const uint32_t *in_ids, const float *in_dist, const uint32_t *in_count,
                    const uint32_t *id_base, uint32_t *out_ids, float *out_dist, uint32_t *out_count);
+/* Host merge for int8 shards: float64 distances in and out (the reference's own order, hnsw_index.go:2429-2454), (distance, global id). */
+KDB_API int kdb_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const double *in_dist, const uint32_t *in_count,
+                               const uint32_t *id_base, uint32_t *out_ids, double *out_dist, uint32_t *out_count);
 KDB_API int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
                        const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
                        uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream);

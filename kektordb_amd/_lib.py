@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "kdb_distance_batch_dev", "kdb_index_build", "kdb_merge_topk", "kdb_merge_topk_dev", "kdb_merge_topk_packed_dev", "kdb_search_batch_multi_dev", "kdb_index_append_nodes", "kdb_index_patch_adjacency", "kdb_index_set_entry", "kdb_flat_scan_groups_dev", "kdb_get_counters", "kdb_get_launch_stats",
     "kdb_index_sync", "kdb_index_set_launch_timing", "kdb_test_select_neighbors", "kdb_cluster_create", "kdb_cluster_destroy", "kdb_cluster_info",
     "kdb_sharded_search_batch", "kdb_sharded_flat_scan_batch", "kdb_index_compress", "kdb_index_get_quantizer", "kdb_index_add_batch", "kdb_merge_topk_packed_f64_dev",
-    "kdb_cluster_comm_info", "kdb_cluster_debug_fail_next", "kdb_index_reserve", "kdb_index_drop_f16_shadow", "kdb_probe_gather", "kdb_probe_stream", "kdb_probe_poison_lds", "kdb_index_caller_stats",
+    "kdb_cluster_comm_info", "kdb_cluster_debug_fail_next", "kdb_index_reserve", "kdb_index_drop_f16_shadow", "kdb_probe_gather", "kdb_probe_stream", "kdb_probe_poison_lds", "kdb_index_caller_stats", "kdb_merge_topk_f64",
 ]
 
 
@@ -115,6 +115,7 @@ def load():
     L.kdb_index_build.argtypes = [vp, u32, C.POINTER(BuildParams)]
     L.kdb_index_add_batch.argtypes = [vp, u32, u32, vp, u32, u32]
     L.kdb_merge_topk.argtypes = [u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.kdb_merge_topk_f64.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_packed_dev.argtypes = [vp, u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.kdb_merge_topk_packed_f64_dev.argtypes = [vp, u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, vp]

@@ -1937,6 +1937,37 @@ extern "C" int kdb_merge_topk(uint32_t metric, uint32_t precision, uint32_t G, u
     return KDB_OK;
 }
 
+// The same for int8 shards, whose distances the reference computes and ORDERS as float64 (hnsw_index.go:2429-2454): doubles in,
+// doubles out, total order (distance, global id).
+extern "C" int kdb_merge_topk_f64(uint32_t G, uint32_t B, uint32_t k, const uint32_t *in_ids, const double *in_dist, const uint32_t *in_count,
+                                  const uint32_t *id_base, uint32_t *out_ids, double *out_dist, uint32_t *out_count) {
+    if (!in_ids || !in_dist || !in_count || !out_ids || !out_dist || !out_count || k == 0) {
+        kdb_set_error("merge_topk_f64: null buffer or k == 0");
+        return KDB_ERR_INVALID;
+    }
+    struct E { double d; uint32_t id; };
+    std::vector<E> buf;
+    for (uint32_t q = 0; q < B; q++) {
+        buf.clear();
+        for (uint32_t g = 0; g < G; g++) {
+            uint32_t c = in_count[(size_t)g * B + q];
+            if (c > k) c = k;
+            for (uint32_t i = 0; i < c; i++) {
+                const size_t off = ((size_t)g * B + q) * k + i;
+                buf.push_back({in_dist[off], in_ids[off] + (id_base ? id_base[g] : 0u)});
+            }
+        }
+        std::sort(buf.begin(), buf.end(), [](const E &a, const E &b) { return a.d < b.d || (a.d == b.d && a.id < b.id); });
+        const uint32_t n = buf.size() < k ? (uint32_t)buf.size() : k;
+        for (uint32_t i = 0; i < k; i++) {
+            out_ids[(size_t)q * k + i] = i < n ? buf[i].id : 0u;
+            out_dist[(size_t)q * k + i] = i < n ? buf[i].d : (double)INFINITY;
+        }
+        out_count[q] = n;
+    }
+    return KDB_OK;
+}
+
 extern "C" int kdb_merge_topk_dev(kdb_index *idx, uint32_t G, uint32_t B, uint32_t k, const uint32_t *d_in_ids,
                                   const float *d_in_dist, const uint32_t *d_in_count, const uint32_t *d_id_base,
                                   uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, void *stream) {

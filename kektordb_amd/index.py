@@ -447,10 +447,17 @@ def merge_topk(metric: int, ids, dist, count, k: int, id_base=None, precision: i
     """Host shard merge through the C ABI (kdb_merge_topk): ids/dist [G,B,k], count [G,B], id_base [G]."""
     L = _lib.load()
     ids = np.ascontiguousarray(ids, dtype=np.uint32)
-    dist = np.ascontiguousarray(dist, dtype=np.float32)
     count = np.ascontiguousarray(count, dtype=np.uint32)
     base = None if id_base is None else np.ascontiguousarray(id_base, dtype=np.uint32)
     G, B = count.shape
+    if np.asarray(dist).dtype == np.float64:  # int8 shards: the reference's float64 distances, ordered as doubles
+        dist = np.ascontiguousarray(dist, dtype=np.float64)
+        o_ids = np.zeros((B, k), dtype=np.uint32)
+        o_dist = np.zeros((B, k), dtype=np.float64)
+        o_cnt = np.zeros(B, dtype=np.uint32)
+        check(L.kdb_merge_topk_f64(G, B, k, _ptr(ids), _ptr(dist), _ptr(count), _ptr(base), _ptr(o_ids), _ptr(o_dist), _ptr(o_cnt)), "kdb_merge_topk_f64")
+        return o_ids, o_dist, o_cnt
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
     o_ids = np.zeros((B, k), dtype=np.uint32)
     o_dist = np.zeros((B, k), dtype=np.float32)
     o_cnt = np.zeros(B, dtype=np.uint32)

@@ -156,7 +156,7 @@ class ShardedSearch:
             g_ids, g_dist, g_cnt = l_ids[None], l_dist[None], l_cnt[None]
         else:
             t_ids = torch.from_numpy(np.ascontiguousarray(l_ids).view(np.int32))
-            t_dist = torch.from_numpy(np.ascontiguousarray(l_dist))
+            t_dist = torch.from_numpy(np.ascontiguousarray(l_dist))   # float32, or float64 for int8 shards (merged as doubles)
             t_cnt = torch.from_numpy(np.ascontiguousarray(l_cnt).view(np.int32))
             a_ids = [torch.zeros_like(t_ids) for _ in range(self.world)]
             a_dist = [torch.zeros_like(t_dist) for _ in range(self.world)]
