@@ -220,7 +220,11 @@ class BasicMicroBatcher {
     struct Options {
         uint32_t maxBatch = 8192;                     // queries per GPU call
         std::chrono::microseconds window{0};          // > 0: a leader that finds the device idle waits this long for company
-        double flatScanSelectivity = 0.05;
+        // Measured (bench.py filter_routing legs, profiles/r05_*): on 1M x 768 and on 10M x 1536 the filtered walk at efSearch 100 / 400
+        // returns ONE OR TWO answers instead of k at 1 %, 2 % and 5 % selectivity (a node keeps 32 x s allowed neighbours: the walk
+        // starves) and k answers from 10 % on.  Below this bound the mirror answers with the exact scan -- deliberately the exact
+        // filtered top-k where the reference returns what its starved walk found; from it on, the walk's answer is the reference's.
+        double flatScanSelectivity = 0.1;
         uint32_t maxInFlight = 2;                     // GPU calls of this batcher on the device at once
     };
     struct Stats {

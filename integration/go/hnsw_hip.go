@@ -283,12 +283,18 @@ func (m *gpuMirror) destroy() {
 // micro-batcher
 // ---------------------------------------------------------------------------------------------------------
 
+// Round 5: the LIBRARY serves concurrent callers itself -- a cgo call holds the handle's lock only to enqueue, one-query calls that
+// find its slots busy are combined into one launch and every caller returns when ITS walk is done (kektor_hip.h, "Conventions").
+// Unfiltered queries therefore go straight to C.kdb_search_batch with B = 1, one cgo call per goroutine (searchHIP below); the
+// batcher only groups what the library does not combine: queries that share an allow list (one conversion and one upload of the
+// list per group, and the routing of selective filters to the exact scan).  Its compiled twin is kektor::hnsw::MicroBatcher.
 const (
-	hipBatchWindow = 150 * time.Microsecond // how long the first caller of a group waits for company
-	hipBatchMax    = 8192                   // queries per GPU call
+	hipBatchWindow = 0 * time.Microsecond // a group's first caller flushes at once when a turn on the device is free
+	hipBatchMax    = 8192                 // queries per GPU call
+	hipMaxInFlight = 2                    // GPU calls of one batcher on the device at once
 	// below this fraction of allowed ids the reference's filtered graph walk is disconnected (it prunes
 	// non-allowed neighbours during traversal, hnsw_index.go:2545-2549): such queries take the exact scan
-	hipFlatScanSelectivity = 0.05
+	hipFlatScanSelectivity = 0.1 // measured: below it the filtered walk returns 1-2 answers instead of k (INTEGRATION.md, "Filter routing")
 )
 
 type hipRequest struct {
@@ -309,14 +315,18 @@ type hipGroup struct {
 
 type hipBatcher struct {
 	h      *Index
-	exec   sync.Mutex // one GPU call at a time; taken before mu
+	turns  chan struct{} // hipMaxInFlight tokens: two groups on the device at once, the next one stays open (and grows) meanwhile
 	mu     sync.Mutex
 	groups map[hipGroupKey]*hipGroup
 	closed bool
 }
 
 func newHipBatcher(h *Index) *hipBatcher {
-	return &hipBatcher{h: h, groups: make(map[hipGroupKey]*hipGroup)}
+	b := &hipBatcher{h: h, groups: make(map[hipGroupKey]*hipGroup), turns: make(chan struct{}, hipMaxInFlight)}
+	for i := 0; i < hipMaxInFlight; i++ {
+		b.turns <- struct{}{}
+	}
+	return b
 }
 
 func (b *hipBatcher) stop() {
@@ -357,10 +367,9 @@ func (b *hipBatcher) submit(query []float32, k, ef int, allow *roaring.Bitmap) [
 }
 
 func (b *hipBatcher) flush(key hipGroupKey, g *hipGroup) {
-	// the group stays open (joinable) while the previous group's call runs: batch size follows the load
-	// (measured with the C++ twin, kektor::hnsw::MicroBatcher: 2.8k -> 70-95k QPS for one-query callers)
-	b.exec.Lock()
-	defer b.exec.Unlock()
+	// the group stays open (joinable) while the calls in flight run: batch size follows the load
+	<-b.turns
+	defer func() { b.turns <- struct{}{} }()
 	b.mu.Lock()
 	if b.groups[key] != g { // already flushed by the other trigger
 		b.mu.Unlock()
@@ -393,6 +402,17 @@ func (h *Index) searchHIP(query []float32, k int, allowList *roaring.Bitmap, efS
 	if len(query) != h.vectorDim {
 		slog.Error("Error during HNSW search", "error", errors.New("query dimension mismatch"))
 		return []types.SearchResult{}
+	}
+	if allowList == nil { // unfiltered: one cgo call per goroutine; the library combines concurrent calls (measured on one MI355X,
+		// 1M x 768, ef 60: 64 goroutine-like callers 189 k QPS at p50 0.29 ms, 256 callers 431 k QPS at p99 0.9 ms -- bench.py micro_batcher)
+		out, err := h.searchBatchHIP([]*hipRequest{{query: query}}, k, efSearch, nil)
+		if err != nil || len(out) == 0 {
+			if err != nil {
+				slog.Error("Error during HNSW search (hip)", "error", err)
+			}
+			return []types.SearchResult{}
+		}
+		return out[0]
 	}
 	h.gpu.mu.Lock()
 	if h.gpu.batcher == nil {

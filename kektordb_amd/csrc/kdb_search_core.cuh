@@ -55,8 +55,9 @@ struct WaveLds {
     uint32_t *beam_lo; // [cap]  int8 + LdsBeam
     uint32_t *nr_lo;   // [nr_cap] int8
     uint32_t *ctl;     // [16] latency mode (several waves per query): the command word and what goes with it (KDB_CTL_*)
-    float *ins_d;      // [64] scatter scratch of the one-pass insertion (may alias nb_d when nobody else writes nb_id)
-    uint32_t *ins_id;  // [64]
+    float *ins_d;      // [ins_cap] scatter scratch of the one-pass insertion (may alias nb_d when nobody else writes nb_id)
+    uint32_t *ins_id;  // [ins_cap]
+    uint32_t ins_cap = 0; // entries the scratch holds: 64 aliased on nb_d / nb_id, 64 x slots when the kernel gives a multi-slot beam its own
 };
 // Latency mode (several waves per query): the control words through which the waves of a workgroup talk.  No barriers:
 // a word that announces something (MB_SEQ, ROWS_SEQ, DONE) is written AFTER what it announces and polled by its reader;
@@ -1169,7 +1170,8 @@ struct EpKnown {
 };
 
 // A hop's candidates (lanes < n hold id / key / deleted flag; `pass` = those that may still enter) go into the beam.
-// One-pass form (single-register beam, no deleted nodes): the reference takes the candidates one by one in stored order
+// One-pass form (register beams -- one, two or four slots, ef <= 256; round 5: the published efSearch = 100 is a two-slot beam --
+// no deleted nodes): the reference takes the candidates one by one in stored order
 // against a shrinking worst (:2577-2590); when no two of the distances involved are EQUAL the outcome is simply the ef
 // smallest of beam + candidates, so every beam entry counts the candidates below it (its shift), every candidate the beam
 // entries and candidates below it (its place), one scatter through LDS puts everybody where he belongs.  Any tie at all ->
@@ -1179,43 +1181,61 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
                                                   float my_d, uint32_t my_lo, uint32_t my_id, bool my_nr, QCtr &ctr) {
     constexpr bool WK = BeamT::kWide;
     const int lane = kdb_lane();
-    if constexpr (BeamT::kSlots == 1 && !WK) {
+    if constexpr (BeamT::kSlots >= 1 && !WK) { // register beams of one, two or four slots (ef <= 64 / 128 / 256)
+        constexpr int S = BeamT::kSlots;
         const uint32_t npass = (uint32_t)__builtin_popcountll(pass);
-        if (npass >= 2u && !v.has_deleted) {
+        if (npass >= 2u && !v.has_deleted && (S == 1 || s.ins_cap >= ef)) {
             const uint32_t m = b.count;
-            const bool in_beam = (uint32_t)lane < m;
             const bool in_pass = ((pass >> lane) & 1ull) != 0ull;
-            const float bd = b.d[0];
-            uint32_t shift = 0u, place = 0u;
+            bool in_beam[S];
+            uint32_t shift[S];
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                in_beam[q] = 64u * q + (uint32_t)lane < m;
+                shift[q] = 0u;
+            }
+            uint32_t place = 0u;
             bool tie = false;
             for (unsigned long long rest = pass; rest;) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(rest);
                 rest &= rest - 1ull;
                 const float cd = readlane_f(my_d, j);
-                shift += (in_beam && cd < bd) ? 1u : 0u;
-                const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(in_beam && bd < cd));
-                tie = tie || (in_beam && bd == cd) || (in_pass && (uint32_t)lane != j && cd == my_d);
+                uint32_t below = 0u;
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    if (64u * q >= m) continue; // (wave-uniform: an empty slot)
+                    shift[q] += (in_beam[q] && cd < b.d[q]) ? 1u : 0u;
+                    below += (uint32_t)__builtin_popcountll(__ballot(in_beam[q] && b.d[q] < cd));
+                    tie = tie || (in_beam[q] && b.d[q] == cd);
+                }
+                tie = tie || (in_pass && (uint32_t)lane != j && cd == my_d);
                 place += (in_pass && cd < my_d) ? 1u : 0u;
                 if ((uint32_t)lane == j) place += below;
             }
             if (__ballot(tie) == 0ull) {
                 const uint32_t total = m + npass;
                 const uint32_t ncount = total < ef ? total : ef;
-                const uint32_t b_to = (uint32_t)lane + shift;
-                const bool b_keep = in_beam && b_to < ef, c_keep = in_pass && place < ef;
+                const bool c_keep = in_pass && place < ef;
                 wave_lds_fence();
-                if (b_keep) {
-                    s.ins_d[b_to] = bd;
-                    s.ins_id[b_to] = b.id[0];
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const uint32_t b_to = 64u * q + (uint32_t)lane + shift[q];
+                    if (in_beam[q] && b_to < ef) {
+                        s.ins_d[b_to] = b.d[q];
+                        s.ins_id[b_to] = b.id[q];
+                    }
                 }
                 if (c_keep) {
                     s.ins_d[place] = my_d;
                     s.ins_id[place] = my_id;
                 }
                 wave_lds_fence();
-                const bool live = (uint32_t)lane < ncount;
-                b.d[0] = live ? s.ins_d[lane] : INFINITY;
-                b.id[0] = live ? s.ins_id[lane] : 0u;
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const bool live = 64u * q + (uint32_t)lane < ncount;
+                    b.d[q] = live ? s.ins_d[64u * q + lane] : INFINITY;
+                    b.id[q] = live ? s.ins_id[64u * q + lane] : 0u;
+                }
                 wave_lds_fence();
                 // the pop scan restarts at the nearest newcomer if that lies before the scan position
                 uint32_t lowest = 0xffffffffu;
@@ -1228,7 +1248,14 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
                 if (lowest < b.scan_from) b.scan_from = lowest;
                 b.count = ncount;
                 b.n_res = ncount;
-                b.worst = ncount >= ef ? readlane_f(b.d[0], ncount - 1u) : INFINITY;
+                if (ncount >= ef) {
+                    float wd;
+                    uint32_t wlo, wid;
+                    b.get(ncount - 1u, wd, wlo, wid);
+                    b.worst = wd;
+                } else {
+                    b.worst = INFINITY;
+                }
                 b.worst_lo = 0u;
                 KDB_T(ctr.n_ins += npass;)
                 return;

@@ -87,11 +87,14 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
     // scatter scratch of the one-pass insertion: its own in latency mode (wave 1 fills nb_id for the next hop meanwhile)
     s.ins_d = s.nb_d;
     s.ins_id = s.nb_id;
-    if (WIDE > 1) {
+    s.ins_cap = 64u;
+    if (WIDE > 1 || BS >= 2) { // (a beam of BS register slots scatters up to 64 * BS entries in one pass)
+        constexpr uint32_t ins_n = 64u * (BS >= 2 ? (uint32_t)BS : 1u);
         s.ins_d = reinterpret_cast<float *>(smem + off);
-        off += 64 * 4;
+        off += ins_n * 4;
         s.ins_id = reinterpret_cast<uint32_t *>(smem + off);
-        off += 64 * 4;
+        off += ins_n * 4;
+        s.ins_cap = ins_n;
     }
     s.nr_d = reinterpret_cast<float *>(smem + off); // traversal-only candidates (deleted nodes, filtered-out entry)
     off += (size_t)nr_cap * 4;
@@ -610,7 +613,8 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     const uint32_t nr_cap = ((idx->n_deleted < 2047u ? idx->n_deleted : 2047u) + 1u + 3u) & ~3u;
     const size_t qb = PREC == KDB_PREC_I8 ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4;
     constexpr bool WK = PREC == KDB_PREC_I8; // 64-bit distance keys: one more word per beam / neighbour / pending entry
-    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * (WK ? 12 : 8) : 0) + 64 * (WK ? 12 : 8) + (size_t)nr_cap * (WK ? 12 : 8);
+    const size_t lds_common = qb + (BS == 0 ? (size_t)beam_cap * (WK ? 12 : 8) : 0) + 64 * (WK ? 12 : 8) + (size_t)nr_cap * (WK ? 12 : 8) +
+                              (BS >= 2 ? (size_t)64 * BS * 8 : 0); // (scatter scratch of the one-pass insertion of a multi-slot register beam)
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
     const uint32_t hsize = (BS == 1 || BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;

@@ -35,10 +35,13 @@ def _poison_device_memory(request):
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    x = torch.empty(int(free * 0.96) // 4, dtype=torch.int32, device="cuda")
+    # ALL of the free HBM before the first test and before every 16th (280 GB take seconds to map and fill), 64 GB before the others
+    # (the allocator hands out the lowest free addresses first: the buffers of one test come from there)
+    share = 0.96 if _POISON["tests"] % 16 == 0 else min(0.96, 64e9 / max(free, 1))
+    x = torch.empty(int(free * share) // 4, dtype=torch.int32, device="cuda")
     x.fill_(pat)
     torch.cuda.synchronize()
-    _POISON["gb"] = x.numel() * 4 / 1e9
+    _POISON["gb"] = max(_POISON["gb"], x.numel() * 4 / 1e9)
     del x
     torch.cuda.empty_cache()
     idx = kektordb_amd.HipIndex(16, 0, 0, 4, 10, capacity=16)
@@ -50,7 +53,8 @@ def _poison_device_memory(request):
 
 def pytest_terminal_summary(terminalreporter):
     if _POISON["tests"]:
-        terminalreporter.write_line(f"--poison: HBM ({_POISON['gb']:.0f} GB) and LDS filled with a pattern before each of {_POISON['tests']} gpu tests")
+        terminalreporter.write_line(f"--poison: HBM (up to {_POISON['gb']:.0f} GB: all of it before every 16th test, 64 GB before the others) and LDS "
+                                    f"filled with a pattern before each of {_POISON['tests']} gpu tests")
     if TOL_SWAPS["lists"]:
         terminalreporter.write_line(f"reference-order comparisons (assert_same_results_tol): {TOL_SWAPS['lists']} lists needed an excuse -- "
                                     f"{TOL_SWAPS['in_run']} ids permuted inside a run of near-equal distances, {TOL_SWAPS['boundary']} swapped at the list's last distance")
