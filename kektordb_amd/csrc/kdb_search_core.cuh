@@ -459,6 +459,7 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
         if (kind == KDB_W_BEGIN) { // a layer search starts (:2461-2489): clear the set, mark the entry point, score it if asked
             lvw = uni(s.ctl[KDB_W_LEVEL]);
             level = (int)(lvw & 0xffu);
+            vis.end_layer(); // (the HBM bitset un-marks what the previous, upper layer marked: BitSet.Clear per layer call; the hash clears itself)
             vis.begin_layer(level > 0);
             (void)vis.test_and_set(node, lane == 0);
             if (lvw & 0x100u) {

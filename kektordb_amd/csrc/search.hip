@@ -118,6 +118,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         vis.bits = visited_pool + (size_t)blockIdx.x * v.vis_words;
         vis.words = v.vis_words;
         vis.marks = s.marks;
+        vis.record = false;
+        vis.n_marks = 0u;
     }
     if constexpr (WIDE > 1) {
         if (threadIdx.x < 16u) s.ctl[threadIdx.x] = 0u;
@@ -678,24 +680,26 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     };
     auto launch_lds = [&](auto kern, uint32_t vis_size, size_t lds) -> int { return launch_any(kern, vis_size, 1u, lds); };
     (void)launch_lds;
-    if constexpr (BS == 1 || BS == 2) {
+    if constexpr (BS == 1 || BS == 2 || BS == 4) {
         // latency mode: a batch that leaves most of the chip idle gives every query four waves: wave 0 walks, the other
         // three evaluate a hop's rows (one HBM round trip per hop instead of three), wave 1 prepares the next node while
         // wave 0 inserts (search_layer_wide); same walk, same results, same counters -- as long as every query gets its own
-        // resident workgroup (512 at 768-d float32)
+        // resident workgroup (512 at 768-d float32).  Round 5: the four-slot beam (ef 129 .. 256) too -- with the hash at its
+        // ordinary size there (the enlarged one would leave two workgroups per CU)
         static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
         static const int wide2_env = [] { const char *e = getenv("KDB_WIDE2_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
-            const size_t wlds = lds1 + 64 + 512 + (size_t)(hsize_w - hsize) * 4;
+            const uint32_t hw = BS == 4 ? hsize : hsize_w;
+            const size_t wlds = lds1 + 64 + 512 + (size_t)(hw - hsize) * 4;
             auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide_max = wide_env >= 0 ? (uint32_t)wide_env : ncu * (uint32_t)occupancy_blocks(wk, 256, wlds);
-            if (B <= wide_max) return launch(wk, hsize_w, 4u);
+            if (B <= wide_max) return launch_any(wk, hw, 4u, wlds);
             // twice as many queries than that: two waves per query -- the walker and one wave that prepares nodes and evaluates rows
             auto wk2 = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 2>;
             if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             const uint32_t wide2_max = wide2_env >= 0 ? (uint32_t)wide2_env : ncu * (uint32_t)occupancy_blocks(wk2, 128, wlds);
-            if (B <= wide2_max) return launch(wk2, hsize_w, 2u);
+            if (B <= wide2_max) return launch_any(wk2, hw, 2u, wlds);
         }
     }
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
@@ -711,9 +715,36 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
             auto kh = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>;
             const size_t lds_h = lds_common + (size_t)hbig * 4;
             if (lds_h + 16 <= 160 * 1024) {
+                // Round 5: the latency mode for the LDS beam as well (k = 100 / ef = 400 on 1024 queries: every query its own four
+                // waves -- the rows of a hop in one round trip, the visit of the next node beside the one-merge insertion)
+                if (!getenv("KDB_NO_WIDE_LDS_BEAM")) {
+                    const size_t wlds = lds_h + 64 + 512;
+                    if (wlds + 16 <= 160 * 1024) {
+                        auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
+                        KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+                        if (B <= ncu * (uint32_t)occupancy_blocks(wk, 256, wlds)) return launch_any(wk, hbig, 4u, wlds);
+                        auto wk2 = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 2>;
+                        KDB_HIP(hipFuncSetAttribute((const void *)wk2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+                        if (B <= ncu * (uint32_t)occupancy_blocks(wk2, 128, wlds)) return launch_any(wk2, hbig, 2u, wlds);
+                    }
+                }
                 KDB_HIP(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
                 const uint32_t one_round = ncu * (uint32_t)occupancy_blocks(kh, 64, lds_h);
                 if (B <= one_round) return launch_lds(kh, hbig, lds_h);
+            }
+        }
+    }
+    if constexpr (BS == 0) { // beyond the large hash (ef > 1040, or a batch too large for it): the latency mode over the HBM bitset --
+        // wave 1 owns the bitset, the walker never waits for its atomics
+        if (!getenv("KDB_NO_WIDE_LDS_BEAM")) {
+            const size_t wlds = lds1 + 64 + 512;
+            if (wlds + 16 <= 160 * 1024) {
+                auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 0, 4>;
+                if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+                if (B <= ncu * (uint32_t)occupancy_blocks(wk, 256, wlds)) return launch_any(wk, 0u, 4u, wlds);
+                auto wk2 = hnsw_search_kernel<PREC, METRIC, NCH, BS, 0, 2>;
+                if (wlds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)wk2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+                if (B <= ncu * (uint32_t)occupancy_blocks(wk2, 128, wlds)) return launch_any(wk2, 0u, 2u, wlds);
             }
         }
     }
