@@ -85,6 +85,7 @@ struct FsParams {
     uint32_t fb_alt;          // 1: odd tiles walk their slabs backwards
     uint32_t fb_grow;         // 1: compaction rounds thin out once the thresholds have settled (KDB_FB_NOGROW: A/B switch)
     uint32_t fb_seeded;       // 1: a seed launch published first thresholds into g_pub (KDB_FB_NOSEED: A/B switch)
+    uint32_t fb_pref;         // 1: threads 0..255 pull the row lines of the slab three steps ahead into L2 (KDB_FB_PREFETCH)
     uint32_t fb_seed_nstr;    // the number of stripes the HOST derived when it decided so: both kernels check it against fs_resolve's
     uint32_t fb_slack, fb_period; // compaction rounds every fb_period tiles for lists longer than kl + fb_slack
     uint32_t fb_dbg;          // measurement switches (KDB_FB_DBG): 1 no selection, 2 no DMA after the first slab, 4 no MFMAs
@@ -2057,6 +2058,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_spx = fb_spx;
         p.fb_slack = fb_slack;
         p.fb_alt = getenv("KDB_FB_NOALT") ? 0u : 1u;
+        { const char *e = getenv("KDB_FB_PREFETCH"); p.fb_pref = e ? (uint32_t)atoi(e) : 0u; }
         p.fb_grow = getenv("KDB_FB_NOGROW") ? 0u : 1u;
         // Seed launch: only when the stripe geometry is known here (no filter, no deleted rows: the row count never leaves the
         // device otherwise), every stripe holds a whole first tile, and a stripe's share of the kl best is at most the 16 rows

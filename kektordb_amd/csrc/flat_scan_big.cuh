@@ -51,7 +51,8 @@ constexpr int FB_SLAB = 128;     // bytes of every row per K slab
 constexpr int FB_CSLOTS = 20;     // fs_compact_wave register slots: a list never holds more than 64 * 20 entries
 constexpr uint32_t FB_DUMPS = 96; // 16-score blocks a wave can park in its scratch between two phase-B passes
 constexpr uint32_t FB_STAGE = 2u * FB_T * FB_SLAB; // one slab buffer: rows + queries = 64 KB
-constexpr size_t FB_LDS = 2u * FB_STAGE + FB_T * 12u + 2u * FB_T * 8u + FB_T * 4u + 64u;
+constexpr size_t FB_LDS_BASE = 2u * FB_STAGE + FB_T * 12u + 2u * FB_T * 8u + FB_T * 4u + 64u;
+constexpr size_t FB_LDS = FB_LDS_BASE + 4u * 256u; // + the landing words of the row prefetch (four waves x 64 lanes x 4 B)
 
 // entries allocated per (stripe, query): lists are compacted every `period` tiles when they hold more than kl + slack
 // entries, and a tile appends at most FB_T entries to a list
@@ -86,6 +87,21 @@ __device__ __forceinline__ void fb_glds4(const unsigned char *g0, const unsigned
                  : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_dst)
                  : "memory", "scc");
 }
+// One dword per lane from each lane's own address to LDS lds_dst + lane*4: used as a PREFETCH -- the line of a row slab that the
+// slab DMA will ask for three steps later is pulled into the XCD's L2 now (the landing words are never read).  LDS-DMA rather than
+// a register load: nothing to keep alive, nothing the compiler could reuse too early.
+__device__ __forceinline__ void fb_glds1(const unsigned char *g0, uint32_t lds_dst /* wave-uniform */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g0), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void fb_dma_wait1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } // all but the youngest request
 __device__ __forceinline__ float fb_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ void fb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -276,6 +292,11 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
     unsigned long long tm_sel = 0, tm_cmp = 0;
     unsigned long long n_app = 0, n_dmp = 0, n_cmp = 0; // debug counts (FB_DBG & 256 / 512)
     uint32_t t = 0;
+    // row prefetch (p.fb_pref, rows of >= 4 slabs, not the seed launch): thread r < 256 touches row r's line of the slab that is
+    // computed three steps from now -- this tile's, or the next tile's first slabs
+    const bool pf_on = !SEED && p.fb_pref != 0u && nslab >= 4u && tid < FB_T;
+    const uint32_t pf_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)FB_LDS_BASE + ((uint32_t)wave & 3u) * 256u);
+    uint32_t cur_id = tid < FB_T ? sel_id[tid] : 0u; // the row this thread prefetches: row tid of the current tile
     for (uint32_t tile = row_begin; tile < row_end; tile += FB_T, t++) {
         const uint32_t tp = t & 1u;
         const bool has_next = tile + FB_T < row_end;
@@ -333,6 +354,19 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             FB_SB();
             read_frags(0, buf, 2);
             if (dma) issue_queries(buf ^ 1u, nslab_i);
+            bool pf = false; // (wave-uniform: waves 0..3 hold the threads r < 256)
+            if (pf_on) { // the slab computed at step s + 3: of this tile (walked backwards when the tile is odd), or of the next one
+                if (s + 3u < nslab) {
+                    const uint32_t sl = odd ? nslab - 1u - (s + 3u) : s + 3u;
+                    fb_glds1(rows8 + (size_t)cur_id * rowb + sl * FB_SLAB, pf_lds);
+                    pf = true;
+                } else if (has_next) {
+                    const uint32_t s2 = s + 3u - nslab, odd2 = p.fb_alt ? (odd ^ 1u) : 0u;
+                    const uint32_t sl = odd2 ? nslab - 1u - s2 : s2;
+                    fb_glds1(rows8 + (size_t)n_id * rowb + sl * FB_SLAB, pf_lds);
+                    pf = true;
+                }
+            }
             FB_SB();
             mfma_step(1);
             FB_SB();
@@ -340,7 +374,8 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             FB_SB();
             mfma_step(0);
             FB_SB();
-            fb_dma_wait();
+            if (pf) fb_dma_wait1(); // (the prefetch is the youngest request: it may stay in flight)
+            else fb_dma_wait();
             // ids / norms of the next tile: stored BEFORE the first slab's barrier.  The last slab step reads them (aptr, above)
             // and with two-slab rows that step is the next one: stored behind this barrier they raced with it (waves 4-7 read
             // what waves 0-3 had not written yet: stale or never-written ids -> wrong rows ranked, or a fault).  The other
@@ -546,6 +581,7 @@ flat_scan_big_kernel(KdbView v, const unsigned char *__restrict__ rows8 /* rowb 
             if (p.g_pub) read_published();
         }
         if (tm_on && !(FB_DBG & 2048u)) tm_cmp += __builtin_readcyclecounter() - tm1;
+        cur_id = n_id;
     }
     if ((FB_DBG & 32u) && p.ctr && lane == 0) { // per-wave cycle totals: selection phases, compaction rounds (with their barriers)
         atomicAdd(p.ctr + 2, tm_sel);
