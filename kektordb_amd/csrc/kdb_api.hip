@@ -1167,6 +1167,8 @@ static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk
 
 void kdb_launch_forming(kdb_index *idx, std::unique_lock<std::mutex> &lk) {
     if (!idx->forming || idx->writers_waiting) return;
+    // calls that wait for a slot themselves must not starve behind a stream of joinable callers: every other freed slot is theirs
+    if (idx->slot_waiters && (idx->release_seq++ & 1u)) return;
     const int si = slot_find_free(idx);
     if (si < 0) return;
     kdb_group *g = idx->forming;
@@ -1281,7 +1283,9 @@ static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B
         } else if (!idx->forming) {
             idx->forming = g; // whoever frees a slot (or ends a write) launches it; callers arriving meanwhile join
         } else { // the forming group is full or has another key: wait for a slot like any other call
+            idx->slot_waiters++;
             idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
+            idx->slot_waiters--;
             launch_search_group(idx, lk, g, si);
         }
     }
@@ -1324,7 +1328,9 @@ static int staged_slot_call(kdb_index *idx, const float *queries, uint32_t B, ui
     static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
     std::unique_lock<std::mutex> lk(idx->mu);
     int si = -1;
+    idx->slot_waiters++;
     idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
+    idx->slot_waiters--;
     kdb_slot &sl = idx->slots[si];
     sl.busy = true;
     idx->inflight++;

@@ -190,6 +190,8 @@ struct kdb_index {
     uint32_t writers_waiting = 0;  // ... and new calls wait while a writer does (no writer starvation)
     std::condition_variable slot_cv; // leaders waiting for a slot, writers waiting for inflight == 0
     kdb_group *forming = nullptr;  // the group that waits for the next free slot and may still be joined
+    uint32_t slot_waiters = 0;     // calls that wait for a slot themselves (exact scans, filtered searches, a group with another key)
+    uint32_t release_seq = 0;      // ... every other freed slot is theirs when both they and a forming group wait (no starvation)
     kdb_group groups[KDB_GROUP_POOL];
     uint32_t *h_done_pool = nullptr;          // KDB_GROUP_POOL x KDB_GROUP_CAP completion words, page-locked
     std::atomic<uint32_t> flag_waiters{0};    // callers watching completion words right now (the first few spin, the others sleep)
