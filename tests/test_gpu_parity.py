@@ -1489,3 +1489,43 @@ def test_flat_scan_k_above_128_ties_with_an_id_list(oracle, hip):
                     assert c == len(oi) == k
                     assert np.array_equal(ids[b, :c], oi), (k, rep, b, np.nonzero(ids[b, :c] != oi)[0][:5])
                     assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (k, rep, b)
+
+
+def test_tiny_negative_dots_that_collide_as_float64(oracle, hip):
+    """the reference orders 1.0 - float64(dot) (distance_go.go:127).  Two DIFFERENT negative dots with |dot| in
+    [2^-30, 2^-29) are one float ulp (2^-53) apart while 1.0 + |dot| has an ulp of 2^-52: the two distances can be ONE double, and
+    the reference then orders the nodes by the history of its heaps -- the fast walk (which orders -dot as floats) must flag such a
+    walk (kdb_tiny_dot_rule: |dot| < 2^-29 exactly; the old bound 1.8e-9 missed [1.8e-9, 2^-29)) and the heap-order pass must give
+    the oracle's ids IN ORDER.  Two rows (-x1, 1, 0, ..) and (-x2, 1, 0, ..) against the query (1, 0, ..): dots -x1, -x2 exactly."""
+    O = oracle
+    n, dim = 160, 16
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[:, 0] = np.abs(X[:, 0]) + 0.5                      # everybody else: a clearly positive dot with the query
+    x1 = np.float32(1.85e-9)
+    while not ((1.0 + np.float64(x1)) == (1.0 + np.float64(np.nextafter(x1, np.float32(1))))):
+        x1 = np.nextafter(x1, np.float32(1))
+    x2 = np.nextafter(x1, np.float32(1))
+    assert np.float32(1.8e-9) <= x1 < x2 < np.float32(2.0 ** -29) and x1 != x2
+    for row, x in ((37, x1), (101, x2)):
+        X[row] = 0.0
+        X[row, 0], X[row, 1] = -x, 1.0
+    orc, idx = build_pair(O, hip, X, 1, m=8, efc=64)
+    stored = orc.rows()
+    assert stored[38, 0] == -x1 and stored[102, 0] == -x2 and stored[38, 1] == 1.0   # (normalising them changed nothing)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = np.zeros((3, dim), np.float32)
+    Q[:, 0] = 1.0
+    Q[1, 2] = 1e-3
+    Q[2, 3] = -2e-3
+    k = n
+    ids, dist, cnt = idx.search_batch(Q, k, 256, tie_flag=True)
+    assert int(cnt[0]) & 0x80000000, "the walk met two distances that are one float64: it must say so"
+    ids, dist, cnt, (nd, nh) = idx.search_batch(Q, k, 256, heap_order=True, trace=True)
+    for b in range(Q.shape[0]):
+        oi, od, (ond, onh) = orc.search(Q[b], k, ef=256, counters=True)
+        c = int(cnt[b])
+        assert c == len(oi)
+        assert np.array_equal(ids[b, :c], oi), (b, np.nonzero(ids[b, :c] != oi)[0][:4])
+        assert np.array_equal(raw_to_score(idx, dist[b, :c]), od)
+        assert (int(nd[b]), int(nh[b])) == (ond, onh)
