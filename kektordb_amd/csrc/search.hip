@@ -55,11 +55,14 @@ __device__ __forceinline__ size_t q_lds_bytes(uint32_t ld) {
 #ifndef KDB_SEARCH_MINW
 #define KDB_SEARCH_MINW 4
 #endif
+#ifndef KDB_GENERIC_MINW
+#define KDB_GENERIC_MINW 3 // the width-generic kernels (any dim)
+#endif
 // VIS = 1: visited set in LDS (hash) that migrates to the wave's HBM bitset if it overflows.
 // VIS = 0: visited bitset in HBM.
 // WIDE > 1: latency mode, WIDE waves per query (search_layer_wide in kdb_search_core.cuh).
 template <int PREC, int METRIC, int NCH, int BS, int VIS, int WIDE = 1>
-__global__ void __launch_bounds__(64 * WIDE, (WIDE == 4 && KDB_WIDE4_MINW ? KDB_WIDE4_MINW : PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? 3 : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
+__global__ void __launch_bounds__(64 * WIDE, (WIDE == 4 && KDB_WIDE4_MINW ? KDB_WIDE4_MINW : PREC == KDB_PREC_I8 ? 4 : PREC == KDB_PREC_F16 ? KDB_F16_MINW : NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? KDB_GENERIC_MINW : KDB_SEARCH_MINW)) // wide rows keep 16+ float4 per lane in flight
 hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__restrict__ qnorms, uint32_t raw, uint32_t B,
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
@@ -619,7 +622,11 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
                               (BS >= 2 ? (size_t)64 * BS * 8 : 0); // (scatter scratch of the one-pass insertion of a multi-slot register beam)
     // visited set: LDS hash (spilling to the HBM bitset if it ever fills) on the register-beam kernels,
     // the HBM bitset alone for large ef
-    const uint32_t hsize = (BS == 1 || BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
+    uint32_t hsize = (BS == 1 || BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
+    if (hsize) { // measurement knob: another table size (a power of two >= 1024)
+        static const uint32_t hs_env = [] { const char *e = getenv("KDB_VIS_HASH"); return e ? (uint32_t)atoi(e) : 0u; }();
+        if (hs_env >= 1024u && (hs_env & (hs_env - 1u)) == 0u) hsize = hs_env;
+    }
     const size_t lds1 = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
     if (lds1 + 16 > 160 * 1024) {
         kdb_set_error("ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, lds1);
