@@ -327,9 +327,13 @@ extern "C" int kdb_index_create(const kdb_index_desc *desc, kdb_index **out) {
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int i = 0; i < idx->n_slots; i++) KDB_TRY(hipStreamCreateWithPriority(&idx->slots[i].stream, hipStreamNonBlocking, prio_hi));
         // completion words of the combined launches: page-locked, coherent, written by the kernels at system scope
-        KDB_TRY(hipHostMalloc(reinterpret_cast<void **>(&idx->h_done_pool), (size_t)KDB_GROUP_POOL * KDB_GROUP_CAP * 4, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(idx->h_done_pool, 0, (size_t)KDB_GROUP_POOL * KDB_GROUP_CAP * 4);
-        for (int i = 0; i < KDB_GROUP_POOL; i++) idx->groups[i].h_done = idx->h_done_pool + (size_t)i * KDB_GROUP_CAP;
+        // (+ 16 words per group: the session word of an open launch, on a cache line of its own)
+        KDB_TRY(hipHostMalloc(reinterpret_cast<void **>(&idx->h_done_pool), (size_t)KDB_GROUP_POOL * (KDB_GROUP_CAP + 16u) * 4, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(idx->h_done_pool, 0, (size_t)KDB_GROUP_POOL * (KDB_GROUP_CAP + 16u) * 4);
+        for (int i = 0; i < KDB_GROUP_POOL; i++) {
+            idx->groups[i].h_done = idx->h_done_pool + (size_t)i * (KDB_GROUP_CAP + 16u);
+            idx->groups[i].h_ctl = idx->groups[i].h_done + KDB_GROUP_CAP;
+        }
     }
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         KDB_TRY(hipEventCreate(&idx->ring_ev0[i]));
@@ -912,9 +916,11 @@ static uint32_t effective_ef(uint32_t ef, uint32_t flags) {
     return ef;
 }
 
-struct KdbDone { // completion words of a combined launch (KdbMultiAllow::done_flags)
+struct KdbDone { // completion words of a combined launch (KdbMultiAllow::done_flags) and, for an open launch, its session word
     uint32_t *flags;
     uint32_t gen;
+    const uint32_t *sess_ctl = nullptr;
+    uint32_t sess_gen = 0, sess_grid = 0;
 };
 
 struct MultiLists { // heterogeneous batch (kdb_search_batch_multi_dev): G lists back to back + the list of every query
@@ -956,6 +962,9 @@ static int search_dev_locked(kdb_index *idx, const float *d_queries, uint32_t B,
     if (done) {
         ma.done_flags = done->flags;
         ma.done_gen = done->gen;
+        ma.sess_ctl = done->sess_ctl;
+        ma.sess_gen = done->sess_gen;
+        ma.sess_grid = done->sess_grid;
     }
     if (ml && ml->G) { // one entry point per list, chosen on the device: no host round trip for any of the G lists
         int rc = kdb_ensure_group_entries(idx, ml->G);
@@ -1112,9 +1121,28 @@ static kdb_group *group_get(kdb_index *idx) { // under mu
             g.launched.store(0u, std::memory_order_relaxed);
             g.failed.store(0u, std::memory_order_relaxed);
             g.members.clear();
+            g.open = false;
+            g.cap_q = 0;
             return &g;
         }
     return nullptr;
+}
+
+// ---- open launches ("sessions"): a combined launch keeps accepting queries for KDB_SESSION_US microseconds while its kernel runs --
+// a caller that arrives meanwhile writes its query into the slot's page-locked buffer, publishes the new count in the session word
+// and is walked by a workgroup that was waiting for exactly that ticket: no launch, no wait for a slot.  At most one launch is open.
+static uint32_t session_us() {
+    static const uint32_t v = [] { const char *e = getenv("KDB_SESSION_US"); return e ? (uint32_t)atoi(e) : 300u; }();
+    return v;
+}
+static uint32_t sess_word(uint32_t gen, uint32_t n, bool closed) { return ((gen & 0xffffu) << 16) | (closed ? 0x8000u : 0u) | (n & 0x3ffu); }
+
+void kdb_close_session(kdb_index *idx) { // under mu
+    kdb_group *g = idx->open_session;
+    if (!g) return;
+    g->open = false;
+    __atomic_store_n(g->h_ctl, sess_word(g->gen, g->nq, true), __ATOMIC_RELEASE); // workgroups waiting for later tickets leave
+    idx->open_session = nullptr;
 }
 
 static void group_fail(kdb_group *g, int rc) {
@@ -1137,7 +1165,10 @@ static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk
     idx->n_groups++;
     idx->n_group_members += g->members.size();
     if (nq > idx->largest_group) idx->largest_group = nq;
-    const StagedLayout L = staged_layout(idx, nq, g->k, false, g->dist_bytes);
+    // an open launch has room for KDB_GROUP_CAP queries (int8 indexes quantise their queries in a kernel of its own: closed launches)
+    const bool session = session_us() != 0u && idx->desc.precision != KDB_PREC_I8 && !idx->writers_waiting && nq < KDB_GROUP_CAP;
+    g->cap_q = session ? KDB_GROUP_CAP : nq;
+    const StagedLayout L = staged_layout(idx, g->cap_q, g->k, false, g->dist_bytes);
     int rc = slot_ensure(sl, L.total);
     if (rc == KDB_OK) {
         unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin);
@@ -1153,13 +1184,28 @@ static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk
         g->h_dist = h + L.o_dist;
         g->h_cnt = h + L.o_cnt;
         g->t_launch_ns = now_ns();
-        g->launched.store(1u, std::memory_order_release); // (before the kernel can publish a word: a member that sees its word set finds these fields)
         KdbDone done{g->h_done, g->gen};
+        if (session && !idx->writers_waiting) {
+            kdb_close_session(idx); // (the previous open launch finishes what it has)
+            __atomic_store_n(g->h_ctl, sess_word(g->gen, nq, false), __ATOMIC_RELEASE);
+            g->open = true;
+            idx->open_session = g;
+            done.sess_ctl = g->h_ctl;
+            done.sess_gen = g->gen & 0xffffu;
+            // workgroups beyond the first queries' own: they wait for the tickets of the callers that join -- more of them when the
+            // launch starts large (the load is high: 256 callers fill a launch within its window)
+            uint32_t spare = 3u * nq > 48u ? 3u * nq : 48u;
+            if (spare > KDB_GROUP_CAP - nq) spare = KDB_GROUP_CAP - nq;
+            done.sess_grid = nq + spare;
+        }
+        g->launched.store(1u, std::memory_order_release); // (before the kernel can publish a word: a member that sees its word set finds these fields)
         KdbLaneGuard lane(idx, sl.stream);
         rc = lane.rc;
         if (rc == KDB_OK)
-            rc = search_dev_locked(idx, reinterpret_cast<float *>(h), nq, g->k, g->ef, nullptr, g->flags, reinterpret_cast<uint32_t *>(h + L.o_ids),
-                                   reinterpret_cast<float *>(h + L.o_dist), reinterpret_cast<uint32_t *>(h + L.o_cnt), sl.stream, nullptr, &done);
+            rc = search_dev_locked(idx, reinterpret_cast<float *>(h), done.sess_ctl ? g->cap_q : nq, g->k, g->ef, nullptr, g->flags,
+                                   reinterpret_cast<uint32_t *>(h + L.o_ids), reinterpret_cast<float *>(h + L.o_dist), reinterpret_cast<uint32_t *>(h + L.o_cnt),
+                                   sl.stream, nullptr, &done);
+        if (rc && idx->open_session == g) kdb_close_session(idx);
     }
     if (rc) group_fail(g, rc);
     idx->ns_in_launch.fetch_add(now_ns() - t_in, std::memory_order_relaxed);
@@ -1261,9 +1307,25 @@ static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B
     const size_t dist_bytes = (flags & KDB_SEARCH_DIST_F64) ? 8 : 4;
     std::unique_lock<std::mutex> lk(idx->mu);
     if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
-    kdb_group *g = idx->forming;
+    kdb_group *g = nullptr;
     uint32_t off = 0;
-    if (g && g->k == k && g->ef == ef && g->flags == flags && g->nq + B <= KDB_GROUP_CAP) { // join the group that waits for a slot
+    if (kdb_group *os = idx->open_session) { // a launch that still accepts queries: write mine into its buffer, publish the count
+        if (now_ns() - os->t_launch_ns > (uint64_t)session_us() * 1000ull || idx->writers_waiting) {
+            kdb_close_session(idx);
+        } else if (os->k == k && os->ef == ef && os->flags == flags && os->nq + B <= os->cap_q && !os->failed.load(std::memory_order_relaxed)) {
+            g = os;
+            off = g->nq;
+            memcpy(reinterpret_cast<unsigned char *>(idx->slots[g->slot].h_pin) + (size_t)off * idx->desc.dim * 4, queries, (size_t)B * idx->desc.dim * 4);
+            g->nq += B;
+            g->refs++;
+            idx->n_group_members++;
+            if (g->nq > idx->largest_group) idx->largest_group = g->nq;
+            __atomic_store_n(g->h_ctl, sess_word(g->gen, g->nq, false), __ATOMIC_RELEASE);
+        }
+    }
+    if (g) {
+        // (joined an open launch)
+    } else if ((g = idx->forming) && g->k == k && g->ef == ef && g->flags == flags && g->nq + B <= KDB_GROUP_CAP) { // join the group that waits for a slot
         off = g->nq;
         g->nq += B;
         g->refs++;
@@ -1299,6 +1361,7 @@ static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B
     }
     lk.lock();
     if (--g->refs == 0) { // the last member out: every walk of the launch is done (its words are set), the slot and the group object are free
+        if (idx->open_session == g) kdb_close_session(idx); // (nobody else joined: its kernel may end)
         if (g->failed.load(std::memory_order_acquire) && g->slot >= 0) {
             lk.unlock();
             (void)hipStreamSynchronize(idx->slots[g->slot].stream); // (whatever was queued must not outlive the slot's next use)

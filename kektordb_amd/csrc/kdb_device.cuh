@@ -15,6 +15,30 @@ __device__ __forceinline__ void kdb_publish_done(uint32_t *flag, uint32_t gen) {
 
 __device__ __forceinline__ int kdb_lane() { return (int)(threadIdx.x & 63u); }
 
+// Ticket qi of an OPEN launch (KdbMultiAllow::sess_ctl): true once the host has published query qi, false when the launch is closed
+// at or below qi (or belongs to another generation, or -- the host is gone -- after 0.5 s: a thousand session lengths, so a host
+// thread that is descheduled between its look at the clock and its publish is still served).  Wave-uniform.
+__device__ __forceinline__ bool kdb_wait_ticket(const uint32_t *ctl, uint32_t gen16, uint32_t qi) {
+    const unsigned long long t0 = wall_clock64(); // 100 MHz
+    for (;;) {
+        uint32_t w = 0u;
+        if ((threadIdx.x & 63u) == 0u) w = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if ((w >> 16) != gen16) return false;
+        if (qi < (w & 0x3ffu)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the query the host wrote before it published the count
+            return true;
+        }
+        if (w & 0x8000u) return false;
+        if (wall_clock64() - t0 > 50000000ull) return false;
+        __builtin_amdgcn_s_sleep(48);
+        if (qi >= (w & 0x3ffu) + 8u) { // a ticket far ahead of the callers: look less often (the word lives in host memory)
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned kdb_mbcnt(unsigned long long m) {
     // number of set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));

@@ -51,6 +51,13 @@ struct KdbMultiAllow {
     // its own and leaves as soon as ITS walk is done, not when the slowest walk of the launch is.
     uint32_t *done_flags = nullptr;
     uint32_t done_gen = 0;
+    // An OPEN launch (kdb_group session): queries may still be appended while the kernel runs.  sess_ctl is one page-locked word
+    // the host publishes -- bits 0..9 the number of queries written so far, bit 15 "closed: no more will come", bits 16..31 the
+    // launch's generation (a word of another generation means closed).  A workgroup that drew ticket qi walks it once qi < published,
+    // leaves when the launch is closed at or below its ticket.  sess_grid: workgroups to launch (the first queries + spare ones).
+    const uint32_t *sess_ctl = nullptr;
+    uint32_t sess_gen = 0;
+    uint32_t sess_grid = 0;
 };
 
 // Per-call scratch of the asynchronous entry points.  An index keeps KDB_LANES sets; a call takes the set last used on
@@ -87,6 +94,9 @@ struct kdb_group {
     char err[256] = "";
     uint32_t gen = 0;                            // value of a completion word that means "done" for THIS use of the group object
     uint32_t *h_done = nullptr;                  // KDB_GROUP_CAP completion words, page-locked (written by the kernels)
+    uint32_t *h_ctl = nullptr;                   // the session word of an open launch, page-locked (written here, read by the kernel)
+    bool open = false;                           // launched and still accepting queries (idx->open_session == this)
+    uint32_t cap_q = 0;                          // queries the launch has room for (layout of the slot's buffer)
     std::atomic<uint32_t> launched{0};           // set (release) by the launching thread once the fields below are valid
     std::atomic<uint32_t> failed{0};             // the launch failed / the device faulted: rc and err say why
     uint64_t t_launch_ns = 0;
@@ -190,6 +200,7 @@ struct kdb_index {
     uint32_t writers_waiting = 0;  // ... and new calls wait while a writer does (no writer starvation)
     std::condition_variable slot_cv; // leaders waiting for a slot, writers waiting for inflight == 0
     kdb_group *forming = nullptr;  // the group that waits for the next free slot and may still be joined
+    kdb_group *open_session = nullptr; // the launch that still accepts queries while its kernel runs (at most one)
     uint32_t slot_waiters = 0;     // calls that wait for a slot themselves (exact scans, filtered searches, a group with another key)
     uint32_t release_seq = 0;      // ... every other freed slot is theirs when both they and a forming group wait (no starvation)
     kdb_group groups[KDB_GROUP_POOL];
@@ -216,10 +227,12 @@ int kdb_lane_release(kdb_index *idx, hipStream_t s);
 // its RLock holders: take mu, announce, wait until no call's kernels can still be running.  (Calls of the _dev entry points run on
 // streams of the caller, who orders them -- as before.)
 void kdb_launch_forming(kdb_index *idx, std::unique_lock<std::mutex> &lk); // kdb_api.hip: under mu; no-op unless a group waits and a slot is free
+void kdb_close_session(kdb_index *idx); // kdb_api.hip: under mu; the open launch (if any) stops accepting queries: its kernel may end
 struct KdbWriteLock {
     kdb_index *idx;
     std::unique_lock<std::mutex> lk;
     explicit KdbWriteLock(kdb_index *i) : idx(i), lk(i->mu) {
+        kdb_close_session(idx); // (an open launch would keep its kernel -- and inflight -- alive)
         if (idx->inflight) {
             idx->writers_waiting++;
             idx->slot_cv.wait(lk, [&] { return idx->inflight == 0; });

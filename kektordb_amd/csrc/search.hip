@@ -142,6 +142,7 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         if (lane == 0) qi = atomicAdd(work, 1u);
         qi = __shfl(qi, 0, 64);
         if (qi >= B) break;
+        if (ma.sess_ctl && !kdb_wait_ticket(ma.sess_ctl, ma.sess_gen, qi)) break; // an open launch: queries still arrive
 
         vis.begin_query();
         // query -> LDS (prepared in the reference's order: kdb_load_query)
@@ -641,6 +642,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         if (lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         uint32_t grid = ncu * (uint32_t)occupancy_blocks(kern, (int)(64u * waves), lds);
         if (grid > B) grid = B;
+        if (ma.sess_ctl && grid > ma.sess_grid) grid = ma.sess_grid; // an open launch: the first queries' workgroups + spare ones
         if (grid == 0) return KDB_OK;
         // KDB_SEARCH_HEAP_ORDER (raw & 16): queries whose walk meets equal distances are queued by the kernel and walked again by
         // heap_walk_kernel (search_heap.hip) behind it -- everything it needs is allocated and armed BEFORE the launch
