@@ -543,6 +543,7 @@ def memory_plan(a, waves_resident=4096, upload_chunk=2_000_000):
         "adjacency_upper_pool_and_slot_table": 2 * (slots * deg_up + 4) * 4,
         "norms_levels_up_idx_deleted": n1 * 4 + n1 + n1 * 4 + (n1 + 31) // 32 * 4,
         "visited_bitsets_two_lanes": 2 * waves_resident * vis_words * 4,     # one bitset per resident wave (spill target of the LDS hash)
+        "visited_bitsets_heap_order_pass_beside_the_kernel": 2 * 7 * 256 * vis_words * 4,  # its workgroups (<= 7 per CU) run while the search kernel's do
         "builder_workspace": n1 * (deg0 * 4 + 4 + rcap * 4 + rcap * 4) + (slots + 1) * (deg_up * 4 + 4 + rcap * 8) + tasks * (efc * 8 + 4 + 32 * 4) + tasks * deg0 * 12,
         "queries_answers_exchange_buffers": 2 * B * dim * 4 + (a.gpus + 3) * (2 * B * k + B) * 4 * 2,
         "harness_upload_chunk_torch": 2 * min(n, upload_chunk) * dim * 4,    # gen_corpus: the chunk and its normalised copy

@@ -390,6 +390,10 @@ extern "C" void kdb_index_destroy(kdb_index *idx) {
         for (void *b : lb)
             if (b) (void)hipFree(b);
         if (l.done) (void)hipEventDestroy(l.done);
+        if (l.side_ev1) kdb_heap_overlap_forget(idx);
+        if (l.side_ev0) (void)hipEventDestroy(l.side_ev0);
+        if (l.side_ev1) (void)hipEventDestroy(l.side_ev1);
+        if (l.side) (void)hipStreamDestroy(l.side);
     }
     for (uint32_t i = 0; i < kdb_index::RING; i++) {
         if (idx->ring_ev0[i]) (void)hipEventDestroy(idx->ring_ev0[i]);

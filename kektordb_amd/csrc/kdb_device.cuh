@@ -474,6 +474,11 @@ __device__ __forceinline__ void kdb_i8_key(int dot, float qnorm, float snorm, fl
         lo = 0u;
         return;
     }
+    if (e == 0x7ffu) { // a norm that is not a number: infinitely far, never a key that compares false with everything
+        hi = INFINITY;
+        lo = 0u;
+        return;
+    }
     hi = __uint_as_float(((e - 896u) << 23) | (uint32_t)((u >> 29) & 0x7fffffu));
     lo = (uint32_t)u & 0x1fffffffu;
 }

@@ -122,6 +122,8 @@ struct kdb_lane {
     size_t tie_bytes = 0;
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
+    hipStream_t side = nullptr;  // heap-order pass beside the search kernel (large batches): created at first use
+    hipEvent_t side_ev0 = nullptr, side_ev1 = nullptr;
     bool used = false;
     uint64_t last_use = 0;
 };
@@ -297,8 +299,36 @@ int kdb_heap_walk_plan(kdb_index *idx, const KdbView &v, uint32_t ef, uint32_t k
 int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B, uint32_t k, uint32_t ef,
                          const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_tie_list, unsigned char *d_tails, const KdbHeapPlan &plan,
                          unsigned long long *d_ctr, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
-                         uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s);
+                         uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s, uint32_t vis_first = 0, unsigned char *d_stash = nullptr, uint32_t mode = 0);
+// Heap-order pass beside the search kernel: where the search kernel puts the answer of a query it queues (B x k ids, B x k distances
+// of 8 bytes -- float or double --, B x {count | tie bit, n_dist, n_hops, -}); read back only if the pass cannot resolve the query
+struct KdbTieStash {
+    unsigned char *base;
+    uint32_t B, k;
+    static size_t bytes(uint32_t B, uint32_t k) { return (size_t)B * k * 12u + (size_t)B * 16u + 256u; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    size_t ids_bytes() const { return ((size_t)B * k * 4u + 7u) & ~(size_t)7u; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t *ids(uint32_t qi) const { return reinterpret_cast<uint32_t *>(base) + (size_t)qi * k; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    float *dist(uint32_t qi) const { return reinterpret_cast<float *>(base + ids_bytes()) + (size_t)qi * k; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    double *dist64(uint32_t qi) const { return reinterpret_cast<double *>(base + ids_bytes()) + (size_t)qi * k; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t *meta(uint32_t qi) const { return reinterpret_cast<uint32_t *>(base + ids_bytes() + (size_t)B * k * 8u) + (size_t)qi * 4u; }
+};
 int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes);
+void kdb_heap_overlap_forget(const kdb_index *idx); // search.hip: kdb_index_destroy, before the lanes' events go
 int kdb_launch_distance(const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t B,
                         const uint32_t *d_ids, uint32_t C, float *d_out, hipStream_t s);
 int kdb_launch_adj_scatter(uint32_t *d_dst, uint32_t deg, uint32_t n, const uint32_t *d_slots, const uint32_t *d_src, hipStream_t s);

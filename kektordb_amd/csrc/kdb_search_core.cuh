@@ -109,6 +109,10 @@ __device__ __forceinline__ void wave_lds_fence() {
 // distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
 // RMAX > 0 caps the rows per 16-lane group and trip (latency mode: a wave's share of a hop is at most 8 rows, and the
 // registers of a third row per group are better spent elsewhere)
+// A key that is not a number (a NaN or Inf - Inf in the query or in a row) would make every comparison of the beam false: slots
+// computed from inconsistent ranks, garbage ids, a fault.  Such a neighbour is "infinitely far" instead: never nearer than anything.
+__device__ __forceinline__ float kdb_sane_key(float key) { return key != key ? INFINITY : key; }
+
 template <int PREC, int METRIC, int NCH = 0, int RMAX = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
@@ -132,7 +136,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const float key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p[r]));
-                    if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                    if (rr[r] < n && t == 0) s.nb_d[rr[r]] = kdb_sane_key(key);
                 }
                 base += 4u * R;
             } else if (left > 4u) { // 5..8 rows: two per group
@@ -143,15 +147,15 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                                                   reinterpret_cast<const float *>(v.rows) + (size_t)id1 * v.ld, s.q, t, p0, p1);
                 const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p0));
                 const float k1 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p1));
-                if (t == 0) s.nb_d[r0] = k0;
-                if (r1 < n && t == 0) s.nb_d[r1] = k1;
+                if (t == 0) s.nb_d[r0] = kdb_sane_key(k0);
+                if (r1 < n && t == 0) s.nb_d[r1] = kdb_sane_key(k1);
                 base += 8u;
             } else { // 1..4 rows
                 const uint32_t r0 = base + (uint32_t)g;
                 const uint32_t id0 = r0 < n ? s.nb_id[r0] : 0u;
                 const float p = kdb_row_partial_f32<METRIC, NCH>(reinterpret_cast<const float *>(v.rows) + (size_t)id0 * v.ld, s.q, v.ld, t);
                 const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p));
-                if (r0 < n && t == 0) s.nb_d[r0] = k0;
+                if (r0 < n && t == 0) s.nb_d[r0] = kdb_sane_key(k0);
                 base += 4u;
             }
         }
@@ -174,7 +178,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const float key = kdb_reduce16(p[r]);
-                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = kdb_sane_key(key);
             }
         }
         wave_lds_fence();
@@ -200,7 +204,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                 uint32_t klo;
                 kdb_i8_key(dot, qnorm, v.norms[ids[r]], key, klo);
                 if (rr[r] < n && t == 0) {
-                    s.nb_d[rr[r]] = key;
+                    s.nb_d[rr[r]] = kdb_sane_key(key);
                     if (s.nb_lo) s.nb_lo[rr[r]] = klo;
                 }
             }
@@ -224,7 +228,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const float key = kdb_reduce16(p[r]);
-                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                if (rr[r] < n && t == 0) s.nb_d[rr[r]] = kdb_sane_key(key);
             }
         }
         wave_lds_fence();
@@ -250,7 +254,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                 uint32_t klo;
                 kdb_i8_key(dot, qnorm, v.norms[ids[r]], key, klo);
                 if (rr[r] < n && t == 0) {
-                    s.nb_d[rr[r]] = key;
+                    s.nb_d[rr[r]] = kdb_sane_key(key);
                     if (s.nb_lo) s.nb_lo[rr[r]] = klo;
                 }
             }
@@ -275,7 +279,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const float key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p[r]));
-                    if (rr[r] < n && t == 0) s.nb_d[rr[r]] = key;
+                    if (rr[r] < n && t == 0) s.nb_d[rr[r]] = kdb_sane_key(key);
                 }
             }
             wave_lds_fence();
@@ -303,7 +307,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
             kdb_i8_key(p, qnorm, v.norms[id], key, klo);
             if (act && t == 0 && s.nb_lo) s.nb_lo[r] = klo;
         }
-        if (act && t == 0) s.nb_d[r] = key;
+        if (act && t == 0) s.nb_d[r] = kdb_sane_key(key);
     }
     wave_lds_fence();
 }

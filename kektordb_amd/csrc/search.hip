@@ -67,7 +67,8 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
                    uint32_t k, uint32_t ef, const uint32_t *__restrict__ allow, KdbMultiAllow ma, uint32_t entry,
                    uint32_t beam_cap, uint32_t nr_cap, uint32_t vis_size, uint32_t *visited_pool, uint32_t *work,
                    unsigned long long *gctr, uint32_t *out_ids, float *out_dist, uint32_t *out_count,
-                   uint32_t *tr_ndist, uint32_t *tr_nhops, uint32_t *tie_list /* [0] count, [1] cursor of the second pass, [2..] queries */) {
+                   uint32_t *tr_ndist, uint32_t *tr_nhops, uint32_t *tie_list /* [0] count, [1] cursor of the second pass, [2] closed, [4..] queries */,
+                   unsigned char *tie_stash /* raw & 32: where the answers of queued queries go (KdbTieStash) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds s;
     size_t off = 0;
@@ -191,27 +192,50 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
             }
         }
         uint32_t nout = 0;
+        if (!failed) layer(ep, 0, ef);
+        // Equal distances met on the way (RegBeam::tied): raw & 8 -> reported in bit 31 of out_count; raw & 16 -> the query is
+        // queued for the heap-order walk (heap_walk_kernel), which replaces its answer and supplies ITS counters.
+        // raw & 32: that pass runs BESIDE this kernel (other stream, workgroups on other XCDs, each XCD with an L2 of its own): a
+        // queued query's answer must not be written to the caller's arrays by BOTH kernels -- whichever L2 writes its lines back
+        // last would win -- so this kernel puts it aside (the pass copies it back should its heaps outgrow their scratch)
+        const bool requeue = b.tied && (raw & 16u) && tie_list != nullptr;
+        const bool aside = requeue && (raw & 32u);
+        const KdbTieStash st{tie_stash, B, k};
+        uint32_t *const o_ids = aside ? st.ids(qi) : out_ids + (size_t)qi * k;
+        float *const o_dist = aside ? st.dist(qi) : out_dist + (size_t)qi * k;
+        double *const o_dist64 = aside ? st.dist64(qi) : reinterpret_cast<double *>(out_dist) + (size_t)qi * k;
         if (!failed) {
-            layer(ep, 0, ef);
             // results, ascending (:2596-2610), first k
             // raw & 4 (int8 indexes): out_dist is a double array -- the reference's float64 distances, not their float rounding
-            nout = b.write_results(k, out_ids + (size_t)qi * k, out_dist + (size_t)qi * k,
-                                   PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE,
-                                   (PREC == KDB_PREC_I8 && (raw & 4u)) ? reinterpret_cast<double *>(out_dist) + (size_t)qi * k : nullptr);
+            nout = b.write_results(k, o_ids, o_dist, PREC == KDB_PREC_F32 && METRIC == KDB_METRIC_COSINE,
+                                   (PREC == KDB_PREC_I8 && (raw & 4u)) ? o_dist64 : nullptr);
         }
         for (uint32_t p = nout + (uint32_t)lane; p < k; p += 64) {
-            out_ids[(size_t)qi * k + p] = 0u;
-            if (PREC == KDB_PREC_I8 && (raw & 4u)) reinterpret_cast<double *>(out_dist)[(size_t)qi * k + p] = (double)INFINITY;
-            else out_dist[(size_t)qi * k + p] = INFINITY;
+            o_ids[p] = 0u;
+            if (PREC == KDB_PREC_I8 && (raw & 4u)) o_dist64[p] = (double)INFINITY;
+            else o_dist[p] = INFINITY;
         }
-        // Equal distances met on the way (RegBeam::tied): raw & 8 -> reported in bit 31 of out_count; raw & 16 -> the query is
-        // queued for the heap-order walk (heap_walk_kernel, same stream), which replaces its answer and supplies ITS counters
-        const bool requeue = b.tied && (raw & 16u) && tie_list != nullptr;
         if (lane == 0) {
-            out_count[qi] = nout | ((b.tied && (raw & 8u)) ? 0x80000000u : 0u);
-            if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
-            if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
-            if (requeue) tie_list[2u + atomicAdd(tie_list, 1u)] = qi;
+            if (aside) {
+                uint32_t *const m = st.meta(qi);
+                m[0] = nout | ((raw & 8u) ? 0x80000000u : 0u);
+                m[1] = ctr.n_dist;
+                m[2] = ctr.n_hops;
+            } else {
+                out_count[qi] = nout | ((b.tied && (raw & 8u)) ? 0x80000000u : 0u);
+                if (tr_ndist) tr_ndist[qi] = ctr.n_dist;
+                if (tr_nhops) tr_nhops[qi] = ctr.n_hops;
+                if (requeue) tie_list[4u + atomicAdd(tie_list, 1u)] = qi;
+            }
+        }
+        if (aside) {
+            // the stash leaves this XCD's L2 before the entry can be seen (write-back only, nothing is invalidated under the walks
+            // still running), the entry is written where every XCD reads it, and "a returned value means the operation is done"
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) {
+                const uint32_t old = atomicExch(&tie_list[4u + atomicAdd(tie_list, 1u)], qi);
+                asm volatile("" ::"v"(old) : "memory");
+            }
         }
         if (ma.done_flags && !requeue) kdb_publish_done(ma.done_flags + qi, ma.done_gen); // (a requeued query is published by the second pass)
         tot_tied += b.tied;
@@ -238,11 +262,21 @@ hnsw_search_kernel(KdbView v, const void *__restrict__ queries, const float *__r
         const unsigned long long r4 = tot_tied ? atomicAdd(&acc[4], tot_tied) : 0ull;
         asm volatile("" ::"v"(r0), "v"(r1), "v"(r3), "v"(r4) : "memory");
         if (atomicAdd(work + 1, 1u) == gridDim.x - 1u) {
-            gctr[0] = atomicExch(&acc[0], 0ull);
-            gctr[1] = atomicExch(&acc[1], 0ull);
-            gctr[3] = atomicExch(&acc[3], 0ull);
-            gctr[2] = atomicExch(&acc[4], 0ull); // queries whose walk met equal distances
-            atomicExch(&acc[2], 0ull); // work and done
+            if (tie_list && (raw & 32u)) { // the heap-order pass is running beside this kernel and will ADD to these words once it sees `closed`
+                const unsigned long long o0 = atomicExch(&gctr[0], atomicExch(&acc[0], 0ull));
+                const unsigned long long o1 = atomicExch(&gctr[1], atomicExch(&acc[1], 0ull));
+                const unsigned long long o3 = atomicExch(&gctr[3], atomicExch(&acc[3], 0ull));
+                const unsigned long long o2 = atomicExch(&gctr[2], atomicExch(&acc[4], 0ull));
+                const unsigned long long ow = atomicExch(&acc[2], 0ull);
+                asm volatile("" ::"v"(o0), "v"(o1), "v"(o3), "v"(o2), "v"(ow) : "memory");
+                atomicExch(&tie_list[2], 1u); // closed: every workgroup has counted itself done, so [0] is final
+            } else {
+                gctr[0] = atomicExch(&acc[0], 0ull);
+                gctr[1] = atomicExch(&acc[1], 0ull);
+                gctr[3] = atomicExch(&acc[3], 0ull);
+                gctr[2] = atomicExch(&acc[4], 0ull); // queries whose walk met equal distances
+                atomicExch(&acc[2], 0ull); // work and done
+            }
         }
     }
 }
@@ -606,6 +640,43 @@ int kdb_launch_row_norms(const KdbView &v, float *d_norms, uint32_t first, uint3
     return KDB_OK;
 }
 
+// One heap-order pass BESIDE its search kernel at a time per process (launch_any below): the last such launch's closing event.
+namespace {
+std::mutex g_ov_mu;
+hipEvent_t g_ov_event = nullptr;
+hipStream_t g_ov_stream = nullptr;
+const kdb_index *g_ov_owner = nullptr;
+bool g_ov_pending = false;
+} // namespace
+static bool kdb_heap_overlap_begin(const kdb_index *idx, hipStream_t s) { // true: the turn is this launch's (until ..._launched)
+    std::lock_guard<std::mutex> lk(g_ov_mu);
+    if (g_ov_pending) return false;
+    if (g_ov_event && !(g_ov_owner == idx && g_ov_stream == s)) { // (same index and stream: ordered before this launch)
+        if (hipEventQuery(g_ov_event) != hipSuccess) {
+            (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+            return false;
+        }
+    }
+    g_ov_pending = true;
+    return true;
+}
+static void kdb_heap_overlap_launched(const kdb_index *idx, hipStream_t s, hipEvent_t ev) { // ev == nullptr: not launched after all
+    std::lock_guard<std::mutex> lk(g_ov_mu);
+    g_ov_pending = false;
+    if (!ev) return;
+    g_ov_event = ev;
+    g_ov_stream = s;
+    g_ov_owner = idx;
+}
+void kdb_heap_overlap_forget(const kdb_index *idx) { // the index is going away (its streams are idle): its events with it
+    std::lock_guard<std::mutex> lk(g_ov_mu);
+    if (g_ov_owner == idx) {
+        g_ov_event = nullptr;
+        g_ov_stream = nullptr;
+        g_ov_owner = nullptr;
+    }
+}
+
 template <int PREC, int METRIC, int NCH, int BS>
 static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B,
                             uint32_t k, uint32_t ef, const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_out_ids,
@@ -650,20 +721,72 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         uint32_t hgrid = 0;
         KdbHeapPlan hplan{};
         uint32_t *d_tie_list = nullptr;
-        unsigned char *d_tails = nullptr;
+        unsigned char *d_tails = nullptr, *d_stash = nullptr;
+        // Large batches: the heap-order pass runs BESIDE the search kernel, on the lane's side stream -- its workgroups take tied
+        // queries as the search kernel queues them (the pass used to take as long as its longest walk, 1.2 ms behind 7.7, with the
+        // chip nearly idle).  The search kernel leaves room for KDB_HEAP_OVERLAP_WG (1) of them per CU; the rest of the pass's grid
+        // moves in as search workgroups leave.  The search kernel is launched FIRST: if the two streams share a hardware queue the
+        // pass simply runs behind it, as before.  Small launches (and open ones) keep the pass behind the kernel on the same stream.
+        static const uint32_t ov_min_b = [] { const char *e = getenv("KDB_HEAP_OVERLAP_MIN_B"); return e ? (uint32_t)atoi(e) : 4096u; }();
+        static const uint32_t ov_wg = [] { const char *e = getenv("KDB_HEAP_OVERLAP_WG"); return e && atoi(e) >= 0 ? (uint32_t)atoi(e) : 1u; }();
+        bool overlap = false;
+        uint32_t raw_l = raw;
+        struct OvGuard { // (an error between the reservation and the launch gives the turn back)
+            bool armed = false;
+            ~OvGuard() { if (armed) kdb_heap_overlap_launched(nullptr, nullptr, nullptr); }
+        } ov_guard;
         if (heap_pass) {
             int rc0 = kdb_heap_walk_plan(idx, v, eff, k, B, &hplan);
             if (rc0) return rc0;
             hgrid = hplan.grid;
-            const size_t list_bytes = (((size_t)B + 2u) * 4u + 255u) & ~(size_t)255u;
-            rc0 = kdb_ensure_tie_scratch(idx, list_bytes + hplan.tail_bytes + 256u);
+            const size_t lds_room = 160u * 1024u - 2048u; // (allocation granularity)
+            if (ov_min_b && B >= ov_min_b && waves == 1u && !ma.sess_ctl && !ma.done_flags && lds + hplan.lds <= lds_room) {
+                uint32_t per_cu = grid / ncu; // grid == ncu * occupancy here (B >= 4096)
+                if (per_cu >= 2u && grid == per_cu * ncu) {
+                    while (per_cu > 1u && (size_t)per_cu * lds + (size_t)ov_wg * hplan.lds > lds_room) per_cu--;
+                    // were every workgroup of the pass resident before the first of the search kernel, one of those would still fit
+                    // on some CU: the pass waits for the search kernel, never the other way round
+                    // ... and never more than KDB_HEAP_OVERLAP_CAP (7) per CU (measured at 1637 tied of 32768: cap 7 8.94 ms, 5 9.32, 3 9.53,
+                    // 1 11.8 -- under a search kernel that saturates HBM the walks are slow, most ties are still there when it ends)
+                    static const uint32_t ov_cap = [] { const char *e = getenv("KDB_HEAP_OVERLAP_CAP"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 7u; }();
+                    uint32_t per_cu_h = (uint32_t)((lds_room - lds) / hplan.lds);
+                    if (per_cu_h > (ov_cap > ov_wg ? ov_cap : ov_wg)) per_cu_h = ov_cap > ov_wg ? ov_cap : ov_wg;
+                    const uint32_t h_cap = ncu * per_cu_h;
+                    // ONE such launch at a time per process (two passes waiting for two search kernels could hold every CU's LDS between
+                    // them): the previous one has finished, or it is ordered before this one (same stream)
+                    if (h_cap >= ncu && kdb_heap_overlap_begin(idx, s)) {
+                        overlap = true;
+                        ov_guard.armed = true;
+                        grid = per_cu * ncu;
+                        if (hgrid > h_cap) hgrid = h_cap;
+                        hplan.grid = hgrid;
+                        raw_l |= 32u;
+                    }
+                }
+            }
+            const size_t list_bytes = (((size_t)B + 4u) * 4u + 255u) & ~(size_t)255u;
+            hplan.tail_bytes = ((size_t)hplan.grid * (size_t)(hplan.cap_c - hplan.nl_c) * 12u + 255u) & ~(size_t)255u;
+            rc0 = kdb_ensure_tie_scratch(idx, list_bytes + hplan.tail_bytes + 256u + (overlap ? KdbTieStash::bytes(B, k) : 0u));
             if (rc0) return rc0;
             d_tie_list = reinterpret_cast<uint32_t *>(idx->d_tie);
             d_tails = reinterpret_cast<unsigned char *>(idx->d_tie) + list_bytes;
-            KDB_HIP(hipMemsetAsync(d_tie_list, 0, 8, s));
+            if (overlap) d_stash = d_tails + hplan.tail_bytes;
+            KDB_HIP(hipMemsetAsync(d_tie_list, 0, 16, s));
+            if (overlap) KDB_HIP(hipMemsetAsync(d_tie_list + 4, 0xff, (size_t)B * 4u, s)); // an entry is there once it is not all ones
         }
-        int rc = kdb_ensure_visited(idx, grid > hgrid ? grid : hgrid, s);
+        // (side by side, the two kernels' workgroups have visited bitsets of their own)
+        int rc = kdb_ensure_visited(idx, overlap ? grid + hgrid : (grid > hgrid ? grid : hgrid), s);
         if (rc) return rc;
+        struct kdb_lane &ln = idx->lanes[idx->cur_lane];
+        if (overlap) {
+            if (!ln.side) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                KDB_HIP(hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, hi));
+                KDB_HIP(hipEventCreateWithFlags(&ln.side_ev0, hipEventDisableTiming));
+                KDB_HIP(hipEventCreateWithFlags(&ln.side_ev1, hipEventDisableTiming));
+            }
+        }
         unsigned long long *d_ctr = kdb_stats_begin(idx, 1, B, 0);
         // the launch's accumulators {n_dist, n_hops, work | done, dropped}: zero between launches (see the kernel's end).  They
         // belong to the call's SCRATCH LANE (words 32..41 of its d_work), not to the statistics ring: two launches that share
@@ -671,14 +794,32 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // finds the words of another one that is still running -- whatever the number of launches in flight on other streams
         unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(idx->d_work + 32);
         if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev0, s));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
+        if (overlap) { // everything queued on s so far (prepared queries, the armed list) is done before the pass starts
+            KDB_HIP(hipEventRecord(ln.side_ev0, s));
+            KDB_HIP(hipStreamWaitEvent(ln.side, ln.side_ev0, 0));
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * waves), lds, s, v, d_q, d_qnorm, raw_l, B, k, eff, d_allow, ma, entry, beam_cap, nr_cap, vis_size,
                            idx->d_visited, reinterpret_cast<uint32_t *>(d_acc + 2), d_ctr, d_out_ids, d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops,
-                           d_tie_list);
+                           d_tie_list, d_stash);
         KDB_HIP(hipGetLastError());
         if (heap_pass) { // (its workgroups return at once when the search kernel queued nothing; the closing event covers both passes:
             // the second one adds its counters to the slot the first one published)
-            rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, hplan, d_ctr, d_out_ids,
-                                      d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s);
+            rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw_l, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, hplan, d_ctr, d_out_ids,
+                                      d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, overlap ? ln.side : s, overlap ? grid : 0u, d_stash, overlap ? 1u : 0u);
+            if (overlap) { // s carries on when the pass is done (the search kernel closes the list as it ends, whatever happened here)
+                if (rc == KDB_OK && hipEventRecord(ln.side_ev1, ln.side) != hipSuccess) rc = KDB_ERR_HIP;
+                if (hipStreamWaitEvent(s, ln.side_ev1, 0) != hipSuccess && rc == KDB_OK) rc = KDB_ERR_HIP;
+                kdb_heap_overlap_launched(idx, s, ln.side_ev1);
+                ov_guard.armed = false;
+                // the sweep: entries the pass did not walk (none, unless its workgroups gave up waiting) -- workgroups that find
+                // every entry marked return at once
+                if (rc == KDB_OK) {
+                    KdbHeapPlan sweep = hplan; // (one workgroup per CU: enough for what is never there)
+                    if (sweep.grid > ncu) sweep.grid = ncu;
+                    rc = kdb_launch_heap_walk(idx, v, d_q, d_qnorm, raw_l, B, k, eff, d_allow, ma, entry, d_tie_list, d_tails, sweep, d_ctr, d_out_ids,
+                                              d_out_dist, d_out_count, d_tr_ndist, d_tr_nhops, s, grid, d_stash, 2u);
+                }
+            }
             if (rc) return rc;
         }
         if (idx->time_launches) KDB_HIP(hipEventRecord(idx->ev1, s));

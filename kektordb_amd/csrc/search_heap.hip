@@ -322,7 +322,9 @@ struct HeapArgs {
     const uint32_t *allow;
     KdbMultiAllow ma;
     uint32_t entry;
-    uint32_t *tie_list;     // [0] count, [1] cursor, [2..] query indices
+    uint32_t *tie_list;     // [0] count, [1] cursor, [2] closed (pass beside the search kernel), [3] cursor of the sweep, [4..] query indices
+    uint32_t mode;          // 0: behind the search kernel (same stream); 1: beside it; 2: the sweep behind a pass that ran beside it
+    unsigned char *stash;   // pass beside the search kernel: the fast walk's answers of the queued queries (KdbTieStash)
     uint32_t *visited_pool; // one bitset per workgroup
     uint32_t hsize;         // words of the LDS visited hash (0: the HBM bitset alone)
     uint32_t nl_c;          // candidate-heap entries kept in LDS
@@ -450,16 +452,82 @@ __device__ uint32_t heap_layer(const KdbView &v, const WaveLds &s, VisT &vis, Re
     return count;
 }
 
+// Ticket w of a list the search kernel is still filling: the query index once entry w is there, 0xffffffff when the list is closed
+// below w, 0xfffffffe after a second without either.  Wave-uniform.  Every word is read with a read-modify-write (add 0): those
+// are performed where all XCDs agree; an atomic LOAD may be answered by this XCD's L2 from a line it kept from an earlier launch
+// (measured: passes that saw the previous launch's `closed` and left at once).
+__device__ __forceinline__ uint32_t heap_rmw_read(uint32_t *p) { return atomicAdd(p, 0u); }
+__device__ __forceinline__ uint32_t heap_wait_ticket(uint32_t *tie_list, uint32_t w) {
+    const unsigned long long t0 = wall_clock64(); // 100 MHz
+    uint32_t r = 0xfffffffeu;
+    if (kdb_lane() == 0) {
+        for (;;) {
+            const uint32_t closed = heap_rmw_read(tie_list + 2);
+            asm volatile("" ::"v"(closed) : "memory"); // (closed is read BEFORE the count it makes final)
+            const uint32_t cnt = heap_rmw_read(tie_list);
+            if (w < cnt) {
+                uint32_t e;
+                do e = heap_rmw_read(tie_list + 4u + w);
+                while (e == 0xffffffffu && wall_clock64() - t0 < 100000000ull);
+                r = e == 0xffffffffu ? 0xfffffffeu : e;
+                break;
+            }
+            if (closed) {
+                r = 0xffffffffu;
+                break;
+            }
+            if (wall_clock64() - t0 > 100000000ull) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)r, 0, 64));
+}
+
+// The fast walk's answer of a query the pass could not resolve, from where the search kernel put it aside: read where every XCD
+// agrees on it, written here -- by the only writer of these words.  (A call: a rare path that must not cost the walk registers.)
+__device__ __noinline__ void heap_restore_stashed(unsigned char *stash, uint32_t B, uint32_t k, uint32_t qi, bool f64, uint32_t *out_ids, float *out_dist,
+                                                  uint32_t *out_count, uint32_t *tr_ndist, uint32_t *tr_nhops) {
+    const KdbTieStash st{stash, B, k};
+    auto ld = [](const uint32_t *p) { return heap_rmw_read(const_cast<uint32_t *>(p)); };
+    const int lane = kdb_lane();
+    for (uint32_t p = (uint32_t)lane; p < k; p += 64) {
+        out_ids[(size_t)qi * k + p] = ld(st.ids(qi) + p);
+        if (f64) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(st.dist64(qi) + p);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(out_dist) + (size_t)qi * k + p);
+            dst[0] = ld(src);
+            dst[1] = ld(src + 1);
+        } else {
+            reinterpret_cast<uint32_t *>(out_dist)[(size_t)qi * k + p] = ld(reinterpret_cast<const uint32_t *>(st.dist(qi) + p));
+        }
+    }
+    if (lane == 0) {
+        const uint32_t *m = st.meta(qi);
+        out_count[qi] = ld(m);
+        if (tr_ndist) tr_ndist[qi] = ld(m + 1);
+        if (tr_nhops) tr_nhops[qi] = ld(m + 2);
+    }
+}
+
 // VIS = 1: visited set in LDS (the fast walk's exact hash, migrating to the wave's HBM bitset if it fills); 0: the HBM bitset
 // RES = 1: the result heap in registers (ef + 2 <= 64), 0: in LDS
-template <int PREC, int METRIC, int NCH, int VIS, int RES>
-__global__ void __launch_bounds__(64)
+// OV = 0: the pass BEHIND the search kernel (a.mode 0); 1: beside it, and the sweep behind that (a.mode 1, 2, 3) -- kernels of their
+// own, so that the waiting, the marks and the stash cost the ordinary pass nothing (in one kernel: 254 -> 256 + 2 registers, one
+// wave per SIMD instead of two, 9.05 -> 9.48 ms)
+template <int PREC, int METRIC, int NCH, int VIS, int RES, int OV>
+__global__ void __launch_bounds__(64, OV ? 2 : 1) // OV: two waves per SIMD = eight per CU whatever the calls below need
 heap_walk_kernel(KdbView v, HeapArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using RK = RefKey<PREC, METRIC>;
     constexpr bool WK = RK::WK;
-    const uint32_t n_tied = a.tie_list[0]; // written by the search kernel before this one started (same stream)
-    if (blockIdx.x >= n_tied) return;
+    // beside == false: the search kernel finished before this one started (same stream) -- [0] is final.  beside == true: it is
+    // still running (other stream): tickets are waited for, the list is final once [2] says closed
+    // mode 2, the sweep: what a pass beside the kernel left behind -- nothing, unless its workgroups gave up waiting (another process's
+    // kernels kept the search kernel off the CUs for a second): every entry without the `walked` bit is walked now
+    if (OV && a.mode == 3u) return; // test hook (KDB_HEAP_OVERLAP_GIVE_UP): the pass walks nothing, the sweep everything
+    const bool beside = OV && a.mode == 1u, sweep = OV && a.mode == 2u;
+    const uint32_t n_tied = beside ? 0u : sweep ? heap_rmw_read(a.tie_list) : a.tie_list[0];
+    if (!beside && blockIdx.x >= n_tied) return;
     WaveLds s{};
     size_t off = 0;
     s.q = reinterpret_cast<float *>(smem + off);
@@ -523,10 +591,24 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
     unsigned long long tot_dist = 0, tot_hops = 0, unresolved = 0;
     for (;;) {
         uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(a.tie_list + 1, 1u);
+        if (lane == 0) w = atomicAdd(a.tie_list + (sweep ? 3 : 1), 1u);
         w = uni((uint32_t)__shfl((int)w, 0, 64));
-        if (w >= n_tied) break;
-        const uint32_t qi = a.tie_list[2u + w];
+        uint32_t qi;
+        if (OV && beside) {
+            if constexpr (OV) qi = heap_wait_ticket(a.tie_list, w);
+            else qi = 0xffffffffu;
+            if (qi >= 0xfffffffeu) break; // closed below w -- or a second without news: the sweep behind this pass walks what is left
+        } else if (sweep) {
+            if (w >= n_tied) break;
+            uint32_t e = 0;
+            if (lane == 0) e = heap_rmw_read(a.tie_list + 4u + w);
+            e = uni((uint32_t)__shfl((int)e, 0, 64));
+            if (e & 0x80000000u) continue; // walked by the pass
+            qi = e;
+        } else {
+            if (w >= n_tied) break;
+            qi = a.tie_list[4u + w];
+        }
         vis.begin_query();
         const float qnorm = kdb_load_query<PREC>(v, s, a.queries, a.qnorms, a.raw, qi);
         const uint32_t *q_allow = a.allow;
@@ -555,8 +637,11 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
         }
         if (over) { // the candidate heap outgrew its scratch: the fast walk's answer stays, the tie stays reported
             unresolved++;
-            if (lane == 0 && (a.raw & 8u)) a.out_count[qi] |= 0x80000000u;
+            if (OV && (beside || sweep)) { // ... the search kernel put it aside (KdbTieStash)
+                if constexpr (OV) heap_restore_stashed(a.stash, a.B, a.k, qi, WK && (a.raw & 4u), a.out_ids, a.out_dist, a.out_count, a.tr_ndist, a.tr_nhops);
+            } else if (lane == 0 && (a.raw & 8u)) a.out_count[qi] |= 0x80000000u;
             if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
+            if (beside && lane == 0) atomicOr(a.tie_list + 4u + w, 0x80000000u);
             continue;
         }
         for (uint32_t p = (uint32_t)lane; p < a.k; p += 64) {
@@ -577,6 +662,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
             if (a.tr_nhops) a.tr_nhops[qi] = ctr.n_hops;
         }
         if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
+        if (beside && lane == 0) atomicOr(a.tie_list + 4u + w, 0x80000000u); // walked
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         wave_lds_fence();
@@ -610,8 +696,9 @@ int heap_occupancy(K kern, size_t lds) { // resident workgroups per CU: asked on
 
 // the kernel for an index: row width unrolled where the fast walk unrolls it (the same device functions: the same distance bits)
 template <typename F>
-int heap_dispatch(const KdbView &v, bool hash, bool reg, F f) {
-#define KDB_HW(P, M, N) (hash ? (reg ? f(heap_walk_kernel<P, M, N, 1, 1>) : f(heap_walk_kernel<P, M, N, 1, 0>)) : f(heap_walk_kernel<P, M, N, 0, 0>))
+int heap_dispatch(const KdbView &v, bool hash, bool reg, bool ov, F f) {
+#define KDB_HW(P, M, N) (ov ? KDB_HW1(P, M, N, 1) : KDB_HW1(P, M, N, 0))
+#define KDB_HW1(P, M, N, O) (hash ? (reg ? f(heap_walk_kernel<P, M, N, 1, 1, O>) : f(heap_walk_kernel<P, M, N, 1, 0, O>)) : f(heap_walk_kernel<P, M, N, 0, 0, O>))
     if (v.precision == KDB_PREC_I8) return KDB_HW(KDB_PREC_I8, KDB_METRIC_COSINE, 0);
     if (v.precision == KDB_PREC_F16) return KDB_HW(KDB_PREC_F16, KDB_METRIC_L2, 0);
     if (v.metric == KDB_METRIC_COSINE) {
@@ -623,6 +710,7 @@ int heap_dispatch(const KdbView &v, bool hash, bool reg, F f) {
     if (v.ld == 1536) return KDB_HW(KDB_PREC_F32, KDB_METRIC_L2, 24);
     return KDB_HW(KDB_PREC_F32, KDB_METRIC_L2, 0);
 #undef KDB_HW
+#undef KDB_HW1
 }
 } // namespace
 
@@ -667,7 +755,7 @@ int kdb_heap_walk_plan(kdb_index *idx, const KdbView &v, uint32_t ef, uint32_t k
         kdb_set_error("heap-order walk: ef=%u needs %zu bytes of LDS per wave (limit 160 KiB)", eff, p.lds);
         return KDB_ERR_UNSUPPORTED;
     }
-    const int occ = heap_dispatch(v, p.hsize != 0, p.reg_results != 0, [&](auto kern) { return heap_occupancy(kern, p.lds); });
+    const int occ = heap_dispatch(v, p.hsize != 0, p.reg_results != 0, false, [&](auto kern) { return heap_occupancy(kern, p.lds); });
     const uint32_t room = (uint32_t)idx->n_cu * (uint32_t)(occ < 1 ? 1 : occ);
     p.grid = B < room ? B : room;
     p.tail_bytes = (size_t)p.grid * (size_t)(p.cap_c - p.nl_c) * 12u;
@@ -678,7 +766,7 @@ int kdb_heap_walk_plan(kdb_index *idx, const KdbView &v, uint32_t ef, uint32_t k
 int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, const float *d_qnorm, uint32_t raw, uint32_t B, uint32_t k, uint32_t ef,
                          const uint32_t *d_allow, KdbMultiAllow ma, uint32_t entry, uint32_t *d_tie_list, unsigned char *d_tails, const KdbHeapPlan &plan,
                          unsigned long long *d_ctr, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
-                         uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s) {
+                         uint32_t *d_tr_ndist, uint32_t *d_tr_nhops, hipStream_t s, uint32_t vis_first, unsigned char *d_stash, uint32_t mode) {
     const uint32_t eff = ef < k ? k : ef;
     HeapArgs a{};
     a.queries = d_q;
@@ -691,7 +779,13 @@ int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, cons
     a.ma = ma;
     a.entry = entry;
     a.tie_list = d_tie_list;
-    a.visited_pool = idx->d_visited;
+    a.stash = d_stash;
+    a.mode = mode;
+    if (mode == 1u) {
+        static const bool give_up = getenv("KDB_HEAP_OVERLAP_GIVE_UP") != nullptr;
+        if (give_up) a.mode = 3u;
+    }
+    a.visited_pool = idx->d_visited + (size_t)vis_first * v.vis_words;
     a.hsize = plan.hsize;
     a.nl_c = plan.nl_c;
     a.cap_c = plan.cap_c;
@@ -702,7 +796,7 @@ int kdb_launch_heap_walk(kdb_index *idx, const KdbView &v, const void *d_q, cons
     a.out_count = d_out_count;
     a.tr_ndist = d_tr_ndist;
     a.tr_nhops = d_tr_nhops;
-    return heap_dispatch(v, plan.hsize != 0, plan.reg_results != 0, [&](auto kern) -> int {
+    return heap_dispatch(v, plan.hsize != 0, plan.reg_results != 0, mode != 0u, [&](auto kern) -> int {
         if (plan.lds > 64 * 1024) KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
         hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(64), plan.lds, s, v, a);
         KDB_HIP(hipGetLastError());

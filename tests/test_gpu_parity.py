@@ -1378,6 +1378,27 @@ def test_tied_walks_with_deleted_nodes_filters_and_int8(oracle, hip):
                     assert c == len(oi) and np.array_equal(ids[b, :c], oi), (prec, metric, ef, b, ids[b, :c], oi)
                     assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (prec, metric, ef, b)
                     assert (int(nd[b]), int(nh[b])) == (ond, onh), (prec, metric, ef, b)
+                if ef != 70:
+                    continue
+                # 4800 queries: the heap-order pass runs BESIDE the search kernel (other stream, tickets taken while the list
+                # fills -- search.hip launch_any): the same answers and counters, query for query, and the same totals
+                c0 = idx.counters()
+                assert (c0["n_dist"], c0["n_hops"]) == (int(nd.sum()), int(nh.sum())), (prec, metric, c0)
+                Qr = np.tile(Q, (200, 1))
+                ids2, dist2, cnt2, (nd2, nh2) = idx.search_batch(Qr, k, ef, allow_bits=ab, trace=True, tie_flag=True, heap_order=True,
+                                                                 dist64=(prec == O.I8))
+                c2 = idx.counters()
+                assert np.array_equal(ids2, np.tile(ids, (200, 1))) and np.array_equal(cnt2, np.tile(cnt, 200)), (prec, metric)
+                assert np.array_equal(dist2.view(np.uint8), np.tile(dist, (200, 1)).view(np.uint8)), (prec, metric)
+                assert np.array_equal(nd2, np.tile(nd, 200)) and np.array_equal(nh2, np.tile(nh, 200)), (prec, metric)
+                assert (c2["n_dist"], c2["n_hops"], c2["n_tied"]) == (200 * c0["n_dist"], 200 * c0["n_hops"], 200 * c0["n_tied"]), (c0, c2)
+                assert c0["n_tied"] > 0
+                # ... and untraced, 9600 queries: chunks of 4096 that alternate between two streams, each with its pass beside it
+                ids3, dist3, cnt3 = idx.search_batch(np.tile(Q, (400, 1)), k, ef, allow_bits=ab, tie_flag=True, heap_order=True, dist64=(prec == O.I8))
+                bad = np.nonzero((ids3 != np.tile(ids, (400, 1))).any(axis=1) | (cnt3 != np.tile(cnt, 400)))[0]
+                assert bad.size == 0, (prec, metric, bad.size, bad[:12].tolist(), sorted(set((bad % 24).tolist())), [hex(int(x)) for x in cnt3[bad[:4]]],
+                                       ids3[bad[0]].tolist(), ids[bad[0] % 24].tolist(), np.bincount(bad // 512, minlength=19).tolist())
+                assert np.array_equal(dist3.view(np.uint8), np.tile(dist, (400, 1)).view(np.uint8)), (prec, metric)
 
 
 def test_dropped_candidates_are_reported(oracle, hip):
@@ -1529,3 +1550,69 @@ def test_tiny_negative_dots_that_collide_as_float64(oracle, hip):
         assert np.array_equal(ids[b, :c], oi), (b, np.nonzero(ids[b, :c] != oi)[0][:4])
         assert np.array_equal(raw_to_score(idx, dist[b, :c]), od)
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1), (1, 2)])
+def test_non_finite_queries_and_rows_do_not_fault(oracle, hip, metric, prec):
+    """A NaN or an infinity in a query (a client's bug, one request of many in a batch) or in a stored row must not take the process
+    down.  The reference compares such distances like any other (every comparison with a NaN is false, hnsw_heap.go:53-82) and
+    returns whatever its heaps then hold -- nothing to be bit-exact with.  Here a distance that is not a number is "infinitely far"
+    (kdb_sane_key): round 5 found that a NaN key made the beam's rank computations inconsistent, the walk followed a garbage id
+    and the GPU faulted -- for every caller of the process.  Asserted: no fault; every returned id names a row; the FINITE
+    queries of the batch get exactly the answers they get alone; graph walk (one-wave and four-wave kernels, heap order or not),
+    exact scan, and the builder on a corpus of NaN rows."""
+    O = oracle
+    rng = np.random.default_rng(91)
+    n, dim, k = 3000, 40, 10
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[rng.choice(n, 40, replace=False)] = X[7]        # some ties: the heap-order pass runs too
+    orc, idx = build_pair(O, hip, X, metric, precision=prec, efc=60)
+    Q = rng.standard_normal((12, dim)).astype(np.float32)
+    bad = Q.copy()
+    bad[1, 0] = np.nan
+    bad[3] = np.inf
+    bad[5] = np.nan
+    bad[7, 2] = -np.inf
+    bad[9] = 3e38                                       # finite, but every squared difference overflows
+    fine = [b for b in range(Q.shape[0]) if b not in (1, 3, 5, 7, 9)]
+    d64 = prec == O.I8
+    for reps in (1, 100):                               # 12 queries: four waves per query; 1200: one
+        Qb = np.tile(bad, (reps, 1))
+        for kw in ({}, {"heap_order": True, "tie_flag": True}):
+            for ef in (30, 300):
+                want = idx.search_batch(Q, k, ef, dist64=d64, **kw)
+                ids, dist, cnt = idx.search_batch(Qb, k, ef, dist64=d64, **kw)
+                c = cnt & hip.index.COUNT_MASK
+                assert np.all(c <= k) and np.all(ids <= n)
+                for b in range(Qb.shape[0]):
+                    assert np.all(ids[b, :int(c[b])] >= 1) and np.all(ids[b, int(c[b]):] == 0), (metric, prec, ef, b)
+                    if b % 12 in fine:
+                        assert c[b] == want[2][b % 12] & hip.index.COUNT_MASK and np.array_equal(ids[b], want[0][b % 12]), (metric, prec, ef, b)
+                        assert np.array_equal(dist[b].view(np.uint8), want[1][b % 12].view(np.uint8)), (metric, prec, ef, b)
+        fi, fd, fc = idx.flat_scan_batch(Qb, k, dist64=d64)
+        wf = idx.flat_scan_batch(Q, k, dist64=d64)
+        assert np.all(fi <= n)
+        for b in range(Qb.shape[0]):
+            if b % 12 in fine:
+                assert np.array_equal(fi[b], wf[0][b % 12]) and np.array_equal(fd[b].view(np.uint8), wf[1][b % 12].view(np.uint8)), (metric, prec, b)
+    # rows that are not numbers: the builder and the walk over them end (what they return is not asserted: the rows say nothing)
+    if prec != O.I8:
+        Xn = X.copy() if prec == O.F32 else X.astype(np.float16).view(np.uint16).copy()
+        if prec == O.F32:
+            Xn[::3] = np.nan
+            Xn[1::7] = np.inf
+        else:
+            Xn[::3] = 0x7e00
+            Xn[1::7] = 0x7c00
+        g = hip.HipIndex(dim, metric, prec, 16, 40, capacity=n + 8)
+        g.upload_rows(Xn, 1)
+        g.build(n, batch=512, ef_construction=40, seed=3)
+        for ef in (30, 300):
+            ids, dist, cnt = g.search_batch(bad, k, ef, heap_order=True)
+            assert np.all(cnt <= k) and np.all(ids <= n)
+        allnan = hip.HipIndex(dim, metric, prec, 16, 40, capacity=n + 8)
+        allnan.upload_rows(np.full((n, dim), np.nan, np.float32) if prec == O.F32 else np.full((n, dim), 0x7e00, np.uint16), 1)
+        allnan.build(n, batch=512, ef_construction=40, seed=3)
+        ids, dist, cnt = allnan.search_batch(Q, k, 50)
+        assert np.all(cnt <= k) and np.all(ids <= n)
