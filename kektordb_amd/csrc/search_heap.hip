@@ -322,7 +322,7 @@ struct HeapArgs {
     const uint32_t *allow;
     KdbMultiAllow ma;
     uint32_t entry;
-    uint32_t *tie_list;     // [0] count, [1] cursor, [2] closed (pass beside the search kernel), [3] cursor of the sweep, [4..] query indices
+    uint32_t *tie_list;     // [0] count, [1] cursor, [2] closed (pass beside the search kernel), [3] entries the pass has walked, [4..] query indices
     uint32_t mode;          // 0: behind the search kernel (same stream); 1: beside it; 2: the sweep behind a pass that ran beside it
     unsigned char *stash;   // pass beside the search kernel: the fast walk's answers of the queued queries (KdbTieStash)
     uint32_t *visited_pool; // one bitset per workgroup
@@ -528,6 +528,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
     const bool beside = OV && a.mode == 1u, sweep = OV && a.mode == 2u;
     const uint32_t n_tied = beside ? 0u : sweep ? heap_rmw_read(a.tie_list) : a.tie_list[0];
     if (!beside && blockIdx.x >= n_tied) return;
+    if (sweep && heap_rmw_read(a.tie_list + 3) == n_tied) return; // the pass walked every entry (it counts them in [3]): the usual case, 3 us
     WaveLds s{};
     size_t off = 0;
     s.q = reinterpret_cast<float *>(smem + off);
@@ -591,7 +592,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
     unsigned long long tot_dist = 0, tot_hops = 0, unresolved = 0;
     for (;;) {
         uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(a.tie_list + (sweep ? 3 : 1), 1u);
+        if (lane == 0) w = sweep ? atomicAdd(a.tie_list + 2, 1u) - 1u : atomicAdd(a.tie_list + 1, 1u); // (the sweep counts on from closed == 1)
         w = uni((uint32_t)__shfl((int)w, 0, 64));
         uint32_t qi;
         if (OV && beside) {
@@ -641,7 +642,10 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
                 if constexpr (OV) heap_restore_stashed(a.stash, a.B, a.k, qi, WK && (a.raw & 4u), a.out_ids, a.out_dist, a.out_count, a.tr_ndist, a.tr_nhops);
             } else if (lane == 0 && (a.raw & 8u)) a.out_count[qi] |= 0x80000000u;
             if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
-            if (beside && lane == 0) atomicOr(a.tie_list + 4u + w, 0x80000000u);
+            if (beside && lane == 0) {
+                atomicOr(a.tie_list + 4u + w, 0x80000000u);
+                atomicAdd(a.tie_list + 3, 1u);
+            }
             continue;
         }
         for (uint32_t p = (uint32_t)lane; p < a.k; p += 64) {
@@ -662,7 +666,10 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
             if (a.tr_nhops) a.tr_nhops[qi] = ctr.n_hops;
         }
         if (a.ma.done_flags) kdb_publish_done(a.ma.done_flags + qi, a.ma.done_gen);
-        if (beside && lane == 0) atomicOr(a.tie_list + 4u + w, 0x80000000u); // walked
+        if (beside && lane == 0) { // walked
+            atomicOr(a.tie_list + 4u + w, 0x80000000u);
+            atomicAdd(a.tie_list + 3, 1u);
+        }
         tot_dist += ctr.n_dist;
         tot_hops += ctr.n_hops;
         wave_lds_fence();

@@ -1616,3 +1616,35 @@ def test_non_finite_queries_and_rows_do_not_fault(oracle, hip, metric, prec):
         allnan.build(n, batch=512, ef_construction=40, seed=3)
         ids, dist, cnt = allnan.search_batch(Q, k, 50)
         assert np.all(cnt <= k) and np.all(ids <= n)
+
+
+@pytest.mark.gpu
+def test_heap_order_sweep_walks_what_the_pass_beside_the_kernel_left(hip):
+    """The pass beside the search kernel gives up when it hears nothing for a second (another process's kernels keep the search
+    kernel off the CUs); the sweep behind the join then walks every entry the pass did not mark.  KDB_HEAP_OVERLAP_GIVE_UP (read
+    once per process, hence the child process) makes the pass walk nothing: 4800 queries with ties must get, from the sweep alone,
+    the answers the same queries get 24 at a time (pass behind the kernel, the path every other test pins to the oracle)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, kektordb_amd as hip
+        rng = np.random.default_rng(5)
+        n, dim, k, ef = 3000, 32, 10, 70
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        for _ in range(6):
+            X[rng.choice(n, 30, replace=False)] = X[int(rng.integers(0, n))]
+        idx = hip.HipIndex(dim, 0, 0, 16, 40, capacity=n + 8)
+        idx.upload_rows(X, 1)
+        idx.build(n, batch=512, ef_construction=40, seed=3)
+        Q = (X[rng.integers(0, n, 24)] + 0.01 * rng.standard_normal((24, dim))).astype(np.float32)
+        ids, dist, cnt = idx.search_batch(Q, k, ef, tie_flag=True, heap_order=True)
+        assert idx.counters()["n_tied"] > 0
+        for reps in (200, 800):
+            i2, d2, c2 = idx.search_batch(np.tile(Q, (reps, 1)), k, ef, tie_flag=True, heap_order=True)
+            assert np.array_equal(i2, np.tile(ids, (reps, 1))) and np.array_equal(c2, np.tile(cnt, reps))
+            assert np.array_equal(d2.view(np.uint8), np.tile(dist, (reps, 1)).view(np.uint8))
+        print("sweep ok")
+    """)
+    env = dict(os.environ, KDB_HEAP_OVERLAP_GIVE_UP="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "sweep ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
