@@ -8,6 +8,8 @@ Bars:  * traversal / index / counter work is BIT-EXACT against the oracle run wi
          distances agree within 1e-4 relative (+1e-6 absolute, the reference's own test tolerance,
          distance_test.go:26-29) and ids agree except where two distances tie within that tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
