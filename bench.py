@@ -876,7 +876,12 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
         except Exception:
             ncpu = 0
         out["caller_threads_pinned_to_cpus"] = ncpu  # (= the cgroup's CPU quota; 0 = not pinned) -- see scripts/micro_batcher_leg.cpp
-        for T, win in ((1, -1), (16, -1), (32, -1), (64, -1), (256, -1), (64, 0), (256, 0)):
+        # (T, window, heap order): the last three with KDB_SEARCH_HEAP_ORDER, the flag the shim and kektor::hnsw::Index set on every call
+        for T, win, ho in ((1, -1, 0), (16, -1, 0), (32, -1, 0), (64, -1, 0), (256, -1, 0), (64, 0, 0), (256, 0, 0), (1, -1, 1), (64, -1, 1), (256, -1, 1)):
+            if ho:
+                os.environ["KDB_LEG_HEAP_ORDER"] = "1"
+            else:
+                os.environ.pop("KDB_LEG_HEAP_ORDER", None)
             lat = np.zeros(T * per, dtype=np.float64)
             phases = np.zeros(8, dtype=np.float64)
             wall, nb, lg, ans = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -885,7 +890,7 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
                                                ncpu, phases.ctypes.data_as(C.c_void_p))
             assert rc == 0
             lat = lat.reshape(T, per)[:, per // 10:]   # (the first tenth of every caller's calls: start-up)
-            name = f"{T}_callers_" + ("direct_one_query_calls" if win < 0 else "through_the_batcher")
+            name = f"{T}_callers_" + ("direct_one_query_calls" if win < 0 else "through_the_batcher") + ("_heap_order_flag" if ho else "")
             out[name] = {"qps": round(T * per / wall.value, 1), "per_caller_p50_ms": round(float(np.percentile(lat, 50)) / 1e3, 4),
                          "per_caller_p99_ms": round(float(np.percentile(lat, 99)) / 1e3, 4), "gpu_calls": int(nb.value),
                          "largest_batch": int(lg.value), "answers_per_call": round(ans.value / (T * per), 2)}
@@ -893,6 +898,7 @@ def micro_batcher_leg(idx, Q, k, ef, per=150):
                 out[name]["combined_call_us"] = {"waiting_for_launch": round(float(phases[0]), 1), "launch_to_own_answer": round(float(phases[1]), 1),
                                                  "a_thread_launching_a_group": round(float(phases[2]), 1), "naps_per_call": round(float(phases[3]), 2)}
     finally:
+        os.environ.pop("KDB_LEG_HEAP_ORDER", None)
         idx.set_launch_timing(True)
         try:
             os.unlink(so)

@@ -1258,12 +1258,21 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
     static const uint64_t nap_div = [] { const char *e = getenv("KDB_NAP_DIV"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 10ull; }();
     static const uint64_t nap_min = [] { const char *e = getenv("KDB_NAP_MIN_NS"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 15000ull; }();
     const uint64_t nap_ns = est0 / nap_div < nap_min ? nap_min : est0 / nap_div > 150000ull ? 150000ull : est0 / nap_div;
+    const uint64_t sess_ns = (uint64_t)session_us() * 1000ull;
     for (;;) {
         if (ready()) break;
         if (g->failed.load(std::memory_order_acquire)) {
             rc = g->rc ? g->rc : KDB_ERR_HIP;
             kdb_set_error("%s", g->err);
             break;
+        }
+        // An open launch is closed by whoever notices that its window has passed -- the next caller, or a member that is still
+        // waiting: a query that met equal distances (KDB_SEARCH_HEAP_ORDER) is answered by the pass BEHIND the search kernel, which
+        // ends only when the launch is closed; with nobody else calling, its own watcher must do it (it used to wait out the
+        // workgroups' 0.5 s safety: one lone call in thirty took half a second with the flag the mirrors set)
+        if (__atomic_load_n(&g->open, __ATOMIC_RELAXED) && g->launched.load(std::memory_order_acquire) && now_ns() - g->t_launch_ns > sess_ns) {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            if (idx->open_session == g) kdb_close_session(idx);
         }
         const uint64_t el = now_ns() - t0;
         if (spin && el < 2000000ull) {

@@ -7,6 +7,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -18,7 +19,11 @@ namespace {
 // what BasicMicroBatcher needs of an index, over a handle somebody else owns
 class BorrowedIndex {
   public:
-    BorrowedIndex(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {}
+    BorrowedIndex(kdb_index *h, uint32_t dim, uint32_t metric, uint32_t precision) : h_(h), dim_(dim), metric_(metric), precision_(precision) {
+        // KDB_LEG_HEAP_ORDER: the flag the shim and kektor::hnsw::Index set (queries that meet equal distances are walked again in
+        // the reference's heap order): a memset and a second, usually empty, kernel behind every launch
+        flags_ = getenv("KDB_LEG_HEAP_ORDER") ? (uint32_t)KDB_SEARCH_HEAP_ORDER : 0u;
+    }
     uint32_t Dim() const { return dim_; }
     bool CombinesConcurrentCalls() const { return true; } // (as kektor::hnsw::Index)
     uint32_t Count() const {
@@ -31,7 +36,7 @@ class BorrowedIndex {
         std::vector<std::vector<kektor::SearchResult>> out(B);
         std::vector<uint32_t> ids((size_t)B * k), cnt(B);
         std::vector<float> dist((size_t)B * k);
-        if (kdb_search_batch(h_, queries, B, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0), allowList ? allowList->words.data() : nullptr, 0u, ids.data(),
+        if (kdb_search_batch(h_, queries, B, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0), allowList ? allowList->words.data() : nullptr, flags_, ids.data(),
                              dist.data(), cnt.data()))
             return out;
         const bool cos = metric_ == KDB_METRIC_COSINE && precision_ == KDB_PREC_F32;
@@ -52,7 +57,7 @@ class BorrowedIndex {
 
   private:
     kdb_index *h_;
-    uint32_t dim_, metric_, precision_;
+    uint32_t dim_, metric_, precision_, flags_ = 0;
 };
 
 } // namespace

@@ -1650,3 +1650,33 @@ def test_heap_order_sweep_walks_what_the_pass_beside_the_kernel_left(hip):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "sweep ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_lone_heap_order_call_with_a_tie_does_not_wait_for_the_launch_to_time_out(hip):
+    """A one-query call leaves in an OPEN launch (its kernel keeps accepting callers for KDB_SESSION_US); a query that meets equal
+    distances is answered by the heap-order pass BEHIND that kernel, which ends only when the launch is closed -- by the next
+    caller, or, when nobody else calls, by the waiting caller's own watcher.  Round 5 first shipped without the latter: one lone
+    call in thirty (the tied ones) waited out the workgroups' 0.5 s safety.  Every call here must return within 50 ms."""
+    import time
+    rng = np.random.default_rng(3)
+    n, dim, k, ef = 4000, 48, 10, 40
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    for _ in range(20):
+        X[rng.choice(n, 20, replace=False)] = X[int(rng.integers(0, n))]
+    idx = hip.HipIndex(dim, 0, 0, 16, 60, capacity=n + 8)
+    idx.upload_rows(X, 1)
+    idx.build(n, batch=512, ef_construction=60, seed=3)
+    Q = (X[rng.integers(0, n, 256)] + 0.001 * rng.standard_normal((256, dim))).astype(np.float32)
+    want = idx.search_batch(Q, k, ef, heap_order=True)
+    flagged = idx.search_batch(Q, k, ef, tie_flag=True)[2]
+    tied = np.nonzero(flagged & hip.index.COUNT_TIED)[0]
+    assert tied.size >= 4, "the corpus produced no tied query: the case tests nothing"
+    worst = 0.0
+    for b in list(tied[:24]) + [int(x) for x in range(8)]:
+        t0 = time.perf_counter()
+        got = idx.search_batch(Q[b:b + 1], k, ef, heap_order=True)
+        worst = max(worst, time.perf_counter() - t0)
+        for a, w in zip(got, want):
+            assert np.array_equal(a[0], w[b])
+    assert worst < 0.05, f"a lone heap-order call took {worst * 1e3:.1f} ms"
