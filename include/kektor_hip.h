@@ -40,7 +40,8 @@
  *     KDB_COMBINE_MAX_B (16) queries with the same (k, ef, flags) and no allow list leave as ONE launch as soon as a slot is
  *     free (no window, no timer: a lone caller never waits), and that launch stays open for KDB_SESSION_US (300) microseconds:
  *     a matching call that arrives while its kernel runs is written into its page-locked buffer and walked by a workgroup that
- *     waited for it -- no launch of its own; kdb_index_caller_stats counts launches and the calls they carried.
+ *     waited for it -- no launch of its own (with KDB_SEARCH_HEAP_ORDER a query that meets equal distances is answered once its
+ *     launch has closed: up to that window later); kdb_index_caller_stats counts launches and the calls they carried.
  *     Writers -- uploads, kdb_index_mark_deleted, kdb_index_set_entry, build / add_batch, reserve, destroy -- wait until no
  *     host-pointer call is in flight and hold new ones back meanwhile (the reference's write lock).  The *_dev entry points
  *     are asynchronous on the stream they are given; the index keeps a set of per-call scratch per stream in use (up to 18):
