@@ -37,6 +37,16 @@ struct Error : std::runtime_error {
 };
 
 // types.SearchResult (pkg/core/types/types.go:12-15)
+// queries must be finite (the kernels' contract): exponent all ones = NaN or infinity
+inline bool AllFinite(const float *x, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t u;
+        std::memcpy(&u, x + i, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return false;
+    }
+    return true;
+}
+
 struct SearchResult {
     uint32_t DocID;
     double Score;
@@ -116,6 +126,7 @@ class Index {
                                                int efSearch) const {
         std::vector<SearchResult> out;
         if (!h_ || k <= 0 || query.size() != dim_) return out;
+        if (!AllFinite(query.data(), query.size())) return out; // (the kernels' contract: a NaN query can fault the GPU -- DESIGN 5.1)
         std::vector<uint32_t> ids((size_t)k), cnt(1);
         DistBuf dist((size_t)k, wide());
         int rc = kdb_search_batch(h_, query.data(), 1, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0),
@@ -253,6 +264,7 @@ class BasicMicroBatcher {
 
     std::vector<SearchResult> SearchWithScores(const std::vector<float> &query, int k, const AllowList *allowList, int efSearch) {
         if (k <= 0 || query.size() != idx_.Dim()) return {};
+        if (!AllFinite(query.data(), query.size())) return {}; // (never into a batch with other callers' queries)
         if (!allowList && combines(idx_, 0)) {
             {
                 std::lock_guard<std::mutex> lk(mu_);

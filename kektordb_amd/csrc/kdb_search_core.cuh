@@ -109,9 +109,18 @@ __device__ __forceinline__ void wave_lds_fence() {
 // distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
 // RMAX > 0 caps the rows per 16-lane group and trip (latency mode: a wave's share of a hop is at most 8 rows, and the
 // registers of a third row per group are better spent elsewhere)
-// A key that is not a number (a NaN or Inf - Inf in the query or in a row) would make every comparison of the beam false: slots
-// computed from inconsistent ranks, garbage ids, a fault.  Such a neighbour is "infinitely far" instead: never nearer than anything.
-__device__ __forceinline__ float kdb_sane_key(float key) { return key != key ? INFINITY : key; }
+// A key that is not a number (a NaN or Inf - Inf in the query or in a row) makes every comparison of the beam false: slots computed
+// from inconsistent ranks, garbage ids, a fault (measured: a NaN query takes the process down).  Mapping such keys to +Inf HERE
+// stopped the fault (-DKDB_SANE_KEYS, tests passed) but changed the answers of the LDS-beam filtered walk on the 10M x 1536 table
+// (ef 400, 50 % allowed: recall against the exact filtered answer 0.41 -> 0.064, below ef 256's; honest ids, ef 100 and the 1M x 768
+// table unchanged; scripts/dbg/c4_filtered_ef400.py) -- not understood at the round's end, so the guard is OFF: inputs must be finite.
+__device__ __forceinline__ float kdb_sane_key(float key) {
+#ifdef KDB_SANE_KEYS
+    return key != key ? INFINITY : key;
+#else
+    return key;
+#endif
+}
 
 template <int PREC, int METRIC, int NCH = 0, int RMAX = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {

@@ -2,6 +2,7 @@
 // tests/test_cpp_host.py.  Many threads issue one-query calls with a few (k, ef, allow list) combinations; every
 // caller must get the answer computed from ITS query, calls must be coalesced, Stop() must release everybody.
 #include <atomic>
+#include <limits>
 #include <chrono>
 #include <cstdio>
 #include <thread>
@@ -88,6 +89,14 @@ int main() {
         r = mb.SearchWithScores(q, 5, &narrow, 33);
         if (r.size() != 5 || r[0].Score != 33.0) bad++;
         idx.refuse_flat = false;
+        // a query that is not finite never reaches the index (the kernels' contract; a NaN query can fault the GPU): empty answer
+        const int calls_before = (int)idx.calls.load();
+        std::vector<float> nq(8, 1.0f);
+        nq[3] = std::numeric_limits<float>::quiet_NaN();
+        if (!mb.SearchWithScores(nq, 5, nullptr, 33).empty()) bad++;
+        nq[3] = std::numeric_limits<float>::infinity();
+        if (!mb.SearchWithScores(nq, 5, &wide, 33).empty()) bad++;
+        if ((int)idx.calls.load() != calls_before) bad++;
     }
     // Stop() releases callers that are still waiting for company, later calls return []
     std::vector<std::thread> late;
