@@ -53,6 +53,9 @@
  *     product for KDB_METRIC_COSINE (f32), the f64-scaled cosine distance for int8.  The shim applies
  *     the reference's f64 epilogue -- float64(sum) (distance_go.go:67) or 1.0-float64(dot)
  *     (distance_go.go:127) -- when it fills types.SearchResult.Score (pkg/core/types/types.go:12-15).
+ *   - queries and stored rows hold FINITE values: a NaN or an infinity makes every comparison of a walk false and can fault the
+ *     device for every caller of the process (the reference compares such distances like any other); the mirrors check a query
+ *     before the call (kektor_hip.hpp AllFinite, integration/go searchHIP) -- DESIGN.md 5.1, an open item;
  *   - there is NO CPU fallback: every compute entry point fails with KDB_ERR_NO_DEVICE when no gfx950
  *     device is visible.
  */

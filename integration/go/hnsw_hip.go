@@ -35,6 +35,7 @@ package hnsw
 import "C"
 
 import (
+	"math"
 	"errors"
 	"fmt"
 	"log/slog"
@@ -403,8 +404,14 @@ func (h *Index) searchHIP(query []float32, k int, allowList *roaring.Bitmap, efS
 		slog.Error("Error during HNSW search", "error", errors.New("query dimension mismatch"))
 		return []types.SearchResult{}
 	}
+	for _, x := range query { // the kernels' contract (kektor_hip.h, DESIGN 5.1): a NaN or an infinity in a query can fault the GPU
+		if math.Float32bits(x)&0x7f800000 == 0x7f800000 {
+			slog.Error("Error during HNSW search", "error", errors.New("query holds a value that is not finite"))
+			return []types.SearchResult{}
+		}
+	}
 	if allowList == nil { // unfiltered: one cgo call per goroutine; the library combines concurrent calls (measured on one MI355X,
-		// 1M x 768, ef 60: 64 goroutine-like callers 189 k QPS at p50 0.29 ms, 256 callers 431 k QPS at p99 0.9 ms -- bench.py micro_batcher)
+		// 1M x 768, ef 60: 64 goroutine-like callers 257-267 k QPS at p50 0.22 ms, 172-193 k with the heap-order flag this file sets -- bench.py micro_batcher)
 		out, err := h.searchBatchHIP([]*hipRequest{{query: query}}, k, efSearch, nil)
 		if err != nil || len(out) == 0 {
 			if err != nil {
