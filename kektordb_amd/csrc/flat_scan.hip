@@ -1004,7 +1004,9 @@ __device__ __forceinline__ float fs_unpack_key(unsigned long long x) {
 }
 
 #include "flat_scan_big.cuh"
+#ifdef KDB_AB // A/B build only (make ab): the out-of-phase variant, measured slower in round 5
 #include "flat_scan_skew.cuh"
+#endif
 
 // Merge the per-stripe lists of one query (block = 256 threads): SELECT the best nf entries of the n gathered
 // ones (nf = k for cosine, the re-score set kl for L2) with a block-wide bitwise search for the nf-th smallest
@@ -2090,40 +2092,47 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         KDB_HIP(hipGetLastError());
         return KDB_OK;
     };
-    // the seed launch (first tile of every stripe -> first thresholds, flat_scan_big.cuh) and the scan proper: the kernel whose two
-    // row halves run half a tile apart (flat_scan_skew.cuh: one half's selection under the other's MFMAs) for rows of at least four
-    // 128-byte slabs, the in-step kernel for shorter rows
-    // (measured slower than the in-step kernel -- flat_scan_skew.cuh's header says why -- and therefore opt-in: KDB_FB_SKEW=1, read per call)
-    const char *skew_env = getenv("KDB_FB_SKEW");
-    const bool skew_on = skew_env && atoi(skew_env) != 0;
+    // the seed launch (first tile of every stripe -> first thresholds, flat_scan_big.cuh) and the scan proper.  (A/B build, -DKDB_AB +
+    // KDB_FB_SKEW=1: the kernel whose two row halves run half a tile apart, flat_scan_skew.cuh -- measured slower, not shipped.)
     auto launch_big = [&](auto seed_kern, auto kern, auto skew_kern, const void *rows_b, const void *q_b) -> int {
         if (p.fb_seeded) {
             int r1 = launch_big_one(seed_kern, rows_b, q_b);
             if (r1) return r1;
         }
+#ifdef KDB_AB
+        const char *skew_env = getenv("KDB_FB_SKEW");
         const KdbView &vv = rows_b == (const void *)idx->d_rows16 ? vr : v;
         const uint32_t rowb = v.precision == KDB_PREC_I8 ? vv.ld : vv.ld * 2u;
-        if (skew_on && rowb / FB_SLAB >= 4u) {
+        if (skew_env && atoi(skew_env) != 0 && rowb / FB_SLAB >= 4u) {
             KDB_HIP(hipFuncSetAttribute((const void *)skew_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FK_LDS));
             hipLaunchKernelGGL(skew_kern, dim3(256), dim3(512), FK_LDS, s, vv, reinterpret_cast<const unsigned char *>(rows_b),
                                reinterpret_cast<const unsigned char *>(q_b), p);
             KDB_HIP(hipGetLastError());
             return KDB_OK;
         }
+#else
+        (void)skew_kern;
+#endif
         return launch_big_one(kern, rows_b, q_b);
     };
+#ifdef KDB_AB
+#define KDB_SKEW_K(M, P) flat_scan_skew_kernel<M, P>
+#else
+#define KDB_SKEW_K(M, P) nullptr
+#endif
     if (big) {
         if (v.precision == KDB_PREC_I8)
             rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8, true>, flat_scan_big_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>,
-                            flat_scan_skew_kernel<KDB_METRIC_COSINE, KDB_PREC_I8>, v.rows, d_q);
+                            KDB_SKEW_K(KDB_METRIC_COSINE, KDB_PREC_I8), v.rows, d_q);
         else if (v.precision == KDB_PREC_F16)
             rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16, true>, flat_scan_big_kernel<KDB_METRIC_L2, KDB_PREC_F16>,
-                            flat_scan_skew_kernel<KDB_METRIC_L2, KDB_PREC_F16>, v.rows, d_fbq);
+                            KDB_SKEW_K(KDB_METRIC_L2, KDB_PREC_F16), v.rows, d_fbq);
         else if (v.metric == KDB_METRIC_COSINE)
             rc = launch_big(flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R, true>, flat_scan_big_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>,
-                            flat_scan_skew_kernel<KDB_METRIC_COSINE, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+                            KDB_SKEW_K(KDB_METRIC_COSINE, FS_PREC_F32R), idx->d_rows16, d_fbq);
         else rc = launch_big(flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R, true>, flat_scan_big_kernel<KDB_METRIC_L2, FS_PREC_F32R>,
-                             flat_scan_skew_kernel<KDB_METRIC_L2, FS_PREC_F32R>, idx->d_rows16, d_fbq);
+                             KDB_SKEW_K(KDB_METRIC_L2, FS_PREC_F32R), idx->d_rows16, d_fbq);
+#undef KDB_SKEW_K
     } else if (small && rank16) { // queries as halfs: half the LDS, more workgroups per CU
         const size_t lds_r = fss_q_bytes<FS_PREC_F32R>(vr.ld) + (size_t)FSS_TQ * cap_s * 8 + FSS_TAIL;
         if (v.metric == KDB_METRIC_COSINE) rc = launch_small_view(fss_kernel_for<KDB_METRIC_COSINE, FS_PREC_F32R>(vr.ld), vr, p, q_rank, lds_r);

@@ -28,10 +28,10 @@ void kdb_set_error(const char *fmt, ...) {
 extern "C" const char *kdb_last_error(void) { return g_err; }
 
 // Kernels of different streams run side by side only on different HARDWARE queues, and the runtime gives a process four unless
-// told otherwise (measured: scripts/micro/launch_rate.hip -- 8 threads with a 150 us kernel each reach 25.6 k launches/s on four
-// queues, 42.7 k on eight).  The slots of concurrent callers want one each: ask for eight, if nobody has decided yet and the
-// runtime has not started (it reads the variable at its first call).
-__attribute__((constructor)) static void kdb_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// GPU_MAX_HW_QUEUES says otherwise (measured: scripts/micro/launch_rate.hip -- 8 threads with a 150 us kernel each reach 25.6 k
+// launches/s on four queues, 42.7 k on eight).  The library does NOT touch the environment (round 5 did, from a constructor: a
+// process-wide side effect, and setenv is not thread-safe under a dlopen from a threaded host): the host that wants eight queues
+// sets the variable before the runtime starts -- INTEGRATION.md, kektordb_amd/__init__.py.
 extern "C" int kdb_abi_version(void) { return KDB_ABI_VERSION; }
 
 extern "C" int kdb_hip_device_count(void) {
@@ -105,6 +105,7 @@ static size_t grown(size_t bytes) {
 int kdb_ensure_scratch(kdb_index *idx, size_t bytes) {
     if (idx->scratch_bytes >= bytes) return KDB_OK;
     if (idx->d_scratch) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_scratch));
         idx->d_scratch = nullptr;
@@ -174,6 +175,7 @@ int kdb_lane_release(kdb_index *idx, hipStream_t s) {
 int kdb_ensure_visited(kdb_index *idx, uint32_t slots, hipStream_t s) {
     if (idx->vis_slots >= slots) return KDB_OK;
     if (idx->d_visited) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_visited));
         idx->d_visited = nullptr;
@@ -210,6 +212,7 @@ unsigned long long *kdb_stats_begin(kdb_index *idx, int kind, uint32_t B, uint32
 int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes) {
     if (idx->tie_bytes >= bytes) return KDB_OK;
     if (idx->d_tie) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_tie));
         idx->d_tie = nullptr;
@@ -223,6 +226,7 @@ int kdb_ensure_tie_scratch(kdb_index *idx, size_t bytes) {
 int kdb_ensure_group_entries(kdb_index *idx, uint32_t n) {
     if (idx->gentry_cap >= n) return KDB_OK;
     if (idx->d_gentry) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_gentry));
         idx->d_gentry = nullptr;
@@ -236,6 +240,7 @@ int kdb_ensure_group_entries(kdb_index *idx, uint32_t n) {
 static int ensure_qbuf(kdb_index *idx, size_t bytes) {
     if (idx->qbuf_bytes >= bytes) return KDB_OK;
     if (idx->d_qbuf) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_qbuf));
         idx->d_qbuf = nullptr;
@@ -249,6 +254,7 @@ static int ensure_qbuf(kdb_index *idx, size_t bytes) {
 static int ensure_iobuf(kdb_index *idx, size_t bytes) {
     if (idx->iobuf_bytes >= bytes) return KDB_OK;
     if (idx->d_iobuf) {
+        kdb_close_session(idx); // (an open launch would sit out its 0.5 s device-side safety under this synchronisation: closing it needs idx->mu, which this thread holds)
         KDB_HIP(hipDeviceSynchronize()); // growth is rare; work of callers' streams may still use the old buffer
         KDB_HIP(hipFree(idx->d_iobuf));
         idx->d_iobuf = nullptr;
@@ -1081,8 +1087,9 @@ static int slot_find_free(const kdb_index *idx) {
 }
 
 // under idx->mu, slot idle (its last call has left)
-static int slot_ensure(kdb_slot &sl, size_t bytes) {
+static int slot_ensure(kdb_index *idx, kdb_slot &sl, size_t bytes) {
     if (sl.bytes >= bytes) return KDB_OK;
+    kdb_close_session(idx); // (hipFree / hipMalloc synchronise the device: an open launch must be able to end)
     if (sl.d_io) (void)hipFree(sl.d_io);
     if (sl.h_pin) (void)hipHostFree(sl.h_pin);
     sl.d_io = sl.h_pin = nullptr;
@@ -1149,6 +1156,13 @@ void kdb_close_session(kdb_index *idx) { // under mu
     idx->open_session = nullptr;
 }
 
+// under mu: an open launch whose window has passed stops accepting queries (any caller that takes the lock may find it so: the
+// calls that never join a launch -- filtered, large, traced -- used to leave it to the next joinable caller)
+static void close_expired_session(kdb_index *idx) {
+    kdb_group *os = idx->open_session;
+    if (os && now_ns() - os->t_launch_ns > (uint64_t)session_us() * 1000ull) kdb_close_session(idx);
+}
+
 static void group_fail(kdb_group *g, int rc) {
     g->rc = rc;
     snprintf(g->err, sizeof g->err, "%s", kdb_last_error());
@@ -1173,7 +1187,7 @@ static void launch_search_group(kdb_index *idx, std::unique_lock<std::mutex> &lk
     const bool session = session_us() != 0u && idx->desc.precision != KDB_PREC_I8 && !idx->writers_waiting && nq < KDB_GROUP_CAP;
     g->cap_q = session ? KDB_GROUP_CAP : nq;
     const StagedLayout L = staged_layout(idx, g->cap_q, g->k, false, g->dist_bytes);
-    int rc = slot_ensure(sl, L.total);
+    int rc = slot_ensure(idx, sl, L.total);
     if (rc == KDB_OK) {
         unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin);
         const size_t dim = idx->desc.dim;
@@ -1403,6 +1417,7 @@ static int staged_slot_call(kdb_index *idx, const float *queries, uint32_t B, ui
                             uint32_t *out_count, size_t dist_bytes, bool direct_out, F run) {
     static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
     std::unique_lock<std::mutex> lk(idx->mu);
+    close_expired_session(idx);
     int si = -1;
     idx->slot_waiters++;
     idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0 && (si = slot_find_free(idx)) >= 0; });
@@ -1413,7 +1428,7 @@ static int staged_slot_call(kdb_index *idx, const float *queries, uint32_t B, ui
     idx->n_groups++;
     idx->n_group_members++;
     const StagedLayout L = staged_layout(idx, B, k, allow_bits != nullptr, dist_bytes);
-    int rc = slot_ensure(sl, L.total);
+    int rc = slot_ensure(idx, sl, L.total);
     unsigned char *const h = reinterpret_cast<unsigned char *>(sl.h_pin), *const d = reinterpret_cast<unsigned char *>(sl.d_io);
     bool queued = false;
     if (rc == KDB_OK) {
@@ -1468,6 +1483,7 @@ static int staged_big_call(kdb_index *idx, const float *queries, uint32_t B, uin
                            uint32_t *out_count, size_t dist_bytes, bool fail_on_drop, F run) {
     std::lock_guard<std::mutex> big(idx->big_mu);
     std::unique_lock<std::mutex> lk(idx->mu);
+    close_expired_session(idx);
     if (idx->writers_waiting) idx->slot_cv.wait(lk, [&] { return idx->writers_waiting == 0; });
     const StagedLayout L = staged_layout(idx, B, k, allow_bits != nullptr, dist_bytes);
     int rc = ensure_iobuf(idx, L.total);

@@ -109,18 +109,13 @@ __device__ __forceinline__ void wave_lds_fence() {
 // distances of nb_id[0..n) -> nb_d[0..n)  (keys, see kdb_key_from_raw)
 // RMAX > 0 caps the rows per 16-lane group and trip (latency mode: a wave's share of a hop is at most 8 rows, and the
 // registers of a third row per group are better spent elsewhere)
-// A key that is not a number (a NaN or Inf - Inf in the query or in a row) makes every comparison of the beam false: slots computed
-// from inconsistent ranks, garbage ids, a fault (measured: a NaN query takes the process down).  Mapping such keys to +Inf HERE
-// stopped the fault (-DKDB_SANE_KEYS, tests passed) but changed the answers of the LDS-beam filtered walk on the 10M x 1536 table
-// (ef 400, 50 % allowed: recall against the exact filtered answer 0.41 -> 0.064, below ef 256's; honest ids, ef 100 and the 1M x 768
-// table unchanged; scripts/dbg/c4_filtered_ef400.py) -- not understood at the round's end, so the guard is OFF: inputs must be finite.
-__device__ __forceinline__ float kdb_sane_key(float key) {
-#ifdef KDB_SANE_KEYS
-    return key != key ? INFINITY : key;
-#else
-    return key;
-#endif
-}
+// A key that is not a number (a NaN or Inf - Inf in a stored row; queries that are not finite never get this far, see
+// kdb_load_query) makes every comparison of the beam false: ranks computed from inconsistent comparisons leave holes in the
+// scatter, stale ids, a gather outside the index.  Such a row is "infinitely far": never nearer than anything.  (Round 5 built
+// this guard and found the answers of ONE kernel changed with it -- on finite inputs.  Round 6: no key was ever NaN there; the
+// extra live value pushed hnsw_search_kernel<f32, cosine, 24, LDS beam, bitset, 4 waves> into a VGPR spill whose reload this
+// toolchain places before the exec restore of a join block -- scripts/tools/isa_check.py)
+__device__ __forceinline__ float kdb_sane_key(float key) { return key != key ? INFINITY : key; }
 
 template <int PREC, int METRIC, int NCH = 0, int RMAX = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
@@ -172,7 +167,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         return;
     }
     if constexpr (PREC == KDB_PREC_F16 && NCH > 0 && NCH % 2 == 0 && NCH <= 24) { // ld == 64*NCH: NCH/2 chunks per lane
-        constexpr int R = KDB_F16_ROWS; // rows per 16-lane group and trip
+        constexpr int R = (RMAX > 0 && KDB_F16_ROWS > RMAX) ? RMAX : KDB_F16_ROWS; // rows per 16-lane group and trip
         for (uint32_t base = 0; base < n; base += 4u * R) {
             const uint16_t *rows[R];
             uint32_t rr[R];
@@ -194,7 +189,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
         return;
     }
     if constexpr (PREC == KDB_PREC_I8 && NCH > 0 && NCH % 4 == 0 && NCH <= 24) { // ld == 64*NCH: NCH/4 chunks per lane
-        constexpr int R = 2; // 8 rows per trip; more would cost the fourth wave per SIMD (registers)
+        constexpr int R = (RMAX > 0 && 2 > RMAX) ? RMAX : 2; // 8 rows per trip; more would cost the fourth wave per SIMD (registers)
         for (uint32_t base = 0; base < n; base += 4u * R) {
             const int8_t *rows[R];
             uint32_t rr[R], ids[R];
@@ -327,20 +322,31 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 // stays untouched (every lane runs the same sequential sum on broadcast LDS reads: no divergence); float16 indexes: the RNE
 // round trip of float16.Fromfloat32 (:425).  Else: a prepared f32 row of `ld` floats.  Shared by the fast walk and the
 // heap-order walk: one preparation, one bit pattern.
+// *dead (wave-uniform): the query holds a component that is not a finite number (a client's bug: one request of a batch).  The
+// reference compares the NaN distances that follow like any others and returns whatever its heaps then hold
+// (hnsw_index.go:2566-2590) -- nothing to be bit-exact with; here such a query is answered with NO results (out_count = 0, the
+// reference's own "swallow to empty" for a search that fails, :356-359) and never walks; the rest of its batch is untouched.
 template <int PREC>
 __device__ __forceinline__ float kdb_load_query(const KdbView &v, const WaveLds &s, const void *__restrict__ queries,
-                                                const float *__restrict__ qnorms, uint32_t raw, uint32_t qi) {
+                                                const float *__restrict__ qnorms, uint32_t raw, uint32_t qi, bool *dead = nullptr) {
     const int lane = kdb_lane();
     float qnorm = 1.f;
+    bool bad = false; // per lane: a component that is not finite
+    auto not_finite = [](float x) { return !(__builtin_fabsf(x) <= 3.402823466e38f); };
     if (PREC == KDB_PREC_I8) {
         const uint32_t nw = (uint32_t)((((size_t)v.ld + 15) / 16 * 16) / 4);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(queries) + (size_t)qi * nw;
         uint32_t *dst = reinterpret_cast<uint32_t *>(s.q);
         for (uint32_t i = (uint32_t)lane; i < nw; i += 64) dst[i] = src[i];
         qnorm = qnorms[qi];
+        bad = !(qnorm > 0.f); // prep_queries_kernel marks a query that is not finite with a negative norm
     } else if (raw & 1u) {
         const float *src = reinterpret_cast<const float *>(queries) + (size_t)qi * v.dim;
-        for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) s.q[i] = i < v.dim ? src[i] : 0.f;
+        for (uint32_t i = (uint32_t)lane; i < v.ld; i += 64) {
+            const float x = i < v.dim ? src[i] : 0.f;
+            bad = bad || not_finite(x);
+            s.q[i] = x;
+        }
         wave_lds_fence();
         if (raw & 2u) {
             float nsq = 0.f;
@@ -371,8 +377,13 @@ __device__ __forceinline__ float kdb_load_query(const KdbView &v, const WaveLds 
     } else {
         const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(queries) + (size_t)qi * v.ld);
         float4 *dst = reinterpret_cast<float4 *>(s.q);
-        for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) dst[i] = src[i];
+        for (uint32_t i = (uint32_t)lane; i < (v.ld >> 2); i += 64) {
+            const float4 x = src[i];
+            bad = bad || not_finite(x.x) || not_finite(x.y) || not_finite(x.z) || not_finite(x.w);
+            dst[i] = x;
+        }
     }
+    if (dead) *dead = __ballot(bad) != 0ull;
     __threadfence_block();
     wave_lds_fence();
     return qnorm;
@@ -463,6 +474,7 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
         const uint2 rq = wide_poll_change(s.ctl + KDB_W_MB_SEQ, seen);
         seen = rq.x;
         const uint32_t kind = rq.y & 3u, node = rq.y >> 2;
+        const bool node_ok = node - 1u < v.count; // never an address from an id that names no node: such a visit is answered "not a hop"
         if (kind == KDB_W_EXIT) {
             if (lane == 0) wide_post(s.ctl + KDB_W_ROWS_SEQ, seen, KDB_W_N_EXIT);
             return;
@@ -474,9 +486,9 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
             level = (int)(lvw & 0xffu);
             vis.end_layer(); // (the HBM bitset un-marks what the previous, upper layer marked: BitSet.Clear per layer call; the hash clears itself)
             vis.begin_layer(level > 0);
-            (void)vis.test_and_set(node, lane == 0);
+            (void)vis.test_and_set(node, lane == 0 && node_ok);
             if (lvw & 0x100u) {
-                if (lane == 0) s.nb_id[0] = node;
+                if (lane == 0) s.nb_id[0] = node_ok ? node : 0u;
                 n = 1u;
             }
             pf_node = 0u;
@@ -485,8 +497,9 @@ __device__ void wide_visitor_loop(const KdbView &v, const WaveLds &s, VisT vis) 
         }
         if (kind == KDB_W_VISIT || (lvw & 0x300u) == 0x200u) { // (a BEGIN whose entry distance is known goes straight on to the entry point's list: it is the first pop)
             uint32_t nb = 0u;
-            bool has_level = true;
-            if (level == 0) {
+            bool has_level = node_ok;
+            if (!node_ok) {
+            } else if (level == 0) {
                 nb = pf_nb; // on its way since the hop before, when the guess was right
                 if (node != pf_node) nb = lane < v.deg0 ? v.adj0[(size_t)node * v.deg0 + lane] : 0u;
             } else {
@@ -1470,6 +1483,7 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)
         uint32_t cur;
         if (!pop_candidate(b, nr, ef, cur)) break;
+        if (cur - 1u >= v.count) continue; // never an address from an id that names no node (a wrong key may cost recall, never a fault)
         const uint32_t *adj = v.adj0 + (size_t)cur * v.deg0;
         if (level > 0) { // the node's level and its first upper slot are requested together (one wait, not two dependent ones)
             const int lv = (int)v.levels[cur];

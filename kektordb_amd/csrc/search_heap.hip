@@ -623,7 +623,7 @@ heap_walk_kernel(KdbView v, HeapArgs a) {
             }
         }
         QCtr ctr{};
-        bool failed = ep == 0u, over = false;
+        bool failed = ep - 1u >= v.count, over = false; // (ep == 0: an empty list / no valid entry)
         for (int l = v.max_level; l > 0 && !failed && !over; l--) { // greedy descent, ef = 1 (:450-459)
             const uint32_t n = heap_layer<PREC, METRIC, NCH>(v, s, vis, cands, results, res_id, res_key, res_lo, q_allow, ep, l, 1u, qnorm, ctr);
             if (n == 0xffffffffu) over = true;

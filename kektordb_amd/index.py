@@ -450,7 +450,9 @@ def merge_topk(metric: int, ids, dist, count, k: int, id_base=None, precision: i
     count = np.ascontiguousarray(count, dtype=np.uint32)
     base = None if id_base is None else np.ascontiguousarray(id_base, dtype=np.uint32)
     G, B = count.shape
-    if np.asarray(dist).dtype == np.float64:  # int8 shards: the reference's float64 distances, ordered as doubles
+    if precision == I8 and np.asarray(dist).dtype == np.float64:  # int8 shards: the reference's float64 distances, ordered as doubles
+        # (chosen by the index's precision, not by the array's dtype alone: a float64 array of an f32 cosine index holds DOTS --
+        # it is cast to float32 and merged on the key -dot below, as before)
         dist = np.ascontiguousarray(dist, dtype=np.float64)
         o_ids = np.zeros((B, k), dtype=np.uint32)
         o_dist = np.zeros((B, k), dtype=np.float64)

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the host's decision, not the library's: eight hardware queues for the slots of concurrent callers, read by the
+# HIP runtime at its first call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

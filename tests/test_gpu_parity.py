@@ -680,6 +680,51 @@ def test_search_beam_and_visited_variants(oracle, hip, ef):
         assert (int(nd[b]), int(nh[b])) == (ond, onh)
 
 
+@pytest.mark.parametrize("shape", ["l2_32d_deleted", "cosine_1536d"])
+@pytest.mark.parametrize("ef", [120, 250, 300, 400, 700, 1200])
+def test_filtered_walks_on_every_beam_and_visited_set(oracle, hip, ef, shape):
+    """The reference skips non-allowed neighbours while it traverses (hnsw_index.go:2545-2549).  An allow list (50 % / 10 % of
+    the ids) x every beam storage (register slots 2 / 4, LDS beam above ef 256) x every visited set (LDS hash, its migration to
+    the HBM bitset -- a filtered walk marks every neighbour but scores only the allowed ones, so the set outgrows the hash long
+    before n_dist says so --, the bitset alone) x every batch mode (four / two waves per query, one wave with the large hash, one
+    wave over the bitset): ids, distance bits, n_dist and n_hops of the oracle.  1536 columns = configs[4]'s row (its own
+    unrolled width); the 32-d case also carries soft-deleted nodes (side list + filter)."""
+    O = oracle
+    from kektordb_amd.index import dense_bitset
+    if shape == "l2_32d_deleted":
+        n, dim, metric = 6000, 32, 0
+        X = make_corpus(n, dim, "uniform", seed=61)
+        deleted = list(range(9, n, 11))
+        efc = 60
+    else:
+        n, dim, metric = 2500, 1536, 1
+        X = make_corpus(n, dim, "clustered", seed=63)
+        deleted = []
+        efc = 60
+    orc, idx = build_pair(O, hip, X, metric, efc=efc, deleted=deleted)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = make_corpus(12, dim, "uniform" if dim == 32 else "clustered", seed=62 if dim == 32 else 63)
+    rng = np.random.default_rng(5)
+    k = 20
+    for frac in (0.5, 0.1):
+        allowed = np.nonzero(rng.random(n + 1) < frac)[0]
+        allowed = allowed[allowed >= 1]
+        ab = dense_bitset(allowed, n)
+        want = [orc.search(Q[b], k, allow=ab, ef=ef, counters=True) for b in range(Q.shape[0])]
+        for reps in (1, 40, 200, 700):   # 12 / 480 / 2400 / 8400 queries: every launch geometry of launch_search_bs
+            Qb = np.tile(Q, (reps, 1))
+            ids, dist, cnt, (nd, nh) = idx.search_batch(Qb, k, ef, allow_bits=ab, trace=True)
+            for b in list(range(12)) + list(range(Qb.shape[0] - 12, Qb.shape[0])):
+                oi, od, (ond, onh) = want[b % 12]
+                c = int(cnt[b])
+                assert c == len(oi), (ef, frac, reps, b)
+                assert np.array_equal(ids[b, :c], oi), (ef, frac, reps, b)
+                assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (ef, frac, reps, b)
+                assert (int(nd[b]), int(nh[b])) == (ond, onh), (ef, frac, reps, b)
+                assert set(ids[b, :c].tolist()) <= set(allowed.tolist()) and not (set(ids[b, :c].tolist()) & set(deleted))
+            assert np.array_equal(ids[:12], ids[-12:]) and np.array_equal(dist[:12].view(np.uint32), dist[-12:].view(np.uint32))
+
+
 @pytest.mark.parametrize("frac", [0.5, 0.9])
 @pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1)])
 def test_search_mostly_deleted_index(oracle, hip, metric, prec, frac):
@@ -1555,18 +1600,17 @@ def test_tiny_negative_dots_that_collide_as_float64(oracle, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.skip(reason="needs a library built with -DKDB_SANE_KEYS (kdb_search_core.cuh kdb_sane_key): the guard is off by default -- it changed "
-                         "the answers of the LDS-beam filtered walk on the 10M x 1536 table, not understood at the end of round 5; without it "
-                         "a NaN query faults the GPU and takes the test process with it")
 @pytest.mark.parametrize("metric,prec", [(0, 0), (1, 0), (0, 1), (1, 2)])
 def test_non_finite_queries_and_rows_do_not_fault(oracle, hip, metric, prec):
     """A NaN or an infinity in a query (a client's bug, one request of many in a batch) or in a stored row must not take the process
     down.  The reference compares such distances like any other (every comparison with a NaN is false, hnsw_heap.go:53-82) and
-    returns whatever its heaps then hold -- nothing to be bit-exact with.  Here a distance that is not a number is "infinitely far"
-    (kdb_sane_key): round 5 found that a NaN key made the beam's rank computations inconsistent, the walk followed a garbage id
-    and the GPU faulted -- for every caller of the process.  Asserted: no fault; every returned id names a row; the FINITE
-    queries of the batch get exactly the answers they get alone; graph walk (one-wave and four-wave kernels, heap order or not),
-    exact scan, and the builder on a corpus of NaN rows."""
+    returns whatever its heaps then hold -- nothing to be bit-exact with.  Here a query with a component that is not finite gets NO
+    results (count 0, the reference's "swallow to empty", hnsw_index.go:356-359) and never walks (kdb_load_query); a stored row
+    that yields a distance that is not a number is "infinitely far" (kdb_sane_key).  Round 5 found that a NaN key made the beam's
+    rank computations inconsistent, the walk followed a garbage id and the GPU faulted -- for every caller of the process.
+    Asserted: no fault; every returned id names a row; the non-finite queries return nothing; the FINITE queries of the batch get
+    exactly the answers they get alone; graph walk (one-wave and four-wave kernels, heap order or not), exact scan, and the
+    builder on a corpus of NaN rows."""
     O = oracle
     rng = np.random.default_rng(91)
     n, dim, k = 3000, 40, 10
@@ -1595,6 +1639,8 @@ def test_non_finite_queries_and_rows_do_not_fault(oracle, hip, metric, prec):
                     if b % 12 in fine:
                         assert c[b] == want[2][b % 12] & hip.index.COUNT_MASK and np.array_equal(ids[b], want[0][b % 12]), (metric, prec, ef, b)
                         assert np.array_equal(dist[b].view(np.uint8), want[1][b % 12].view(np.uint8)), (metric, prec, ef, b)
+                    elif b % 12 in (1, 3, 5, 7):
+                        assert c[b] == 0, (metric, prec, ef, b)        # not finite: no results
         fi, fd, fc = idx.flat_scan_batch(Qb, k, dist64=d64)
         wf = idx.flat_scan_batch(Q, k, dist64=d64)
         assert np.all(fi <= n)
