@@ -638,7 +638,7 @@ __host__ inline uint32_t fss_exact_cs(uint32_t ld) {
     auto fits = [&](uint32_t c) { // whole chunks, an even number of them; a chunk of fewer than 4 steps only for rows of two chunks
         return c >= 1u && c <= 8u && nsteps % (2u * c) == 0u && (c >= 4u || nsteps == 2u * c);
     };
-    if (const char *e = getenv("KDB_FSS_CS")) {
+    if (const char *e = KDB_AB_ENV("KDB_FSS_CS")) {
         const uint32_t c = (uint32_t)atoi(e);
         if (c == 0u) return 0u;
         if (fits(c)) return c;
@@ -1742,7 +1742,7 @@ merge_topk_kernel(int negate, uint32_t G, uint32_t B, uint32_t k, const uint32_t
 static int kdb_flat_big_min() {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("KDB_FLAT_BIG_MIN");
+        const char *e = KDB_AB_ENV("KDB_FLAT_BIG_MIN");
         v = e ? atoi(e) : 33;
         if (v < 1) v = 1;
     }
@@ -1753,7 +1753,7 @@ static int kdb_flat_big_min() {
 static int kdb_flat_small_max() {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("KDB_FLAT_SMALL_MAX");
+        const char *e = KDB_AB_ENV("KDB_FLAT_SMALL_MAX");
         v = e ? atoi(e) : 64;
         if (v < 0) v = 0;
         if (v > 128) v = 128; // the merge layout of the small kernel holds one 128-query tile
@@ -1913,7 +1913,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
     if (big) {
         fb_nqt = (B + FB_T - 1) / FB_T;                 // <= 32 (batches above 8192 queries are split)
         uint32_t per_xcd = 8u;
-        if (const char *e = getenv("KDB_FB_NQX")) per_xcd = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 8u;
+        if (const char *e = KDB_AB_ENV("KDB_FB_NQX")) per_xcd = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 8u;
         while (fb_nqg * per_xcd < fb_nqt && fb_nqg < 8u) fb_nqg *= 2u; // groups of <= 8 query tiles; 1, 2 or 4 groups
         fb_nqx = (fb_nqt + fb_nqg - 1u) / fb_nqg;       // query tiles an XCD serves
         fb_spx = 32u / fb_nqx;                          // stripes an XCD walks (32 CUs, one workgroup each)
@@ -1925,8 +1925,8 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         if (want_big < 1) want_big = 1;
     }
     uint32_t fb_slack = 64u, fb_period = 4u; // measured at 8192 queries over 1M x 768: period 1 / 2 / 4 = 14.8 / 14.0 / 13.9 ms
-    if (const char *e = getenv("KDB_FB_SLACK")) fb_slack = (uint32_t)atoi(e);
-    if (const char *e = getenv("KDB_FB_PERIOD")) fb_period = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 1u;
+    if (const char *e = KDB_AB_ENV("KDB_FB_SLACK")) fb_slack = (uint32_t)atoi(e);
+    if (const char *e = KDB_AB_ENV("KDB_FB_PERIOD")) fb_period = (uint32_t)atoi(e) >= 1 ? (uint32_t)atoi(e) : 1u;
     while (fb_period > 1u && fb_cap(kl, fb_slack, fb_period) > 64u * (uint32_t)FB_CSLOTS) fb_period--;
     if (fb_cap(kl, fb_slack, fb_period) > 64u * (uint32_t)FB_CSLOTS) fb_slack = 64u * (uint32_t)FB_CSLOTS - kl - fb_period * (uint32_t)FB_T;
     const uint32_t cap_big = fb_cap(kl, fb_slack, fb_period);
@@ -2047,7 +2047,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.part_key = reinterpret_cast<float *>(part);
         p.part_id = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 4);
         p.part_cnt = reinterpret_cast<uint32_t *>(part + n_part_big * cap_big * 8);
-        if (!getenv("KDB_FB_NOSHARE")) {
+        if (!KDB_AB_ENV("KDB_FB_NOSHARE")) {
             p.g_pub = reinterpret_cast<float *>(part + n_part_big * cap_big * 8 + n_part_big * 4);
             p.part_thr = p.g_pub + n_part_big;
             KDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.g_pub), 0x7f800000, n_part_big, s)); // +inf: nothing published yet
@@ -2059,13 +2059,13 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
         p.fb_nqx = fb_nqx;
         p.fb_spx = fb_spx;
         p.fb_slack = fb_slack;
-        p.fb_alt = getenv("KDB_FB_NOALT") ? 0u : 1u;
-        { const char *e = getenv("KDB_FB_PREFETCH"); p.fb_pref = e ? (uint32_t)atoi(e) : 0u; }
-        p.fb_grow = getenv("KDB_FB_NOGROW") ? 0u : 1u;
+        p.fb_alt = KDB_AB_ENV("KDB_FB_NOALT") ? 0u : 1u;
+        { const char *e = KDB_AB_ENV("KDB_FB_PREFETCH"); p.fb_pref = e ? (uint32_t)atoi(e) : 0u; }
+        p.fb_grow = KDB_AB_ENV("KDB_FB_NOGROW") ? 0u : 1u;
         // Seed launch: only when the stripe geometry is known here (no filter, no deleted rows: the row count never leaves the
         // device otherwise), every stripe holds a whole first tile, and a stripe's share of the kl best is at most the 16 rows
         // a tile's block maxima vouch for.  Same integer arithmetic as fs_resolve_n.
-        if (p.g_pub && !need_ids && !getenv("KDB_FB_NOSEED")) {
+        if (p.g_pub && !need_ids && !KDB_AB_ENV("KDB_FB_NOSEED")) {
             const uint32_t n_tiles = (v.count + FB_T - 1) / FB_T;
             uint32_t ns = want_big;
             const uint32_t lim4 = (n_tiles + 3u) / 4u;
@@ -2083,7 +2083,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
             p.fb_seed_nstr = n_str;
         }
         p.fb_period = fb_period;
-        { const char *e = getenv("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
+        { const char *e = KDB_AB_ENV("KDB_FB_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     }
     auto launch_big_one = [&](auto kern, const void *rows_b, const void *q_b) -> int {
         KDB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
@@ -2100,7 +2100,7 @@ int kdb_launch_flat_scan(kdb_index *idx, const KdbView &v, const void *d_q, cons
             if (r1) return r1;
         }
 #ifdef KDB_AB
-        const char *skew_env = getenv("KDB_FB_SKEW");
+        const char *skew_env = KDB_AB_ENV("KDB_FB_SKEW");
         const KdbView &vv = rows_b == (const void *)idx->d_rows16 ? vr : v;
         const uint32_t rowb = v.precision == KDB_PREC_I8 ? vv.ld : vv.ld * 2u;
         if (skew_env && atoi(skew_env) != 0 && rowb / FB_SLAB >= 4u) {
@@ -2357,7 +2357,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
             const double t = (double)rounds * (rows_g / (double)w + startup);
             if (t < best * 0.98) { best = t; want = w; } // the fewest stripes within 2 % of the best
         }
-        if (const char *e = getenv("KDB_GROUP_STRIPES")) { // measurement knob
+        if (const char *e = KDB_AB_ENV("KDB_GROUP_STRIPES")) { // measurement knob
             const uint32_t w = (uint32_t)atoi(e);
             if (w >= 1 && w <= stripes_max) want = w;
         }
@@ -2426,7 +2426,7 @@ int kdb_launch_flat_scan_groups(kdb_index *idx, const KdbView &v, const void *d_
     p.rs_count = d_rsc;
     p.rs_list = d_rsl;
     p.rmax = idx->max_norm2 > 0.f ? sqrtf(idx->max_norm2) : 1.0f;
-    { const char *e = getenv("KDB_FSS_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
+    { const char *e = KDB_AB_ENV("KDB_FSS_DBG"); p.fb_dbg = e ? (uint32_t)atoi(e) : 0u; }
     p.g_tile = d_tiles;
     p.g_nscan = d_gn;
     p.g_base = d_gbase;

@@ -1269,8 +1269,8 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
     uint64_t last_check = t0, naps = 0;
     const uint64_t est0 = idx->walk_ns.load(std::memory_order_relaxed);
     // short naps, but no more than about ten per call however long calls take under the present load
-    static const uint64_t nap_div = [] { const char *e = getenv("KDB_NAP_DIV"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 10ull; }();
-    static const uint64_t nap_min = [] { const char *e = getenv("KDB_NAP_MIN_NS"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 15000ull; }();
+    static const uint64_t nap_div = [] { const char *e = KDB_AB_ENV("KDB_NAP_DIV"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 10ull; }();
+    static const uint64_t nap_min = [] { const char *e = KDB_AB_ENV("KDB_NAP_MIN_NS"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : 15000ull; }();
     const uint64_t nap_ns = est0 / nap_div < nap_min ? nap_min : est0 / nap_div > 150000ull ? 150000ull : est0 / nap_div;
     const uint64_t sess_ns = (uint64_t)session_us() * 1000ull;
     for (;;) {
@@ -1415,7 +1415,7 @@ static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B
 template <typename F>
 static int staged_slot_call(kdb_index *idx, const float *queries, uint32_t B, uint32_t k, const uint64_t *allow_bits, uint32_t *out_ids, void *out_dist,
                             uint32_t *out_count, size_t dist_bytes, bool direct_out, F run) {
-    static const size_t direct_max = [] { const char *e = getenv("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
+    static const size_t direct_max = [] { const char *e = KDB_AB_ENV("KDB_HOST_DIRECT_OUT_MAX"); return e ? (size_t)atoll(e) : (size_t)64 << 10; }();
     std::unique_lock<std::mutex> lk(idx->mu);
     close_expired_session(idx);
     int si = -1;

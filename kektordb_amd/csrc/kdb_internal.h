@@ -17,6 +17,17 @@
 #define KDB_UP_MARK_CAP 256u        // upper-layer visited un-mark list (per wave, LDS); overflow -> full clear
 
 // Device view of one index (passed by value to kernels).
+// A/B levers of finished experiments (KDB_FB_*, KDB_HEAP_NO_*, KDB_FSS_*, KDB_NAP_*, KDB_WIDE*_MAX_B, ...): the product compiles them
+// to their defaults; only the A/B build (make ab, -DKDB_AB) reads them from the environment.  What the shipped library reads at run
+// time is the documented handful of INTEGRATION.md: KDB_SLOTS, KDB_SESSION_US, KDB_COMBINE_MAX_B, KDB_HOST_PIN_MAX,
+// KDB_HOST_CHUNK_MIN, KDB_SPIN_WATCHERS, KDB_FLAT_EXACT_ONLY, KDB_HEAP_OVERLAP_MIN_B and three test hooks (KDB_FB_SEED_MIN_TILES,
+// KDB_RL_UCAP, KDB_HEAP_OVERLAP_GIVE_UP).
+#ifdef KDB_AB
+#define KDB_AB_ENV(name) getenv(name)
+#else
+#define KDB_AB_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 constexpr uint32_t KDB_NO_SLOT = 0xffffffffu;
 
 struct KdbView {

@@ -732,12 +732,12 @@ int kdb_heap_walk_plan(kdb_index *idx, const KdbView &v, uint32_t ef, uint32_t k
     const size_t ew = wk ? 12 : 8;
     KdbHeapPlan p{};
     p.hsize = kdb_vis_hash_size(eff); // 2048 / 4096 words up to ef 260, beyond: the HBM bitset
-    if (getenv("KDB_HEAP_NO_HASH")) p.hsize = 0;
-    if (const char *e = getenv("KDB_HEAP_HASH")) { // measurement: another table size (a power of two)
+    if (KDB_AB_ENV("KDB_HEAP_NO_HASH")) p.hsize = 0;
+    if (const char *e = KDB_AB_ENV("KDB_HEAP_HASH")) { // measurement: another table size (a power of two)
         const uint32_t h = (uint32_t)atoi(e);
         if (p.hsize && h >= 1024u && (h & (h - 1u)) == 0u) p.hsize = h;
     }
-    p.reg_results = p.hsize != 0 && eff + 2u <= 64u && !getenv("KDB_HEAP_NO_REG"); // the result heap in registers (entry i in lane i)
+    p.reg_results = p.hsize != 0 && eff + 2u <= 64u && !KDB_AB_ENV("KDB_HEAP_NO_REG"); // the result heap in registers (entry i in lane i)
     const size_t fixed = (wk ? ((size_t)v.ld + 15) / 16 * 16 : (size_t)v.ld * 4) + 64 * (wk ? 12 : 8) + (p.hsize ? (size_t)p.hsize * 4 : KDB_UP_MARK_CAP * 4) +
                          (p.reg_results ? 1 : 2) * (size_t)(eff + 2u) * ew;
     const uint64_t cap64 = (uint64_t)16u * eff > 2048u ? (uint64_t)16u * eff : 2048u;

@@ -6,7 +6,7 @@
 #define KDB_CAT4(a, b, c, d) KDB_CAT4_(a, b, c, d)
 
 int KDB_CAT4(kdb_launch_search_inst_, KDB_INST_PREC, KDB_INST_METRIC, KDB_INST_GROUP)(KDB_LAUNCH_SEARCH_PARAMS) {
-    static const bool force_generic = getenv("KDB_SEARCH_GENERIC") != nullptr; // measurement knob
+    static const bool force_generic = KDB_AB_ENV("KDB_SEARCH_GENERIC") != nullptr; // measurement knob
     (void)force_generic;
 #if KDB_INST_PREC == 0
 #if KDB_INST_GROUP == 0

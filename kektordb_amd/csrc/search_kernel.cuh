@@ -331,7 +331,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     // the HBM bitset alone for large ef
     uint32_t hsize = (BS == 1 || BS == 2 || BS == 4) ? kdb_vis_hash_size(eff) : 0u;
     if (hsize) { // measurement knob: another table size (a power of two >= 1024)
-        static const uint32_t hs_env = [] { const char *e = getenv("KDB_VIS_HASH"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t hs_env = [] { const char *e = KDB_AB_ENV("KDB_VIS_HASH"); return e ? (uint32_t)atoi(e) : 0u; }();
         if (hs_env >= 1024u && (hs_env & (hs_env - 1u)) == 0u) hsize = hs_env;
     }
     const size_t lds1 = lds_common + (hsize ? (size_t)hsize * 4 : KDB_UP_MARK_CAP * 4);
@@ -363,7 +363,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // moves in as search workgroups leave.  The search kernel is launched FIRST: if the two streams share a hardware queue the
         // pass simply runs behind it, as before.  Small launches (and open ones) keep the pass behind the kernel on the same stream.
         static const uint32_t ov_min_b = [] { const char *e = getenv("KDB_HEAP_OVERLAP_MIN_B"); return e ? (uint32_t)atoi(e) : 4096u; }();
-        static const uint32_t ov_wg = [] { const char *e = getenv("KDB_HEAP_OVERLAP_WG"); return e && atoi(e) >= 0 ? (uint32_t)atoi(e) : 1u; }();
+        static const uint32_t ov_wg = [] { const char *e = KDB_AB_ENV("KDB_HEAP_OVERLAP_WG"); return e && atoi(e) >= 0 ? (uint32_t)atoi(e) : 1u; }();
         bool overlap = false;
         uint32_t raw_l = raw;
         struct OvGuard { // (an error between the reservation and the launch gives the turn back)
@@ -383,7 +383,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
                     // on some CU: the pass waits for the search kernel, never the other way round
                     // ... and never more than KDB_HEAP_OVERLAP_CAP (7) per CU (measured at 1637 tied of 32768: cap 7 8.94 ms, 5 9.32, 3 9.53,
                     // 1 11.8 -- under a search kernel that saturates HBM the walks are slow, most ties are still there when it ends)
-                    static const uint32_t ov_cap = [] { const char *e = getenv("KDB_HEAP_OVERLAP_CAP"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 7u; }();
+                    static const uint32_t ov_cap = [] { const char *e = KDB_AB_ENV("KDB_HEAP_OVERLAP_CAP"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 7u; }();
                     uint32_t per_cu_h = (uint32_t)((lds_room - lds) / hplan.lds);
                     if (per_cu_h > (ov_cap > ov_wg ? ov_cap : ov_wg)) per_cu_h = ov_cap > ov_wg ? ov_cap : ov_wg;
                     const uint32_t h_cap = ncu * per_cu_h;
@@ -471,8 +471,8 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // wave 0 inserts (search_layer_wide); same walk, same results, same counters -- as long as every query gets its own
         // resident workgroup (512 at 768-d float32).  Round 5: the four-slot beam (ef 129 .. 256) too -- with the hash at its
         // ordinary size there (the enlarged one would leave two workgroups per CU)
-        static const int wide_env = [] { const char *e = getenv("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
-        static const int wide2_env = [] { const char *e = getenv("KDB_WIDE2_MAX_B"); return e ? atoi(e) : -1; }();
+        static const int wide_env = [] { const char *e = KDB_AB_ENV("KDB_WIDE_MAX_B"); return e ? atoi(e) : -1; }();
+        static const int wide2_env = [] { const char *e = KDB_AB_ENV("KDB_WIDE2_MAX_B"); return e ? atoi(e) : -1; }();
         if (hsize) {
             const uint32_t hw = BS == 4 ? hsize : hsize_w;
             const size_t wlds = lds1 + 64 + 512 + (size_t)(hw - hsize) * 4;
@@ -496,13 +496,13 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
         // bitset's dependent round trip per hop (atomicOr at the device's coherence point); larger batches keep the bitset, whose
         // eight waves per CU hide more latency than the hash saves.  (The hash still migrates to the bitset if a walk outgrows it.)
         const uint32_t hbig = kdb_vis_hash_size_large(eff);
-        if (hbig && !getenv("KDB_NO_LARGE_HASH")) {
+        if (hbig && !KDB_AB_ENV("KDB_NO_LARGE_HASH")) {
             auto kh = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>;
             const size_t lds_h = lds_common + (size_t)hbig * 4;
             if (lds_h + 16 <= 160 * 1024) {
                 // Round 5: the latency mode for the LDS beam as well (k = 100 / ef = 400 on 1024 queries: every query its own four
                 // waves -- the rows of a hop in one round trip, the visit of the next node beside the one-merge insertion)
-                if (!getenv("KDB_NO_WIDE_LDS_BEAM")) {
+                if (!KDB_AB_ENV("KDB_NO_WIDE_LDS_BEAM")) {
                     const size_t wlds = lds_h + 64 + 512;
                     if (wlds + 16 <= 160 * 1024) {
                         auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 1, 4>;
@@ -521,7 +521,7 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
     }
     if constexpr (BS == 0) { // beyond the large hash (ef > 1040, or a batch too large for it): the latency mode over the HBM bitset --
         // wave 1 owns the bitset, the walker never waits for its atomics
-        if (!getenv("KDB_NO_WIDE_LDS_BEAM")) {
+        if (!KDB_AB_ENV("KDB_NO_WIDE_LDS_BEAM")) {
             const size_t wlds = lds1 + 64 + 512;
             if (wlds + 16 <= 160 * 1024) {
                 auto wk = hnsw_search_kernel<PREC, METRIC, NCH, BS, 0, 4>;

@@ -243,6 +243,50 @@ def test_config5_prefilter_10m_1536(oracle, hip):
     assert np.all(sc == k) and np.isin(si, allowed[c0]).all()
     a, b = int(offs[0]), int(offs[1])                                      # the queries that carry this very list
     assert np.array_equal(si[a:b], gi[a:b]) and np.array_equal(sd[a:b].view(np.uint32), gd[a:b].view(np.uint32))
+    # ---- the HNSW half of config 5 (round 6): the FILTERED WALK on this very table -- the reference skips non-allowed neighbours
+    #      while it traverses (hnsw_index.go:2545-2549).  Graph built on the GPU over the 10M x 1536 rows, graph + rows downloaded,
+    #      16 walks at ef 100 (two-slot register beam) and ef 400 (LDS beam; large LDS hash migrating to the HBM bitset for the small
+    #      batch, the bitset alone for 1024 queries) with a 50 % and a 10 % list: ids, distance bits, n_dist and n_hops of the oracle, in
+    #      three launch geometries.  (Round 5 left this walk unpinned after a build with one more live register changed its answers:
+    #      a spilled helper-wave index reloaded under an empty exec mask, DESIGN 5.1 -- this is the shape that showed it.)
+    idx.build(n, batch=16384, ef_construction=200, seed=9)
+    cnt_, e_, ml_, levels_, goffs_, nbrs_ = idx.download_graph()
+    rows = np.zeros((n + 1, dim), dtype=np.float32)
+    for s in range(0, n, CHUNK):
+        rows[s + 1:s + 1 + CHUNK] = idx.download_rows(s + 1, CHUNK)
+    og = O.Graph(cnt_, levels_, ml_, e_, goffs_, nbrs_, np.zeros((cnt_ >> 6) + 1, dtype=np.uint64))
+    orc = O.OracleIndex.from_graph(dim, O.COSINE, O.F32, 16, 200, rows, og)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    q16 = Q[:16].cpu().numpy()
+    gm = torch.Generator(device=dev)
+    gm.manual_seed(43)
+    walks = 0
+    for frac in (0.5, 0.1):
+        mask = torch.rand(n + 1, device=dev, generator=gm) < frac
+        mask[0] = False
+        abh = dense_bitset(torch.nonzero(mask).flatten().cpu().numpy().astype(np.uint32), n)
+        abd = torch.from_numpy(abh.view(np.int64)).to(dev)
+        for ef in (100, 400):
+            want = [orc.search(q16[b], k, allow=abh, ef=ef, counters=True) for b in range(16)]
+            idx.poison_lds(0x5a5a5a5a if ef == 100 else 0x01010101)   # FINITE garbage in every CU's LDS (a stale slot then reads as a plausible key)
+            ids, dist, cn, (nd, nh) = idx.search_batch(q16, k, ef, allow_bits=abh, trace=True)       # 16 queries: four waves per query
+            big = _outs(B, k, dev)
+            idx.search_batch_dev(Q, k, ef, *big, d_allow=abd)                                          # 1024 queries
+            huge = _outs(8192, k, dev)
+            idx.search_batch_dev(Q[:16].repeat(512, 1), k, ef, *huge, d_allow=abd)                     # 8192: one wave per query
+            idx.sync()
+            bi, bd, bc = _np(big)
+            hi_, hd_, hc_ = _np(huge)
+            for b in range(16):
+                oi_, od_, (ond, onh) = want[b]
+                c = int(cn[b])
+                assert c == len(oi_) and np.array_equal(ids[b, :c], oi_), (frac, ef, b)
+                assert np.array_equal(1.0 - dist[b, :c].astype(np.float64), od_), (frac, ef, b)
+                assert (int(nd[b]), int(nh[b])) == (ond, onh), (frac, ef, b)
+                assert int(bc[b]) == c and np.array_equal(bi[b, :c], oi_) and np.array_equal(bd[b, :c].view(np.uint32), dist[b, :c].view(np.uint32)), (frac, ef, b, "1024-query batch")
+                assert np.array_equal(hi_[b + 16 * 7, :c], oi_) and np.array_equal(hi_[b + 16 * 511, :c], oi_), (frac, ef, b, "8192-query batch")
+                walks += 1
+    print(f"config 5: {walks} filtered walks at 10M x 1536 (50 % / 10 % lists, ef 100 / 400): bit-exact vs the oracle incl. n_dist / n_hops, three launch geometries")
 
 
 def test_config4_one_shard_12m5(oracle, hip):

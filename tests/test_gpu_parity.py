@@ -711,6 +711,7 @@ def test_filtered_walks_on_every_beam_and_visited_set(oracle, hip, ef, shape):
         allowed = allowed[allowed >= 1]
         ab = dense_bitset(allowed, n)
         want = [orc.search(Q[b], k, allow=ab, ef=ef, counters=True) for b in range(Q.shape[0])]
+        idx.poison_lds(0x5a5a5a5a if frac == 0.5 else 0x01010101)   # FINITE garbage in every CU's LDS: a slot nobody wrote reads as a plausible key / id
         for reps in (1, 40, 200, 700):   # 12 / 480 / 2400 / 8400 queries: every launch geometry of launch_search_bs
             Qb = np.tile(Q, (reps, 1))
             ids, dist, cnt, (nd, nh) = idx.search_batch(Qb, k, ef, allow_bits=ab, trace=True)
