@@ -99,21 +99,28 @@ __device__ __forceinline__ int kdb_wave_sum_i(int v) {
 // Two rows at once (f32, ld == 64*NCH): all 2*NCH row loads are issued before the first FMA, so a hop with 5-8 new
 // neighbours costs ONE HBM round trip instead of two; every query fragment is read from LDS once for both rows.
 // Per row the accumulation order is exactly that of kdb_row_partial_f32.
+// NCH == 2 also serves rows of 17 .. 32 sixteen-byte pieces (65 .. 128 columns: GloVe-100's 112): `np` = the row's pieces; a lane
+// whose second piece lies past the end takes zeros for row AND query there -- fma(0, 0, a) == a exactly, so the accumulation is the
+// any-width path's (which skips the piece), bit for bit.
+template <int NCH>
+__device__ __forceinline__ bool kdb_piece_ok(int t, int i, uint32_t np) { return NCH != 2 || i == 0 || (uint32_t)(t + 16) < np; }
+__device__ __forceinline__ float4 kdb_ld4_or_zero(const float4 *p, bool ok) { return ok ? *p : make_float4(0.f, 0.f, 0.f, 0.f); }
+
 template <int METRIC, int NCH>
 __device__ __forceinline__ void kdb_row_partial2_f32(const float *__restrict__ row0, const float *__restrict__ row1,
-                                                     const float *q, int t, float &p0, float &p1) {
+                                                     const float *q, int t, float &p0, float &p1, uint32_t np = 0xffffffffu) {
     const float4 *r0 = reinterpret_cast<const float4 *>(row0);
     const float4 *r1 = reinterpret_cast<const float4 *>(row1);
     const float4 *q4 = reinterpret_cast<const float4 *>(q);
     float4 x0[NCH], x1[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; i++) x0[i] = r0[t + 16 * i];
+    for (int i = 0; i < NCH; i++) x0[i] = kdb_ld4_or_zero(r0 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
 #pragma unroll
-    for (int i = 0; i < NCH; i++) x1[i] = r1[t + 16 * i];
+    for (int i = 0; i < NCH; i++) x1[i] = kdb_ld4_or_zero(r1 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
-        const float4 y = q4[t + 16 * i];
+        const float4 y = kdb_ld4_or_zero(q4 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
         if (METRIC == KDB_METRIC_L2) {
             float d0 = y.x - x0[i].x, d1 = y.y - x0[i].y, d2 = y.z - x0[i].z, d3 = y.w - x0[i].w;
             a0 = __builtin_fmaf(d0, d0, a0);
@@ -142,19 +149,19 @@ __device__ __forceinline__ void kdb_row_partial2_f32(const float *__restrict__ r
 
 // R rows at once (generalises kdb_row_partial2_f32): R*NCH loads in flight, per row the same accumulation order.
 template <int METRIC, int NCH, int R>
-__device__ __forceinline__ void kdb_row_partialR_f32(const float *const (&rows)[R], const float *q, int t, float (&p)[R]) {
+__device__ __forceinline__ void kdb_row_partialR_f32(const float *const (&rows)[R], const float *q, int t, float (&p)[R], uint32_t np = 0xffffffffu) {
     const float4 *q4 = reinterpret_cast<const float4 *>(q);
     float4 x[R][NCH];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int i = 0; i < NCH; i++) x[r][i] = reinterpret_cast<const float4 *>(rows[r])[t + 16 * i];
+        for (int i = 0; i < NCH; i++) x[r][i] = kdb_ld4_or_zero(reinterpret_cast<const float4 *>(rows[r]) + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
     float a[R][4];
 #pragma unroll
     for (int r = 0; r < R; r++) a[r][0] = a[r][1] = a[r][2] = a[r][3] = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
-        const float4 y = q4[t + 16 * i];
+        const float4 y = kdb_ld4_or_zero(q4 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (METRIC == KDB_METRIC_L2) {
@@ -232,11 +239,12 @@ __device__ __forceinline__ float kdb_row_partial_f32(const float *__restrict__ r
         // ld == 64*NCH known at compile time: every 16-byte load of the row is issued before the first
         // FMA (one HBM round trip per 4-row pass instead of NCH/4).  Same accumulation order as below.
         float4 x[NCH > 0 ? NCH : 1];
+        const uint32_t np = ld >> 2;
 #pragma unroll
-        for (int i = 0; i < NCH; i++) x[i] = r4[t + 16 * i];
+        for (int i = 0; i < NCH; i++) x[i] = kdb_ld4_or_zero(r4 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const float4 y = q4[t + 16 * i];
+            const float4 y = kdb_ld4_or_zero(q4 + t + 16 * i, kdb_piece_ok<NCH>(t, i, np));
             if (METRIC == KDB_METRIC_L2) {
                 float d0 = y.x - x[i].x, d1 = y.y - x[i].y, d2 = y.z - x[i].z, d3 = y.w - x[i].w;
                 a0 = __builtin_fmaf(d0, d0, a0);

@@ -136,7 +136,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                     rows[r] = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
                 }
                 float p[R];
-                kdb_row_partialR_f32<METRIC, NCH, R>(rows, s.q, t, p);
+                kdb_row_partialR_f32<METRIC, NCH, R>(rows, s.q, t, p, v.ld >> 2);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const float key = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p[r]));
@@ -148,7 +148,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                 const uint32_t id0 = s.nb_id[r0], id1 = r1 < n ? s.nb_id[r1] : 0u;
                 float p0, p1;
                 kdb_row_partial2_f32<METRIC, NCH>(reinterpret_cast<const float *>(v.rows) + (size_t)id0 * v.ld,
-                                                  reinterpret_cast<const float *>(v.rows) + (size_t)id1 * v.ld, s.q, t, p0, p1);
+                                                  reinterpret_cast<const float *>(v.rows) + (size_t)id1 * v.ld, s.q, t, p0, p1, v.ld >> 2);
                 const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p0));
                 const float k1 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p1));
                 if (t == 0) s.nb_d[r0] = kdb_sane_key(k0);
@@ -1478,6 +1478,9 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
     }
     const uint32_t deg = level == 0 ? v.deg0 : v.deg_up;
+    // (Tried in round 6 and dropped: requesting the NEXT node's neighbour list before the insertion, as search_layer_wide does -- the
+    // prediction's ~40 instructions cost the one-wave walk what the hidden latency saved: 400k x 100-d ef 100 0.937 -> 0.987 ms, SIFT-shaped
+    // rows 1.409 -> 1.447, 768-d unchanged.)
     KDB_T(const unsigned long long tq_layer = __builtin_readcyclecounter();)
     for (;;) {
         KDB_T(const unsigned long long tq_a = __builtin_readcyclecounter();)

@@ -422,7 +422,7 @@ KDB_DECL_INST(1, 0, 0) KDB_DECL_INST(2, 1, 0)
 int kdb_launch_search(KDB_LAUNCH_SEARCH_PARAMS) {
     if (v.precision == KDB_PREC_F32) { // common row widths get fully unrolled row loads (NCH = ld/64): group 0 = 128..512, 1 = 768 / 1024, 2 = 1536 + any other
         static const bool force_generic = KDB_AB_ENV("KDB_SEARCH_GENERIC") != nullptr; // measurement knob
-        const int g = force_generic ? 2 : (v.ld == 128 || v.ld == 256 || v.ld == 384 || v.ld == 512) ? 0 : (v.ld == 768 || v.ld == 1024) ? 1 : 2;
+        const int g = force_generic ? 2 : ((v.ld > 64 && v.ld <= 128) || v.ld == 256 || v.ld == 384 || v.ld == 512) ? 0 : (v.ld == 768 || v.ld == 1024) ? 1 : 2;
         if (v.metric == KDB_METRIC_L2) return g == 0 ? kdb_launch_search_inst_0_0_0(KDB_LAUNCH_SEARCH_ARGS) : g == 1 ? kdb_launch_search_inst_0_0_1(KDB_LAUNCH_SEARCH_ARGS) : kdb_launch_search_inst_0_0_2(KDB_LAUNCH_SEARCH_ARGS);
         if (v.metric == KDB_METRIC_COSINE) return g == 0 ? kdb_launch_search_inst_0_1_0(KDB_LAUNCH_SEARCH_ARGS) : g == 1 ? kdb_launch_search_inst_0_1_1(KDB_LAUNCH_SEARCH_ARGS) : kdb_launch_search_inst_0_1_2(KDB_LAUNCH_SEARCH_ARGS);
     }

@@ -10,8 +10,8 @@ int KDB_CAT4(kdb_launch_search_inst_, KDB_INST_PREC, KDB_INST_METRIC, KDB_INST_G
     (void)force_generic;
 #if KDB_INST_PREC == 0
 #if KDB_INST_GROUP == 0
+    if (v.ld <= 128) return launch_search_t<KDB_PREC_F32, KDB_INST_METRIC, 2>(KDB_LAUNCH_SEARCH_ARGS); // 65 .. 128 columns (kdb_piece_ok)
     switch (v.ld) {
-    case 128: return launch_search_t<KDB_PREC_F32, KDB_INST_METRIC, 2>(KDB_LAUNCH_SEARCH_ARGS);
     case 256: return launch_search_t<KDB_PREC_F32, KDB_INST_METRIC, 4>(KDB_LAUNCH_SEARCH_ARGS);
     case 384: return launch_search_t<KDB_PREC_F32, KDB_INST_METRIC, 6>(KDB_LAUNCH_SEARCH_ARGS);
     default: return launch_search_t<KDB_PREC_F32, KDB_INST_METRIC, 8>(KDB_LAUNCH_SEARCH_ARGS);

@@ -123,6 +123,38 @@ def test_search_bit_exact_vs_oracle(oracle, hip, metric, law, n, dim, ef):
         assert_same_results_tol(ids[b, :int(cnt[b])], raw_to_score(idx, dist[b, :int(cnt[b])]), oi, od)
 
 
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("dim", [64, 72, 100, 128, 200])
+def test_short_rows_of_the_published_shapes(oracle, hip, metric, dim):
+    """The reference publishes 100 / 128 / 200 / 300-d numbers only (BENCHMARKS.md:31-70).  Rows of 65 .. 128 columns take the unrolled
+    two-piece kernel since round 6 (a lane whose second 16-byte piece lies past the row's end takes zeros for row and query: the
+    any-width path's accumulation, bit for bit), 64 and 200 columns the any-width kernel: ids, distance bits, n_dist, n_hops AND the
+    tie flag of the oracle at efSearch 20 / 100 (one- and two-slot beams), in the four-wave, two-wave and one-wave launch geometries;
+    duplicates in the corpus so that some walks do meet equal distances (those are walked in heap order)."""
+    O = oracle
+    n = 3000
+    X = make_corpus(n, dim, "clustered", seed=300 + dim)
+    X[np.random.default_rng(1).choice(n, 30, replace=False)] = X[5]
+    orc, idx = build_pair(O, hip, X, metric, efc=80)
+    orc.set_arith(O.ARITH_HIP_WAVE)
+    Q = np.concatenate([X[:6], make_corpus(34, dim, "clustered", seed=301 + dim)])
+    k = 10
+    for ef in (20, 100):
+        want = [orc.search(Q[b], k, ef=ef, counters=True) for b in range(Q.shape[0])]
+        for reps in (1, 30, 220):   # 40 / 1200 / 8800 queries
+            Qb = np.tile(Q, (reps, 1))
+            ids, dist, cnt, (nd, nh) = idx.search_batch(Qb, k, ef, trace=True, heap_order=True, tie_flag=True)
+            assert not np.any(cnt & hip.index.COUNT_TIED)   # heap order resolved every tie
+            for b in list(range(40)) + list(range(Qb.shape[0] - 40, Qb.shape[0])):
+                oi, od, (ond, onh) = want[b % 40]
+                c = int(cnt[b])
+                assert c == len(oi) and np.array_equal(ids[b, :c], oi), (dim, ef, reps, b)
+                assert np.array_equal(raw_to_score(idx, dist[b, :c]), od), (dim, ef, reps, b)
+                assert (int(nd[b]), int(nh[b])) == (ond, onh), (dim, ef, reps, b)
+        plain = idx.search_batch(Q, k, ef, tie_flag=True)
+        assert np.any(plain[2] & hip.index.COUNT_TIED)      # ... and some walks did meet equal distances
+
+
 def test_search_self_match_first(oracle, hip):
     # pkg/client/client_test.go:171-236: 100x16 uniform, euclidean, m=8 efC=20; a stored vector ranks itself
     # first at ef=12 and ef=100
