@@ -458,17 +458,22 @@ __device__ uint32_t heap_layer(const KdbView &v, const WaveLds &s, VisT &vis, Re
 // (measured: passes that saw the previous launch's `closed` and left at once).
 __device__ __forceinline__ uint32_t heap_rmw_read(uint32_t *p) { return atomicAdd(p, 0u); }
 __device__ __forceinline__ uint32_t heap_wait_ticket(uint32_t *tie_list, uint32_t w) {
-    const unsigned long long t0 = wall_clock64(); // 100 MHz
+    // "without news" = the list did not GROW for 10 ms (round 5: one second since the wait began -- two processes on one GPU, each with
+    // a pass waiting for a search kernel the other's kernels kept off the CUs, paid 1.02 s per such call; now 10 ms, and a pass that
+    // only waits long because its ticket is far down a list that keeps growing is not mistaken for a stalled one)
+    unsigned long long t0 = wall_clock64(); // 100 MHz
     uint32_t r = 0xfffffffeu;
     if (kdb_lane() == 0) {
+        uint32_t last = 0xffffffffu;
         for (;;) {
             const uint32_t closed = heap_rmw_read(tie_list + 2);
             asm volatile("" ::"v"(closed) : "memory"); // (closed is read BEFORE the count it makes final)
             const uint32_t cnt = heap_rmw_read(tie_list);
             if (w < cnt) {
                 uint32_t e;
+                const unsigned long long t1 = wall_clock64();
                 do e = heap_rmw_read(tie_list + 4u + w);
-                while (e == 0xffffffffu && wall_clock64() - t0 < 100000000ull);
+                while (e == 0xffffffffu && wall_clock64() - t1 < 1000000ull);
                 r = e == 0xffffffffu ? 0xfffffffeu : e;
                 break;
             }
@@ -476,7 +481,11 @@ __device__ __forceinline__ uint32_t heap_wait_ticket(uint32_t *tie_list, uint32_
                 r = 0xffffffffu;
                 break;
             }
-            if (wall_clock64() - t0 > 100000000ull) break;
+            if (cnt != last) {
+                last = cnt;
+                t0 = wall_clock64();
+            }
+            if (wall_clock64() - t0 > 1000000ull) break;
             __builtin_amdgcn_s_sleep(64);
         }
     }

@@ -399,6 +399,10 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
                     }
                 }
             }
+            // (Round 6 tried the pass BESIDE the kernel for open launches too -- 16 workgroups on the side stream taking tied queries as
+            // tickets while the launch still accepts callers.  64 one-query callers with the flag: 172 k QPS / p99 1.10 ms before,
+            // 141 k / 1.11 with it: a tied query's latency is its heap-order WALK (0.3 - 1.2 ms, long walks tie), not the wait for the
+            // launch to close, and three launches + two memsets per open launch cost the launching thread more than they saved.)
             const size_t list_bytes = (((size_t)B + 4u) * 4u + 255u) & ~(size_t)255u;
             hplan.tail_bytes = ((size_t)hplan.grid * (size_t)(hplan.cap_c - hplan.nl_c) * 12u + 255u) & ~(size_t)255u;
             rc0 = kdb_ensure_tie_scratch(idx, list_bytes + hplan.tail_bytes + 256u + (overlap ? KdbTieStash::bytes(B, k) : 0u));
