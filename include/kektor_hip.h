@@ -53,9 +53,13 @@
  *     product for KDB_METRIC_COSINE (f32), the f64-scaled cosine distance for int8.  The shim applies
  *     the reference's f64 epilogue -- float64(sum) (distance_go.go:67) or 1.0-float64(dot)
  *     (distance_go.go:127) -- when it fills types.SearchResult.Score (pkg/core/types/types.go:12-15).
- *   - queries and stored rows hold FINITE values: a NaN or an infinity makes every comparison of a walk false and can fault the
- *     device for every caller of the process (the reference compares such distances like any other); the mirrors check a query
- *     before the call (kektor_hip.hpp AllFinite, integration/go searchHIP) -- DESIGN.md 5.1, an open item;
+ *   - values that are not finite cannot hurt anybody else's call.  A graph-search query with a NaN or an infinity among its
+ *     components is answered with NO results (out_count 0 -- the reference's "log and return an empty slice" for a search that
+ *     fails, hnsw_index.go:356-359; the reference itself compares the NaN distances that follow like any others and returns
+ *     whatever its heaps then hold: nothing to be bit-exact with) and never walks; the other queries of the batch -- and of a
+ *     launch it was combined into -- are answered bit for bit as alone.  A stored row that yields a distance that is not a
+ *     number is "infinitely far" in a walk, never nearer than anything.  Every node id is range-checked before a row or list
+ *     address is formed from it;
  *   - there is NO CPU fallback: every compute entry point fails with KDB_ERR_NO_DEVICE when no gfx950
  *     device is visible.
  */

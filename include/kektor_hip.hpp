@@ -37,7 +37,8 @@ struct Error : std::runtime_error {
 };
 
 // types.SearchResult (pkg/core/types/types.go:12-15)
-// queries must be finite (the kernels' contract): exponent all ones = NaN or infinity
+// a query that is not finite gets no results (the library answers it with count 0 as well; checked here so that the caller's log
+// line is the reference's, hnsw_index.go:356-359): exponent all ones = NaN or infinity
 inline bool AllFinite(const float *x, size_t n) {
     for (size_t i = 0; i < n; i++) {
         uint32_t u;
@@ -126,7 +127,7 @@ class Index {
                                                int efSearch) const {
         std::vector<SearchResult> out;
         if (!h_ || k <= 0 || query.size() != dim_) return out;
-        if (!AllFinite(query.data(), query.size())) return out; // (the kernels' contract: a NaN query can fault the GPU -- DESIGN 5.1)
+        if (!AllFinite(query.data(), query.size())) return out; // (the library would answer it with count 0 too: kdb_load_query)
         std::vector<uint32_t> ids((size_t)k), cnt(1);
         DistBuf dist((size_t)k, wide());
         int rc = kdb_search_batch(h_, query.data(), 1, (uint32_t)k, (uint32_t)(efSearch > 0 ? efSearch : 0),

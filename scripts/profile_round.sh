@@ -12,6 +12,7 @@ O=$R/gpurun_out
 rm -rf $O/prof_$TAG $O/fsq_$TAG $O/fsf_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o bench -- python $R/bench.py --no-extras --no-cpu > $O/bench_prof_$TAG.json 2> $O/bench_prof_$TAG.log
 timeout 1500 python $R/bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.log
+cp $O/bench_extras.json $O/bench_${TAG}_extras.json
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --kernel-trace -d $O/fsq_$TAG -o p -- python $R/scripts/flat_probe.py --bs 8192 --reps 2 > /tmp/fsq.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fsf_$TAG -o p -- python $R/scripts/flat_probe.py --bs 8192 --reps 2 > /tmp/fsf.log 2>&1
 python3 $R/scripts/prof_summary.py $(ls $O/prof_$TAG/*.db $O/prof_$TAG/*/*.db 2>/dev/null | head -1) > $O/${TAG}_bench_rocprofv3_summary.txt
@@ -21,7 +22,9 @@ print("# command under the tracer: rocprofv3 --kernel-trace --stats -- python be
 try:
     d = json.loads(open("$O/bench_$TAG.json").read().strip().splitlines()[-1])
     print("# plain run of the same box (python bench.py): value %.0f %s, ms_per_step %.4f, roofline %s" % (d["value"], d["unit"], d["ms_per_step"], json.dumps(d["roofline"])))
-    print("# flat-scan leg:", json.dumps(d.get("flat_scan_leg")))
+    print("# legs (compact line):", json.dumps(d.get("legs")))
+    full = json.loads(open("$O/bench_extras.json").read())   # the full record of the same run (bench.py emit)
+    print("# flat-scan leg:", json.dumps(full.get("flat_scan_leg")))
 except Exception as e:
     print("# bench json unreadable:", e)
 for d in ("fsq_$TAG", "fsf_$TAG"):
