@@ -24,7 +24,7 @@ for case in range(n_cases):
         n = int(rng.choice([1, 2, 9, 300, 3000])); dim = int(rng.choice([1, 3, 7, 33, 128, 1000]))
         k = int(rng.choice([1, 10, 200])); ef = int(rng.choice([0, 1, 64, 110, 111, 400, 2000])); B = int(rng.choice([1, 5, 70]))
     else:
-        n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 100, 128, 256, 384, 512, 768]))
+        n = int(rng.choice([200, 1500, 4000])); dim = int(rng.choice([8, 48, 72, 100, 128, 256, 384, 512, 768, 1024, 1536]))
         k = int(rng.choice([1, 10, 50])); ef = int(rng.choice([0, 5, 40, 120, 300, 500])); B = int(rng.choice([1, 7, 40]))
     X = rng.random((n, dim), dtype=np.float32) if rng.random() < 0.5 else rng.standard_normal((n, dim)).astype(np.float32)
     if case % 3 == 2 and n >= 9:  # duplicates: 2..40 copies of a few rows, the queries next to them
@@ -81,7 +81,18 @@ for case in range(n_cases):
         ok &= bool(good)
         if only is not None and not good:
             print("  q", b, "got", ids[b, :c], got_d, None if nd is None else (int(nd[b]), int(nh[b])), "want", wi, wd, (ond, onh))
-    print(f"case {case}: ndel={n_del} prec={prec} metric={metric} n={n} dim={dim} m={orc.m} k={k} ef={ef} B={B} mode={mode} tie-queries={ties} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    # round 6: the same queries in the other launch geometries (two waves per query, one wave with the LDS hash, one wave over the
+    # HBM bitset): a query's answer and counters must not depend on the batch it arrives in
+    geo = ""
+    if mode < 2 and ok and not wide:
+        for reps in (int(rng.choice([20, 40])), int(rng.choice([150, 260]))):
+            Qb = np.tile(Q, (reps, 1))
+            i2, d2, c2, (nd2, nh2) = idx.search_batch(Qb, k, ef, allow_bits=allow, trace=True, dist64=(prec == O.I8), tie_flag=True, heap_order=True)
+            for sl in (slice(0, B), slice(Qb.shape[0] - B, Qb.shape[0])):
+                same = np.array_equal(i2[sl], ids) and np.array_equal(d2[sl].view(np.uint8), dist.view(np.uint8)) and np.array_equal(c2[sl], cnt) and np.array_equal(nd2[sl], nd) and np.array_equal(nh2[sl], nh)
+                ok &= bool(same)
+            geo += f" x{reps}"
+    print(f"case {case}: ndel={n_del} prec={prec} metric={metric} n={n} dim={dim} m={orc.m} k={k} ef={ef} B={B} mode={mode} tie-queries={ties} geometries{geo} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
     del idx
 print("mismatching cases:", bad)
