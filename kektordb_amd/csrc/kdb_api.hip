@@ -1160,7 +1160,7 @@ void kdb_close_session(kdb_index *idx) { // under mu
 // calls that never join a launch -- filtered, large, traced -- used to leave it to the next joinable caller)
 static void close_expired_session(kdb_index *idx) {
     kdb_group *os = idx->open_session;
-    if (os && now_ns() - os->t_launch_ns > (uint64_t)session_us() * 1000ull) kdb_close_session(idx);
+    if (os && now_ns() - os->t_launch_ns.load(std::memory_order_relaxed) > (uint64_t)session_us() * 1000ull) kdb_close_session(idx);
 }
 
 static void group_fail(kdb_group *g, int rc) {
@@ -1284,7 +1284,7 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
         // waiting: a query that met equal distances (KDB_SEARCH_HEAP_ORDER) is answered by the pass BEHIND the search kernel, which
         // ends only when the launch is closed; with nobody else calling, its own watcher must do it (it used to wait out the
         // workgroups' 0.5 s safety: one lone call in thirty took half a second with the flag the mirrors set)
-        if (__atomic_load_n(&g->open, __ATOMIC_RELAXED) && g->launched.load(std::memory_order_acquire) && now_ns() - g->t_launch_ns > sess_ns) {
+        if (g->open.load(std::memory_order_relaxed) && g->launched.load(std::memory_order_acquire) && now_ns() - g->t_launch_ns.load(std::memory_order_relaxed) > sess_ns) {
             std::lock_guard<std::mutex> lk(idx->mu);
             if (idx->open_session == g) kdb_close_session(idx);
         }
@@ -1318,7 +1318,7 @@ static int watch_done_words(kdb_index *idx, kdb_group *g, uint32_t off, uint32_t
     idx->n_naps.fetch_add(naps, std::memory_order_relaxed);
     if (rc == KDB_OK) { // running estimate (1/8 weights) of what a caller waits, for the next watcher's first sleep
         const uint64_t t1 = now_ns(), el = t1 - t0;
-        const uint64_t tl = g->t_launch_ns;
+        const uint64_t tl = g->t_launch_ns.load(std::memory_order_relaxed);
         idx->n_combined_calls.fetch_add(1u, std::memory_order_relaxed);
         idx->ns_to_launch.fetch_add(tl > t0 ? tl - t0 : 0u, std::memory_order_relaxed);
         idx->ns_launch_to_done.fetch_add(tl > t0 ? t1 - tl : el, std::memory_order_relaxed);
@@ -1337,7 +1337,7 @@ static int combined_search_call(kdb_index *idx, const float *queries, uint32_t B
     kdb_group *g = nullptr;
     uint32_t off = 0;
     if (kdb_group *os = idx->open_session) { // a launch that still accepts queries: write mine into its buffer, publish the count
-        if (now_ns() - os->t_launch_ns > (uint64_t)session_us() * 1000ull || idx->writers_waiting) {
+        if (now_ns() - os->t_launch_ns.load(std::memory_order_relaxed) > (uint64_t)session_us() * 1000ull || idx->writers_waiting) {
             kdb_close_session(idx);
         } else if (os->k == k && os->ef == ef && os->flags == flags && os->nq + B <= os->cap_q && !os->failed.load(std::memory_order_relaxed)) {
             g = os;

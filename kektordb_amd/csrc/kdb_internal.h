@@ -106,11 +106,11 @@ struct kdb_group {
     uint32_t gen = 0;                            // value of a completion word that means "done" for THIS use of the group object
     uint32_t *h_done = nullptr;                  // KDB_GROUP_CAP completion words, page-locked (written by the kernels)
     uint32_t *h_ctl = nullptr;                   // the session word of an open launch, page-locked (written here, read by the kernel)
-    bool open = false;                           // launched and still accepting queries (idx->open_session == this)
+    std::atomic<bool> open{false};               // launched and still accepting queries (idx->open_session == this); written under idx->mu, read by watchers outside it
     uint32_t cap_q = 0;                          // queries the launch has room for (layout of the slot's buffer)
     std::atomic<uint32_t> launched{0};           // set (release) by the launching thread once the fields below are valid
     std::atomic<uint32_t> failed{0};             // the launch failed / the device faulted: rc and err say why
-    uint64_t t_launch_ns = 0;
+    std::atomic<uint64_t> t_launch_ns{0};        // (written by the launcher under idx->mu; watchers read it outside the lock)
     struct Member {
         const float *q;
         uint32_t B;
