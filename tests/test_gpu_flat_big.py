@@ -110,31 +110,6 @@ def test_flat_scan_big_tile_seed_launch_on_small_cases(oracle, hip, metric, prec
     _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, B, 5)) + [255, 256, B - 1], prec)
 
 
-@pytest.mark.skipif(not os.environ.get("KEKTOR_HIP_LIB", "").endswith("_ab.so"),
-                    reason="the out-of-phase variant (flat_scan_skew.cuh, measured slower in round 5) is compiled into the A/B build only: "
-                           "make -C kektordb_amd/csrc ab; KEKTOR_HIP_LIB=.../libkektor_hip_ab.so")
-@pytest.mark.parametrize("metric,prec,n,dim,k,B", [(1, 0, 9000, 768, 10, 300), (0, 0, 9000, 256, 10, 520), (0, 1, 9000, 512, 100, 300), (1, 2, 9000, 1024, 10, 300)])
-def test_flat_scan_big_tile_out_of_phase_halves(oracle, hip, metric, prec, n, dim, k, B, monkeypatch):
-    """flat_scan_skew.cuh (KDB_FB_SKEW=1): the same tile kernel with its two row halves half a tile apart -- a schedule, measured
-    slower and therefore opt-in, but it must rank exactly like the in-step kernel: ids and distance bits of the oracle's exact scan,
-    and the answers of the default kernel, with the seed launch forced on and off (rows of 4 / 8 / 12 slabs, f32 / f16 / int8)."""
-    O = oracle
-    X = make_corpus(n, dim, "normal", seed=171)
-    if prec == O.F16:
-        X = X * 0.5
-    orc, idx = _pair(O, hip, X, metric, prec)
-    Q = make_corpus(B, dim, "normal", seed=172)
-    base = idx.flat_scan_batch(Q, k)
-    for seed_tiles in ("1", "1000000"):
-        monkeypatch.setenv("KDB_FB_SEED_MIN_TILES", seed_tiles)
-        monkeypatch.setenv("KDB_FB_SKEW", "1")
-        ids, dist, cnt = idx.flat_scan_batch(Q, k)
-        monkeypatch.delenv("KDB_FB_SKEW")
-        assert np.array_equal(ids, base[0]) and np.array_equal(dist, base[1]) and np.array_equal(cnt, base[2])
-        _check(O, orc, idx, Q, k, ids, dist, cnt, list(range(0, B, 11)) + [B - 1], prec)
-
-
-
 @pytest.mark.parametrize("metric", [1, 0])
 @pytest.mark.parametrize("case", ["near_duplicates", "dense_block"])
 def test_flat_scan_big_tile_band(oracle, hip, metric, case):
