@@ -838,7 +838,18 @@ struct LdsBeamT {
         return -1;
     }
     __device__ __forceinline__ uint32_t second_pending() const { return 0u; }
-    __device__ __forceinline__ uint32_t first_pending() const { return 0u; }
+    // id of the first un-expanded entry at or behind scan_from (0 = none): the latency mode's hint for wave 1 -- the node the walk pops
+    // after the one in work if nothing nearer turns up.  (Round 6: the LDS beam used to give no hint, so every hop of a large-ef walk
+    // waited for its neighbour list: timers build, ef 400: wave 1's visit 2200 cycles per hop, hint hits 0.)
+    __device__ __forceinline__ uint32_t first_pending() const {
+        for (uint32_t base = scan_from; base < count; base += 64) {
+            const uint32_t i = base + (uint32_t)kdb_lane();
+            const bool f = i < count && !(bi[i] & KDB_F_EXPANDED);
+            const unsigned long long m = __ballot(f);
+            if (m) return uni(bi[base + (uint32_t)__builtin_ctzll(m)]) & KDB_ID_MASK;
+        }
+        return 0u;
+    }
     __device__ __forceinline__ void insert(float dd, uint32_t dlo, uint32_t idf) {
         const int lane = kdb_lane();
         const uint32_t idm = idf & KDB_ID_MASK;
