@@ -1322,15 +1322,50 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
                 }
             }
             wave_lds_fence();
-            uint32_t lo = 0u, hi = in_pass ? m : 0u;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const float e = b.bd[mid];
-                const uint32_t elo = WK ? b.bl[mid] : 0u;
-                if (key_lt<WK>(e, elo, my_d, my_lo)) lo = mid + 1u;
-                else hi = mid;
+            uint32_t lo = 0u;
+            const uint32_t nchunk = (m + 63u) >> 6;
+            if (m > 256u && nchunk <= 64u) {
+                // Long beams (round 6): a per-lane binary search is log2(m) DEPENDENT LDS round trips (11 at ef 1600, ~1400 cycles on
+                // wave 0's critical path there).  Two levels instead, the whole wave on one candidate at a time: lane c holds the LAST key
+                // of 64-entry chunk c (one LDS read for all candidates); a ballot says how many chunks lie wholly below the candidate, a
+                // second ballot over that one chunk gives the position inside it -- the same lower bound, and an equal key, if there is
+                // one, sits at it (inside this chunk: its last key is not below the candidate).
+                const uint32_t si = (uint32_t)lane * 64u + 63u < m ? (uint32_t)lane * 64u + 63u : m - 1u;
+                const bool sv = (uint32_t)lane < nchunk;
+                const float sd = sv ? b.bd[si] : 0.f;
+                const uint32_t sl = (WK && sv) ? b.bl[si] : 0u;
+                for (unsigned long long rest = pass; rest;) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    const float cd = readlane_f(my_d, j);
+                    const uint32_t clo = WK ? readlane_u(my_lo, j) : 0u;
+                    const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(sv && key_lt<WK>(sd, sl, cd, clo)));
+                    uint32_t lj = m;
+                    bool tj = false;
+                    if (c < nchunk) {
+                        const uint32_t i = c * 64u + (uint32_t)lane;
+                        const bool in = i < m;
+                        const float e = in ? b.bd[i] : 0.f;
+                        const uint32_t el = (WK && in) ? b.bl[i] : 0u;
+                        lj = c * 64u + (uint32_t)__builtin_popcountll(__ballot(in && key_lt<WK>(e, el, cd, clo)));
+                        tj = __ballot(in && key_eq<WK>(e, el, cd, clo)) != 0ull;
+                    }
+                    if ((uint32_t)lane == j) {
+                        lo = lj;
+                        tie = tie || tj;
+                    }
+                }
+            } else {
+                uint32_t hi = in_pass ? m : 0u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const float e = b.bd[mid];
+                    const uint32_t elo = WK ? b.bl[mid] : 0u;
+                    if (key_lt<WK>(e, elo, my_d, my_lo)) lo = mid + 1u;
+                    else hi = mid;
+                }
+                if (in_pass && lo < m) tie = tie || key_eq<WK>(b.bd[lo], WK ? b.bl[lo] : 0u, my_d, my_lo);
             }
-            if (in_pass && lo < m) tie = tie || key_eq<WK>(b.bd[lo], WK ? b.bl[lo] : 0u, my_d, my_lo);
             if (__ballot(tie) == 0ull) {
                 uint32_t pmin = m;
                 for (unsigned long long rest = pass; rest;) {
@@ -1339,28 +1374,39 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
                     const uint32_t pj = readlane_u(lo, j);
                     pmin = pj < pmin ? pj : pmin;
                 }
-                for (int top = (int)m - 1; top >= (int)pmin; top -= 64) {
-                    const int i = top - lane;
-                    const bool act = i >= (int)pmin;
-                    float e = 0.f;
-                    uint32_t x = 0u, l = 0u;
-                    if (act) {
-                        e = b.bd[i];
-                        x = b.bi[i];
-                        if (WK) l = b.bl[i];
+                // two 64-entry chunks per step (round 6): both chunks' reads are issued before either is written back -- one LDS round trip
+                // per 128 entries instead of per 64 (LDS operations of a wave execute in order: a read issued before a write sees the old data,
+                // and every entry's target i + sh(i) is strictly increasing in i, so no two writes meet)
+                for (int top = (int)m - 1; top >= (int)pmin; top -= 128) {
+                    int ii[2];
+                    bool act[2];
+                    float e[2] = {0.f, 0.f};
+                    uint32_t x[2] = {0u, 0u}, l[2] = {0u, 0u}, sh[2] = {0u, 0u};
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        ii[u] = top - 64 * u - lane;
+                        act[u] = ii[u] >= (int)pmin;
+                        if (act[u]) {
+                            e[u] = b.bd[ii[u]];
+                            x[u] = b.bi[ii[u]];
+                            if (WK) l[u] = b.bl[ii[u]];
+                        }
                     }
-                    uint32_t sh = 0u;
                     for (unsigned long long rest = pass; rest;) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(rest);
                         rest &= rest - 1ull;
-                        sh += (act && readlane_u(lo, j) <= (uint32_t)i) ? 1u : 0u;
+                        const uint32_t lj = readlane_u(lo, j);
+#pragma unroll
+                        for (int u = 0; u < 2; u++) sh[u] += (act[u] && lj <= (uint32_t)ii[u]) ? 1u : 0u;
                     }
                     wave_lds_fence();
-                    if (act && (uint32_t)i + sh < ef) {
-                        b.bd[(uint32_t)i + sh] = e;
-                        b.bi[(uint32_t)i + sh] = x;
-                        if (WK) b.bl[(uint32_t)i + sh] = l;
-                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        if (act[u] && (uint32_t)ii[u] + sh[u] < ef) {
+                            b.bd[(uint32_t)ii[u] + sh[u]] = e[u];
+                            b.bi[(uint32_t)ii[u] + sh[u]] = x[u];
+                            if (WK) b.bl[(uint32_t)ii[u] + sh[u]] = l[u];
+                        }
                     wave_lds_fence();
                 }
                 const uint32_t place = lo + rank;
