@@ -14,6 +14,9 @@
 #include "kdb_device.cuh"
 #include <math.h>
 
+#ifndef KDB_F32_ROWS2
+#define KDB_F32_ROWS2 4 // rows per 16-lane group and trip for rows of up to 128 columns
+#endif
 #ifndef KDB_F32_ROWS6
 #define KDB_F32_ROWS6 2
 #endif
@@ -122,7 +125,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
     const int lane = kdb_lane();
     const int g = lane >> 4, t = lane & 15;
     if constexpr (PREC == KDB_PREC_F32 && NCH > 0 && NCH <= 16 && KDB_F32_DUAL) { // 4*R rows per round trip
-        constexpr int R0 = NCH <= 2 ? 4 : NCH <= 6 ? KDB_F32_ROWS6 : NCH <= 12 ? KDB_F32_ROWS : 2;
+        constexpr int R0 = NCH <= 2 ? KDB_F32_ROWS2 : NCH <= 6 ? KDB_F32_ROWS6 : NCH <= 12 ? KDB_F32_ROWS : 2;
         constexpr int R = (RMAX > 0 && R0 > RMAX) ? RMAX : R0;
         for (uint32_t base = 0; base < n;) {
             const uint32_t left = n - base;
