@@ -29,10 +29,13 @@
  * (tests/test_oracle_kat.py):  distance KATs (distance_test.go:37-84,
  * lib.rs:423-458), heap pop orders (hnsw_heap_test.go:9-54), self-match ranks
  * first at ef=12/100 (pkg/client/client_test.go:171-236).
- * NOT reproduced, hence UNPINNED: the recall bar of clients/python/stress_test_recall.py:11-87 (recall@10 >= 0.95 on
- * 10k x 64 uniform L2 through single vadd calls = the sequential Add below).  The restated Add re-prunes full neighbour
- * lists over an UNSORTED candidate list, as :748-771 reads, and reaches 0.17 / 0.53 / 0.90 at ef 10 / 100 / 1000 on that
- * corpus (tests/test_oracle_kat.py); whether the reference really behaves so cannot be settled without a Go toolchain.
+ * NOT reproduced: the recall bar of clients/python/stress_test_recall.py:11-87 (recall@10 >= 0.95 on 10k x 64 uniform L2 through
+ * single vadd calls = the sequential Add below, queries = stored vectors, ef_search 0 -> ef = k = 10: ops.go:1006 passes the 0
+ * through, :2377-2380).  The restated Add re-prunes full neighbour lists over an UNSORTED candidate list, as :748-771 reads, and
+ * gives 0.41 there (0.64 at ef 100).  Round 6 (tests/test_oracle_add_trace.py): a SECOND restatement of Add / searchLayerUnlocked /
+ * selectNeighbors / the heaps, written in Python straight from the Go text, agrees with this one list for list after every insert
+ * (ties included) -- the number is the reference algorithm's as written, not a slip of this file; the script is not in the
+ * reference's CI and cannot run here (no Go toolchain).
  * The traversal (searchLayerUnlocked), on which the GPU parity tests rest, holds no test vectors in the reference at
  * all: its fidelity is by review against :2351-2611.
  * Bit-level accumulation order of the cosine kernel (gonum v0.16.0 Sdot amd64
