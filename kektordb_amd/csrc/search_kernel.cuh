@@ -491,6 +491,11 @@ static int launch_search_bs(kdb_index *idx, const KdbView &v, const void *d_q, c
             if (B <= wide2_max) return launch_any(wk2, hw, 2u, wlds);
         }
     }
+    // (Round 6 built "two queries per wave" for short rows -- docs/probes/r06_search_pair.cuh: one walk per 32-lane half, every
+    // wave-uniform value of this walk kept per half, ballots split, cross-lane reads inside the half; bit-exact at the first run -- and
+    // measured it on the GloVe-100 shape, 8192 queries: efS 20 0.450 ms against 0.455 here, efS 100 1.27 ms against 0.93: what is scalar
+    // bookkeeping for one query per wave becomes vector work per half (a half-ballot is five instructions, not one), and a four-slot
+    // beam per half triples the insertion: more instructions per QUERY, not fewer.  Not shipped.)
     if constexpr (BS == 1 || BS == 2 || BS == 4) {
         if (hsize) return launch(hnsw_search_kernel<PREC, METRIC, NCH, BS, 1>, hsize);
     }
