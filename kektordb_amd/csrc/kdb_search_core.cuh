@@ -120,6 +120,17 @@ __device__ __forceinline__ void wave_lds_fence() {
 // toolchain places before the exec restore of a join block -- scripts/tools/isa_check.py)
 __device__ __forceinline__ float kdb_sane_key(float key) { return key != key ? INFINITY : key; }
 
+// LDS word i when i < n, else `other`: the read itself is unconditional (a stale word of the workgroup's own LDS is harmless and a
+// select costs one instruction where a conditional read costs three scalar ones around it); i stays inside the allocation for every caller
+__device__ __forceinline__ uint32_t lds_u32_or(const uint32_t *p, uint32_t i, uint32_t n, uint32_t other) {
+    const uint32_t x = p[i];
+    return i < n ? x : other;
+}
+__device__ __forceinline__ float lds_f32_or(const float *p, uint32_t i, uint32_t n, float other) {
+    const float x = p[i];
+    return i < n ? x : other;
+}
+
 template <int PREC, int METRIC, int NCH = 0, int RMAX = 0>
 __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s, uint32_t n, float qnorm) {
     const int lane = kdb_lane();
@@ -135,7 +146,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                    const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                    const uint32_t id = lds_u32_or(s.nb_id, rr[r], n, 0u); // row 0 is all zero
                     rows[r] = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
                 }
                 float p[R];
@@ -148,7 +159,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                 base += 4u * R;
             } else if (left > 4u) { // 5..8 rows: two per group
                 const uint32_t r0 = base + (uint32_t)g, r1 = r0 + 4u;
-                const uint32_t id0 = s.nb_id[r0], id1 = r1 < n ? s.nb_id[r1] : 0u;
+                const uint32_t id0 = s.nb_id[r0], id1 = lds_u32_or(s.nb_id, r1, n, 0u);
                 float p0, p1;
                 kdb_row_partial2_f32<METRIC, NCH>(reinterpret_cast<const float *>(v.rows) + (size_t)id0 * v.ld,
                                                   reinterpret_cast<const float *>(v.rows) + (size_t)id1 * v.ld, s.q, t, p0, p1, v.ld >> 2);
@@ -159,7 +170,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
                 base += 8u;
             } else { // 1..4 rows
                 const uint32_t r0 = base + (uint32_t)g;
-                const uint32_t id0 = r0 < n ? s.nb_id[r0] : 0u;
+                const uint32_t id0 = lds_u32_or(s.nb_id, r0, n, 0u);
                 const float p = kdb_row_partial_f32<METRIC, NCH>(reinterpret_cast<const float *>(v.rows) + (size_t)id0 * v.ld, s.q, v.ld, t);
                 const float k0 = kdb_key_from_raw<PREC, METRIC>(kdb_reduce16(p));
                 if (r0 < n && t == 0) s.nb_d[r0] = kdb_sane_key(k0);
@@ -177,7 +188,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                const uint32_t id = lds_u32_or(s.nb_id, rr[r], n, 0u); // row 0 is all zero
                 rows[r] = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld;
             }
             float p[R];
@@ -199,7 +210,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                ids[r] = rr[r] < n ? s.nb_id[rr[r]] : 0u;
+                ids[r] = lds_u32_or(s.nb_id, rr[r], n, 0u);
                 rows[r] = reinterpret_cast<const int8_t *>(v.rows) + (size_t)ids[r] * v.ld;
             }
             int p[R];
@@ -227,7 +238,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                const uint32_t id = lds_u32_or(s.nb_id, rr[r], n, 0u); // row 0 is all zero
                 rows[r] = reinterpret_cast<const uint16_t *>(v.rows) + (size_t)id * v.ld;
             }
             float p[R];
@@ -249,7 +260,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                ids[r] = rr[r] < n ? s.nb_id[rr[r]] : 0u;
+                ids[r] = lds_u32_or(s.nb_id, rr[r], n, 0u);
                 rows[r] = reinterpret_cast<const int8_t *>(v.rows) + (size_t)ids[r] * v.ld;
             }
             int p[R];
@@ -278,7 +289,7 @@ __device__ __forceinline__ void compute_dists(const KdbView &v, const WaveLds &s
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     rr[r] = base + 4u * (uint32_t)r + (uint32_t)g;
-                    const uint32_t id = rr[r] < n ? s.nb_id[rr[r]] : 0u; // row 0 is all zero
+                    const uint32_t id = lds_u32_or(s.nb_id, rr[r], n, 0u); // row 0 is all zero
                     rows[r] = reinterpret_cast<const float *>(v.rows) + (size_t)id * v.ld;
                 }
                 float p[R];
@@ -1569,13 +1580,13 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         wave_lds_fence();
         // soft-delete flags of the new neighbours (Node.Deleted), fetched beside the row gather;
         // skipped when the index holds no deleted node
-        const uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
+        const uint32_t my_id = lds_u32_or(s.nb_id, (uint32_t)lane, n, 0u);
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;
         KDB_T(const unsigned long long tq1 = __builtin_readcyclecounter();)
         compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
         ctr.n_dist += n;
         const bool my_nr = ((delw >> (my_id & 31)) & 1u) != 0;
-        const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
+        const float my_d = lds_f32_or(s.nb_d, (uint32_t)lane, n, INFINITY);
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // candidates that can pass "len(results) < ef || d < worst" (worst only shrinks)
         const unsigned long long pass = __ballot((uint32_t)lane < n && (b.n_res < ef || key_lt<WK>(my_d, my_lo, b.worst, b.worst_lo)));
@@ -1639,8 +1650,8 @@ __device__ void search_layer_wide(const KdbView &v, const WaveLds &s, BeamT &b, 
         if (n == KDB_W_N_SKIP) continue; // :2524-2527 node lacks this level
         ctr.n_hops++;
         if (n == 0) continue;
-        const uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
-        const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : INFINITY;
+        const uint32_t my_id = lds_u32_or(s.nb_id, (uint32_t)lane, n, 0u);
+        const float my_d = lds_f32_or(s.nb_d, (uint32_t)lane, n, INFINITY);
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // soft-delete flags of the new neighbours (Node.Deleted); skipped when the index holds no deleted node
         const uint32_t delw = ((uint32_t)lane < n && v.has_deleted) ? v.deleted[my_id >> 5] : 0u;

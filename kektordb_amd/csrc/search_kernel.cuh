@@ -66,7 +66,7 @@ constexpr int kdb_search_minw() {
     if (WIDE == 4 && KDB_WIDE4_MINW) return NCH > 16 ? KDB_WIDE4_MINW_LONG : NCH == 0 ? (KDB_WIDE4_MINW > 3 ? 3 : KDB_WIDE4_MINW) : KDB_WIDE4_MINW; // (any-width rows: two registers short at 128)
     if (WIDE == 2 && NCH > 16) return 2;
     if (PREC == KDB_PREC_I8) return 4;
-    if (PREC == KDB_PREC_F16) return KDB_F16_MINW;
+    if (PREC == KDB_PREC_F16) return NCH > 16 ? 2 : KDB_F16_MINW; // (1536 columns: three waves per SIMD spilled ~40 registers -- and the gate found a reload ahead of an exec restore there)
     return NCH > 12 ? 2 : NCH > 6 ? KDB_F32_MINW : NCH > 4 ? KDB_F32_MINW6 : NCH == 0 ? KDB_GENERIC_MINW : KDB_SEARCH_MINW; // wide rows keep 16+ float4 per lane in flight
 }
 template <int PREC, int METRIC, int NCH, int BS, int VIS, int WIDE = 1>
