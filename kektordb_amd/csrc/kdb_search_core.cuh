@@ -1285,8 +1285,10 @@ __device__ __forceinline__ void insert_candidates(const KdbView &v, const WaveLd
 #pragma unroll
                 for (int q = 0; q < S; q++) {
                     const bool live = 64u * q + (uint32_t)lane < ncount;
-                    b.d[q] = live ? s.ins_d[64u * q + lane] : INFINITY;
-                    b.id[q] = live ? s.ins_id[64u * q + lane] : 0u;
+                    const float xd = s.ins_d[64u * q + lane]; // (unconditional reads + selects: see lds_u32_or)
+                    const uint32_t xi = s.ins_id[64u * q + lane];
+                    b.d[q] = live ? xd : INFINITY;
+                    b.id[q] = live ? xi : 0u;
                 }
                 wave_lds_fence();
                 // the pop scan restarts at the nearest newcomer if that lies before the scan position
@@ -1567,7 +1569,8 @@ __device__ void search_layer(const KdbView &v, const WaveLds &s, BeamT &b, VisT 
         }
         ctr.n_hops++;
         KDB_T(const unsigned long long tq0 = __builtin_readcyclecounter(); if (level == 0) ctr.t_pop += tq0 - tq_a;)
-        const uint32_t nb = (uint32_t)lane < deg ? adj[lane] : 0u;
+        const uint32_t nbx = adj[(uint32_t)lane < deg ? (uint32_t)lane : deg - 1u]; // (unconditional: a lane past the list re-reads its last word)
+        const uint32_t nb = (uint32_t)lane < deg ? nbx : 0u;
         KDB_T(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tq_v = __builtin_readcyclecounter();)
         // visited test-and-set (:2539-2542)
         bool fresh = vis.test_and_set(nb, nb != 0u && nb <= v.count);
