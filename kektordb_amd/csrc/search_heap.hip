@@ -399,12 +399,12 @@ __device__ uint32_t heap_layer(const KdbView &v, const WaveLds &s, VisT &vis, Re
         if (fresh) s.nb_id[kdb_mbcnt(m)] = nb; // stored order preserved
         wave_lds_fence();
         // the Deleted bit of every fresh neighbour, requested beside the rows (the decisions below read it from a register)
-        const uint32_t my_id = (uint32_t)lane < n ? s.nb_id[lane] : 0u;
+        const uint32_t my_id = lds_u32_or(s.nb_id, (uint32_t)lane, n, 0u);
         const uint32_t my_del = (v.has_deleted && (uint32_t)lane < n) ? ((v.deleted[my_id >> 5] >> (my_id & 31u)) & 1u) : 0u;
         KDB_HT(const unsigned long long h2 = __builtin_readcyclecounter(); t_vis += h2 - h1;)
         compute_dists<PREC, METRIC, NCH>(v, s, n, qnorm);
         ctr.n_dist += n;
-        const float my_d = (uint32_t)lane < n ? s.nb_d[lane] : 0.f;
+        const float my_d = lds_f32_or(s.nb_d, (uint32_t)lane, n, 0.f);
         const uint32_t my_lo = (WK && (uint32_t)lane < n) ? s.nb_lo[lane] : 0u;
         // One by one, in stored order (:2555-2591).  A neighbour that does not beat the worst result NOW cannot beat it later in this
         // hop either (the worst of a full result set only comes nearer): those are skipped in one ballot.
